@@ -1,0 +1,205 @@
+"""ctypes bindings of the native libraries (built in-tree under igd_amd/lib by `make`).
+
+Nothing here computes overlaps: every search entry point ends in libigd_hip.so (hand-written
+HIP for gfx950).  If a library is missing this module raises -- there is no Python or CPU
+fallback."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIBDIR = os.path.join(HERE, "lib")
+
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+
+class NativeMissing(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every native target for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", ROOT, "all"], stdout=out)
+
+
+def _load(name):
+    path = os.path.join(LIBDIR, name)
+    if not os.path.exists(path):
+        raise NativeMissing(
+            "%s not built: run `make` (or `python -c 'import __graft_entry__ as g; g.build()'`) "
+            "in %s -- igd_amd has no fallback path" % (path, ROOT))
+    return C.CDLL(path)
+
+
+class HipDesc(C.Structure):
+    _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("nFiles", C.c_int32),
+                ("nTile", i32p), ("nCnt", i32p), ("records", C.c_void_p), ("nRecords", C.c_int64)]
+
+
+class HipHit(C.Structure):
+    _fields_ = [("q", C.c_int32), ("idx", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
+
+
+class HipStats(C.Structure):
+    _fields_ = [("queries", C.c_int64), ("pairs", C.c_int64), ("S", C.c_int64), ("B", C.c_int64),
+                ("H", C.c_int64)]
+
+
+class CoreDb(C.Structure):
+    """struct igdc_db of igd_amd/csrc/igd_core.h"""
+    _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("nFiles", C.c_int32),
+                ("nTile", i32p), ("nCntFlat", i32p), ("nCnt", C.POINTER(i32p)),
+                ("tIdxFlat", i64p), ("tIdx", C.POINTER(i64p)),
+                ("cName", C.POINTER(C.c_char_p)), ("fileName", C.POINTER(C.c_char_p)),
+                ("fileNr", i32p), ("fileMd", C.POINTER(C.c_double)),
+                ("nTileTotal", C.c_int64), ("nRecords", C.c_int64), ("dataOff", C.c_int64),
+                ("dict", i32p), ("dictCap", C.c_int32), ("dev", C.c_void_p)]
+
+
+class CoreQueries(C.Structure):
+    _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("ichr", i32p), ("qs", i32p), ("qe", i32p)]
+
+
+IGD_HIP_RULE_NEST = 0
+IGD_HIP_RULE_FLAT = 1
+IGD_HIP_NO_VALUE_FILTER = -(2 ** 31)
+
+_hip = None
+_cli = None
+_py = None
+_synth = None
+_r = None
+
+
+def hip():
+    """libigd_hip.so -- include/igd_hip.h"""
+    global _hip
+    if _hip is None:
+        L = _load("libigd_hip.so")
+        L.igd_hip_device_count.restype = C.c_int
+        L.igd_hip_last_error.restype = C.c_char_p
+        L.igd_hip_open.argtypes = [C.POINTER(HipDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.igd_hip_close.argtypes = [C.c_void_p]
+        L.igd_hip_nfiles.argtypes = [C.c_void_p]
+        L.igd_hip_nfiles.restype = C.c_int32
+        L.igd_hip_resident_bytes.argtypes = [C.c_void_p]
+        L.igd_hip_resident_bytes.restype = C.c_int64
+        L.igd_hip_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_int32, C.c_int, C.c_void_p, i64p]
+        L.igd_hip_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igd_hip_max_batch.restype = C.c_int64
+        L.igd_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.igd_hip_enumerate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.POINTER(C.POINTER(HipHit)), i64p]
+        L.igd_hip_free.argtypes = [C.c_void_p]
+        L.igd_hip_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_int32, C.c_int, C.POINTER(HipStats)]
+        L.igd_hip_profile_begin.argtypes = [C.c_void_p, C.c_int]
+        L.igd_hip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double)]
+        L.igd_hip_scan_kernel_name.restype = C.c_char_p
+        _hip = L
+    return _hip
+
+
+def _bind_core(L):
+    L.igdc_open.restype = C.POINTER(CoreDb)
+    L.igdc_open.argtypes = [C.c_char_p]
+    L.igdc_index_path.restype = C.c_void_p
+    L.igdc_index_path.argtypes = [C.c_char_p]
+    L.igdc_load_index.argtypes = [C.POINTER(CoreDb), C.c_char_p]
+    L.igdc_close.argtypes = [C.POINTER(CoreDb)]
+    L.igdc_get_id.argtypes = [C.POINTER(CoreDb), C.c_char_p]
+    L.igdc_get_id.restype = C.c_int32
+    L.igdc_attach_path.argtypes = [C.POINTER(CoreDb), C.c_char_p, C.c_int]
+    L.igdc_parse_bed.restype = C.c_void_p
+    L.igdc_parse_bed.argtypes = [C.c_char_p, i32p, i32p, C.c_int]
+    L.igdc_read_queries.argtypes = [C.POINTER(CoreDb), C.c_char_p, C.c_int, C.POINTER(CoreQueries)]
+    L.igdc_queries_free.argtypes = [C.POINTER(CoreQueries)]
+    L.igdc_create_from_beds.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+    return L
+
+
+def cli():
+    """libigd.so -- include/igd_search.h + include/igd_base.h (+ the igdc_* core)"""
+    global _cli
+    if _cli is None:
+        hip()
+        L = _bind_core(_load("libigd.so"))
+        L.igd_search.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.get_igdinfo.restype = C.c_void_p
+        L.get_igdinfo.argtypes = [C.c_char_p]
+        L.get_id.argtypes = [C.c_char_p]
+        L.get_id.restype = C.c_int32
+        L.parse_bed.restype = C.c_void_p
+        L.parse_bed.argtypes = [C.c_char_p, i32p, i32p]
+        L.bSearch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.bSearch.restype = C.c_int32
+        _cli = L
+    return _cli
+
+
+def pyabi():
+    """libigd_py.so -- include/igd_py_abi.h"""
+    global _py
+    if _py is None:
+        hip()
+        L = _load("libigd_py.so")
+        L.iGD_init.restype = C.c_void_p
+        L.get_nFiles.argtypes = [C.c_void_p]
+        L.get_nFiles.restype = C.c_int32
+        L.open_iGD.argtypes = [C.c_void_p, C.c_char_p]
+        L.close_iGD.argtypes = [C.c_void_p]
+        L.create_iGD.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+        L.get_overlaps.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, i64p]
+        L.get_overlaps.restype = None
+        L.getOverlaps.argtypes = [C.c_void_p, C.c_char_p, i64p]
+        L.getOverlaps.restype = C.c_int64
+        _py = L
+    return _py
+
+
+def rabi():
+    """libigdr.so -- include/igdr_abi.h (plain-C / .C entry points)"""
+    global _r
+    if _r is None:
+        hip()
+        L = _load("libigdr.so")
+        L.open_iGD.restype = C.c_void_p
+        L.open_iGD.argtypes = [C.c_char_p]
+        L.close_iGD.argtypes = [C.c_void_p]
+        L.get_overlaps32.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, i32p]
+        L.igdr_search_n32.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p]
+        L.search_1.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32p, i32p, i64p]
+        L.getOverlaps.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i64p]
+        _r = L
+    return _r
+
+
+def synth():
+    """libigd_synth.so -- tools/igd_synth.c"""
+    global _synth
+    if _synth is None:
+        hip()
+        L = _load("libigd_synth.so")
+        L.igd_synth_db.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int,
+                                   C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int]
+        L.igd_synth_db_beds.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int, C.c_int,
+                                        C.c_int32, C.c_int32]
+        L.igd_synth_queries.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int32, C.c_int32, C.c_int,
+                                        C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igd_synth_queries.restype = C.c_int64
+        L.igd_synth_write_bed.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igd_synth_contig_name.restype = C.c_char_p
+        L.igd_synth_contig_name.argtypes = [C.c_int, C.c_int]
+        L.igd_synth_ncontigs.argtypes = [C.c_int]
+        _synth = L
+    return _synth
+
+
+def free(ptr):
+    C.CDLL(None).free(C.c_void_p(ptr))

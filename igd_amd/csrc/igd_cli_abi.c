@@ -1,0 +1,436 @@
+/* igd_cli_abi.c -- the CLI/libigd flavour of the reference ABI (include/igd_search.h,
+ * include/igd_base.h) on top of the host core (igd_core.c) and the HIP engine (igd_hip.h).
+ *
+ * Every function keeps the name, prototype, return value and silent-failure behaviour of
+ * its counterpart in /root/reference/src/igd_search.c / igd_base.c (lines cited at each
+ * definition).  What differs is how the answer is computed: the whole tile region is put on
+ * the GPU once and every call -- single query or query file -- is one batch for the engine.
+ * There is no CPU search here; if no HIP device is usable the process stops with a message.
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <string.h>
+#include <sysexits.h>
+
+#include "igd_search.h"
+#include "igd_core.h"
+
+/* process-wide state of this flavour (reference: src/igd.c:14-19) */
+void     *hc = NULL;
+iGD_t    *IGD = NULL;
+gdata_t  *gData = NULL;
+gdata0_t *gData0 = NULL;
+int32_t   preIdx = 0, preChr = 0, tile_size = 16384;
+FILE     *fP = NULL;
+
+/* our side of an iGD_t handed out by get_igdinfo */
+static igdc_db *g_core = NULL;       /* header tables + dictionary + device handle        */
+static iGD_t   *g_core_of = NULL;    /* the iGD_t that g_core mirrors                      */
+static char    *g_core_path = NULL;
+
+static int device_from_env(void)
+{
+    const char *e = getenv("IGD_DEVICE");
+    return e && *e ? atoi(e) : 0;
+}
+
+static void die_no_gpu(const char *where, int rc)
+{
+    fprintf(stderr, "igd: %s: GPU engine unavailable (code %d): %s\n"
+                    "igd: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
+    exit(EX_UNAVAILABLE);
+}
+
+/* The engine for the current IGD, created at the first search call: this is the moment the
+ * reference would do its first fseek/fread on fP (src/igd_search.c:469-476). */
+static igd_hip_db *engine(void)
+{
+    if (!IGD || !g_core || g_core_of != IGD) {
+        fprintf(stderr, "igd: search called before get_igdinfo()\n");
+        exit(EX_SOFTWARE);
+    }
+    if (g_core->dev && igd_hip_nfiles(g_core->dev) == IGD->nFiles) return g_core->dev;
+    g_core->nFiles = IGD->nFiles;        /* hits[] is sized from the TSV (:923-925) */
+    int rc = fP ? igdc_attach_fp(g_core, fP, device_from_env())
+                : igdc_attach_path(g_core, g_core_path, device_from_env());
+    if (rc != IGD_HIP_OK) die_no_gpu("open", rc);
+    return g_core->dev;
+}
+
+/* ------------------------------- base ------------------------------------------------- */
+char *parse_bed(char *s, int32_t *st_, int32_t *en_)                /* src/igd_base.c:53-72 */
+{
+    return igdc_parse_bed(s, st_, en_, 1);
+}
+
+int32_t bSearch(gdata_t *g, int32_t t0, int32_t tc, int32_t qe)    /* src/igd_base.c:74-94 */
+{
+    /* last index in [t0,tc] whose start < qe; -1 when there is none */
+    if (tc < t0 || g[t0].start >= qe) return -1;
+    int32_t lo = t0, hi = tc;            /* invariant: g[lo].start < qe */
+    while (lo < hi) {
+        int32_t mid = lo + (hi - lo + 1) / 2;
+        if (g[mid].start < qe) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+int32_t get_id(const char *chrm)                                   /* src/igd_base.c:325-331 */
+{
+    return igdc_get_id((const igdc_db *)hc, chrm);
+}
+
+info_t *get_fileinfo(char *ifName, int32_t *nFiles)                /* src/igd_base.c:235-267 */
+{
+    igdc_db tmp;
+    memset(&tmp, 0, sizeof tmp);
+    if (igdc_load_index(&tmp, ifName) != 0) {
+        printf("file not found:%s\n", ifName);
+        return NULL;
+    }
+    info_t *fi = (info_t *)malloc(sizeof(info_t) * (size_t)(tmp.nFiles + 1));
+    for (int32_t i = 0; i < tmp.nFiles; i++) {
+        fi[i].fileName = tmp.fileName[i];      /* ownership moves to the caller, as strdup'd */
+        fi[i].nr = tmp.fileNr[i];
+        fi[i].md = tmp.fileMd[i];
+    }
+    *nFiles = tmp.nFiles;
+    free(tmp.fileName); free(tmp.fileNr); free(tmp.fileMd);
+    return fi;
+}
+
+iGD_t *get_igdinfo(char *igdFile)                                  /* src/igd_base.c:269-323 */
+{
+    igdc_db *core = igdc_open(igdFile);
+    if (!core) {
+        printf("Can't open file %s", igdFile);
+        return NULL;
+    }
+    /* hand out the tables in the allocation shape the reference's callers free
+     * (src/igd_search.c:1067-1076: nTile, each nCnt[i]/tIdx[i], the arrays, then IGD) */
+    iGD_t *g = (iGD_t *)calloc(1, sizeof *g);
+    const int32_t m = core->nCtg;
+    g->nbp = core->nbp; g->gType = core->gType; g->nCtg = m;
+    g->nTile = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    g->nCnt = (int32_t **)malloc(sizeof(int32_t *) * (size_t)(m + 1));
+    g->tIdx = (int64_t **)malloc(sizeof(int64_t *) * (size_t)(m + 1));
+    g->cName = (char **)malloc(sizeof(char *) * (size_t)(m + 1));
+    for (int32_t c = 0; c < m; c++) {
+        const int32_t k = core->nTile[c];
+        g->nTile[c] = k;
+        g->nCnt[c] = (int32_t *)calloc((size_t)k + 1, sizeof(int32_t));
+        g->tIdx[c] = (int64_t *)calloc((size_t)k + 1, sizeof(int64_t));
+        memcpy(g->nCnt[c], core->nCnt[c], sizeof(int32_t) * (size_t)k);
+        memcpy(g->tIdx[c], core->tIdx[c], sizeof(int64_t) * (size_t)k);
+        g->cName[c] = (char *)malloc(40);
+        memcpy(g->cName[c], core->cName[c], 40);
+    }
+    if (g_core) igdc_close(g_core);
+    free(g_core_path);
+    g_core = core;
+    g_core_of = g;
+    g_core_path = strdup(igdFile);
+    hc = core;                         /* the dictionary lives in the core */
+    tile_size = core->nbp;
+    return g;
+}
+
+/* ------------------------------- one query -------------------------------------------- */
+static int32_t one_query(const char *chrm, int32_t qs, int32_t qe, int32_t v, int rule, int64_t *hits)
+{
+    int32_t ichr = get_id(chrm);
+    if (ichr < 0) return 0;                                   /* :456-457 */
+    igd_hip_db *dev = engine();
+    int64_t total = 0;
+    int rc = igd_hip_search(dev, &ichr, &qs, &qe, 1, v, rule, hits, &total);
+    if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+    return (int32_t)total;
+}
+
+int32_t get_overlaps(char *chrm, int32_t qs, int32_t qe, int64_t *hits)      /* :454-534 */
+{
+    one_query(chrm, qs, qe, IGD_HIP_NO_VALUE_FILTER, IGD_HIP_RULE_NEST, hits);
+    return 0;                           /* the reference's nols is never incremented (:533) */
+}
+
+int32_t get_overlaps0(char *chrm, int32_t qs, int32_t qe, int64_t *hits)     /* :30-112 */
+{
+    one_query(chrm, qs, qe, IGD_HIP_NO_VALUE_FILTER, IGD_HIP_RULE_NEST, hits);
+    return 0;
+}
+
+int32_t get_overlaps_v(char *chrm, int32_t qs, int32_t qe, int32_t v, int64_t *hits) /* :623-694 */
+{
+    /* the driver calls this only for v>0 (:1027); any v keeps the predicate value>=v */
+    return one_query(chrm, qs, qe, v, IGD_HIP_RULE_FLAT, hits);
+}
+
+/* ------------------------------- query files ------------------------------------------ */
+static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
+{
+    if (!g_core || g_core_of != IGD) { engine(); }
+    igdc_queries q;
+    if (igdc_read_queries(g_core, qFile, 1, &q) != 0) return 0;      /* :701-702 */
+    int64_t total = 0;
+    if (q.n > 0) {
+        igd_hip_db *dev = engine();
+        int rc = igd_hip_search(dev, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total);
+        if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+    }
+    igdc_queries_free(&q);
+    return total;
+}
+
+int64_t getOverlaps(char *qFile, int64_t *hits)                              /* :696-719 */
+{
+    file_query(qFile, IGD_HIP_NO_VALUE_FILTER, IGD_HIP_RULE_NEST, hits);
+    return 0;                           /* sum of get_overlaps returns = 0 */
+}
+
+int64_t getOverlaps0(char *qFile, int64_t *hits)                             /* :202-225 */
+{
+    file_query(qFile, IGD_HIP_NO_VALUE_FILTER, IGD_HIP_RULE_NEST, hits);
+    return 0;
+}
+
+int64_t getOverlaps_v(char *qFile, int64_t *hits, int32_t v)                 /* :746-769 */
+{
+    return file_query(qFile, v, IGD_HIP_RULE_FLAT, hits);
+}
+
+/* ------------------------------- full enumeration (-f) -------------------------------- */
+typedef struct { char *buf; size_t n, cap; } obuf;
+static void ob_flush(obuf *o) { if (o->n) fwrite(o->buf, 1, o->n, stdout); o->n = 0; }
+static void ob_room(obuf *o, size_t need) { if (o->n + need > o->cap) ob_flush(o); }
+static void ob_int(obuf *o, int32_t x)
+{
+    char t[12];
+    int k = 0;
+    uint32_t u = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
+    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (x < 0) o->buf[o->n++] = '-';
+    while (k) o->buf[o->n++] = t[--k];
+}
+static void ob_str(obuf *o, const char *s, size_t L) { memcpy(o->buf + o->n, s, L); o->n += L; }
+
+/* Prints what get_overlaps_f1/_f0 print for each query of the batch, in order
+ * ("Query %s, %i, %i: \n" at :548, one "%i\t %i\t %i\t %s\n" per overlap at :577,:610). */
+static int64_t enumerate_and_print(const igdc_queries *q, char **names)
+{
+    if (q->n == 0) return 0;
+    igd_hip_db *dev = engine();
+    int64_t *qoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->n + 1));
+    igd_hip_hit *hit = NULL;
+    int64_t total = 0, grand = 0;
+    obuf o;
+    o.cap = 1 << 20; o.n = 0; o.buf = (char *)malloc(o.cap + 4096);
+    const int64_t step = igd_hip_max_batch();
+    for (int64_t q0 = 0; q0 < q->n; q0 += step) {
+        int64_t m = q->n - q0 < step ? q->n - q0 : step;
+        int rc = igd_hip_enumerate(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, &hit, &total);
+        if (rc != IGD_HIP_OK) die_no_gpu("enumerate", rc);
+        for (int64_t i = 0; i < m; i++) {
+            const int32_t c = q->ichr[q0 + i], qs = q->qs[q0 + i], qe = q->qe[q0 + i];
+            const int32_t n1 = qs / IGD->nbp;
+            if (n1 > IGD->nTile[c] - 1 || n1 < 0) continue;           /* :544-545 */
+            ob_room(&o, 128);
+            ob_str(&o, "Query ", 6);
+            ob_str(&o, names[q0 + i], strlen(names[q0 + i]));
+            ob_str(&o, ", ", 2); ob_int(&o, qs); ob_str(&o, ", ", 2); ob_int(&o, qe);
+            ob_str(&o, ": \n", 3);
+            int32_t k = 0;
+            for (int64_t h = qoff[i]; h < qoff[i + 1]; h++, k++) {
+                const char *fn = IGD->finfo[hit[h].idx].fileName;
+                size_t L = strlen(fn);
+                ob_room(&o, 64 + L);
+                if (L + 64 > o.cap) { ob_flush(&o); printf("%i\t %i\t %i\t %s\n", k, hit[h].start, hit[h].end, fn); continue; }
+                ob_int(&o, k); ob_str(&o, "\t ", 2); ob_int(&o, hit[h].start); ob_str(&o, "\t ", 2);
+                ob_int(&o, hit[h].end); ob_str(&o, "\t ", 2); ob_str(&o, fn, L); o.buf[o.n++] = '\n';
+            }
+        }
+        igd_hip_free(hit);
+        hit = NULL;
+        grand += total;
+    }
+    ob_flush(&o);
+    free(o.buf);
+    free(qoff);
+    return grand;
+}
+
+static int64_t file_enumerate(const char *qFile)
+{
+    if (!g_core || g_core_of != IGD) engine();
+    igdc_lines *r = igdc_lines_open(qFile);
+    if (!r) return 0;
+    igdc_queries q;
+    memset(&q, 0, sizeof q);
+    char **names = NULL;
+    int64_t ncap = 0;
+    char *line;
+    while ((line = igdc_lines_next(r, NULL)) != NULL) {
+        int32_t st, en;
+        char *chrm = igdc_parse_bed(line, &st, &en, 1);
+        if (!chrm) continue;
+        int32_t id = igdc_get_id(g_core, chrm);
+        if (id < 0) continue;
+        if (q.n == ncap) {
+            ncap = ncap ? ncap * 2 : 4096;
+            names = (char **)realloc(names, sizeof(char *) * (size_t)ncap);
+        }
+        names[q.n] = g_core->cName[id];    /* the accepted name equals the stored one */
+        igdc_queries_push(&q, id, st, en);
+    }
+    igdc_lines_close(r);
+    int64_t total = enumerate_and_print(&q, names);
+    igdc_queries_free(&q);
+    free(names);
+    return total;
+}
+
+int64_t getOverlaps_f1(char *qFile) { return file_enumerate(qFile); }        /* :721-744 */
+int64_t getOverlaps_f0(char *qFile) { return file_enumerate(qFile); }        /* :227-250 */
+
+static int32_t one_enumerate(char *chrm, int32_t qs, int32_t qe)
+{
+    int32_t ichr = get_id(chrm);
+    if (ichr < 0) return 0;
+    igdc_queries q;
+    memset(&q, 0, sizeof q);
+    igdc_queries_push(&q, ichr, qs, qe);
+    char *name = chrm;
+    int64_t total = enumerate_and_print(&q, &name);
+    igdc_queries_free(&q);
+    return (int32_t)total;
+}
+
+int32_t get_overlaps_f1(char *chrm, int32_t qs, int32_t qe) { return one_enumerate(chrm, qs, qe); } /* :537-620 */
+int32_t get_overlaps_f0(char *chrm, int32_t qs, int32_t qe) { return one_enumerate(chrm, qs, qe); } /* :114-200 */
+
+/* ------------------------------- `igd search` ----------------------------------------- */
+static int usage_search(void)
+{
+    fprintf(stderr,
+            "igd (MI355X build), search usage:\n"
+            "  igd search <igd database file> [options]\n"
+            "    -q <query file>            BED or BED.gz\n"
+            "    -r <chrN start end>        a single region\n"
+            "    -v <signal value 0-1000>   keep records with value >= v\n"
+            "    -f                         print every overlap (with -q or -r)\n"
+            "    -o <name>, -c              accepted, no effect on this path\n"
+            "    -s, -m                     Seqpare / hit map: not part of this build\n"
+            "  environment: IGD_DEVICE=<n> selects the GPU (default 0)\n");
+    return EX_OK;
+}
+
+int igd_search(int argc, char **argv)                                        /* :889-1079 */
+{
+    if (argc < 4) return usage_search();
+    char *igdName = argv[2];
+    size_t L = strlen(igdName);
+    if (L < 4 || strcmp(igdName + L - 4, ".igd") != 0) {                      /* :894-898 */
+        printf("%s is not an igd database", igdName);
+        return EX_OK;
+    }
+    FILE *probe = fopen(igdName, "rb");
+    if (!probe) {                                                             /* :899-903 */
+        printf("%s does not exist", igdName);
+        return EX_OK;
+    }
+    fclose(probe);
+
+    IGD = get_igdinfo(igdName);
+    if (!IGD) return EX_OK;
+    char *tsv = igdc_index_path(igdName);
+    {   /* fname = path without extension; the reference strcpy's into 64 bytes (:916-922) */
+        size_t stem = strlen(tsv) - strlen("_index.tsv");
+        if (stem > sizeof IGD->fname - 1) stem = sizeof IGD->fname - 1;
+        memcpy(IGD->fname, igdName, stem);
+        IGD->fname[stem] = '\0';
+    }
+    IGD->finfo = get_fileinfo(tsv, &IGD->nFiles);
+    free(tsv);
+    if (!IGD->finfo) return EX_OK;
+    const int32_t nfiles = IGD->nFiles;
+    int64_t *hits = (int64_t *)calloc((size_t)nfiles + 1, sizeof(int64_t));
+
+    int32_t v = 0, qs = 1, qe = 2;
+    int mode = -1, full = 0;
+    char *chrm = NULL, *qfName = (char *)"";
+    for (int i = 3; i < argc; i++) {                                          /* :931-971 */
+        const char *a = argv[i];
+        if (strcmp(a, "-q") == 0) {
+            if (i + 1 >= argc) { printf("No query file.\n"); return EX_OK; }
+            qfName = argv[i + 1];
+            mode = 1;
+        } else if (strcmp(a, "-r") == 0) {
+            if (i + 3 < argc) {
+                mode = 2;
+                chrm = argv[i + 1];
+                qs = atoi(argv[i + 2]);
+                qe = atoi(argv[i + 3]);
+            }
+        } else if (strcmp(a, "-v") == 0) {
+            if (i + 1 < argc) v = atoi(argv[i + 1]);
+        } else if (strcmp(a, "-m") == 0) {
+            mode = 0;
+        } else if (strcmp(a, "-s") == 0 && mode != 2) {
+            mode = 3;
+        } else if (strcmp(a, "-f") == 0) {
+            full = 1;
+        }
+    }
+
+    fP = fopen(igdName, "rb");                                                /* :974 */
+    if (full) {                                                               /* :975-995 */
+        if (mode == 1) {
+            int64_t total = IGD->gType == 0 ? getOverlaps_f0(qfName) : getOverlaps_f1(qfName);
+            printf("Total overlaps: %lld\n", (long long)total);
+        } else if (mode == 2) {
+            int64_t total = IGD->gType == 0 ? get_overlaps_f0(chrm, qs, qe) : get_overlaps_f1(chrm, qs, qe);
+            printf("Total overlaps: %lld\n", (long long)total);
+        } else {
+            printf("Not supported -f option\n");
+            return EX_OK;
+        }
+    } else if (mode == 1) {                                                   /* :1023-1040 */
+        if (IGD->gType == 0) getOverlaps0(qfName, hits);
+        else if (v > 0) getOverlaps_v(qfName, hits, v);
+        else getOverlaps(qfName, hits);
+        printf("index\t number of regions\t number of hits\t File_name\n");
+        int64_t total = 0;
+        for (int32_t i = 0; i < nfiles; i++) {
+            if (hits[i] > 0)
+                printf("%i\t%i\t%lld\t%s\n", i, IGD->finfo[i].nr, (long long)hits[i], IGD->finfo[i].fileName);
+            total += hits[i];
+        }
+        printf("Total: %lld\n", (long long)total);
+    } else if (mode == 2) {                                                   /* :1041-1053 */
+        if (IGD->gType == 0) get_overlaps0(chrm, qs, qe, hits);
+        else if (v > 0) get_overlaps_v(chrm, qs, qe, v, hits);
+        else get_overlaps(chrm, qs, qe, hits);
+        printf("index\t number of regions\t number of hits\t File_name\n");
+        for (int32_t i = 0; i < nfiles; i++)
+            printf("%i\t%i\t%lld\t%s\n", i, IGD->finfo[i].nr, (long long)hits[i], IGD->finfo[i].fileName);
+    } else if (mode == 0 || mode == 3) {
+        printf("igd: -m (hit map) and -s (Seqpare) are not part of the MI355X search build\n");
+    } else {
+        free(hits);
+        return usage_search();
+    }
+
+    /* release everything, in the shape get_igdinfo/get_fileinfo handed it out (:1066-1078) */
+    if (fP) { fclose(fP); fP = NULL; }
+    free(IGD->nTile);
+    for (int32_t c = 0; c < IGD->nCtg; c++) {
+        free(IGD->nCnt[c]); free(IGD->tIdx[c]); free(IGD->cName[c]);
+    }
+    for (int32_t i = 0; i < nfiles; i++) free(IGD->finfo[i].fileName);
+    free(IGD->nCnt); free(IGD->tIdx); free(IGD->cName); free(IGD->finfo);
+    free(IGD);
+    IGD = NULL;
+    free(hits);
+    if (g_core) { igdc_close(g_core); g_core = NULL; g_core_of = NULL; hc = NULL; }
+    free(g_core_path); g_core_path = NULL;
+    return EX_OK;
+}

@@ -1,0 +1,455 @@
+/* igd_core.c -- host core: .igd / _index.tsv loaders, contig dictionary, BED reader,
+ * GPU attach, minimal .igd writer.  See igd_core.h for the reference counterparts.
+ * No search is done here: every overlap count comes from the HIP engine (igd_hip.h). */
+#define _GNU_SOURCE
+#include "igd_core.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+/* ---------------------------------------------------------------------------------------
+ * contig dictionary: exact, case-sensitive name -> index (what the reference gets from
+ * khash, src/igd_base.c:313-331).  FNV-1a + linear probing; names are the NUL-terminated
+ * prefix of the 40-byte on-disk field (bytes after the NUL are garbage in real files). */
+static uint32_t name_hash(const char *s)
+{
+    uint32_t h = 2166136261u;
+    while (*s) h = (h ^ (unsigned char)*s++) * 16777619u;
+    return h;
+}
+
+static int dict_build(igdc_db *db)
+{
+    int32_t cap = 8;
+    while (cap < 4 * (db->nCtg + 1)) cap <<= 1;
+    db->dict = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    if (!db->dict) return -1;
+    db->dictCap = cap;
+    for (int32_t i = 0; i < cap; i++) db->dict[i] = -1;
+    for (int32_t c = 0; c < db->nCtg; c++) {
+        uint32_t p = name_hash(db->cName[c]) & (uint32_t)(cap - 1);
+        while (db->dict[p] >= 0 && strcmp(db->cName[db->dict[p]], db->cName[c]) != 0)
+            p = (p + 1) & (uint32_t)(cap - 1);
+        db->dict[p] = c;   /* a repeated name resolves to its LAST index, as kh_put+kh_val= does */
+    }
+    return 0;
+}
+
+int32_t igdc_get_id(const igdc_db *db, const char *chrm)
+{
+    if (!db || !db->dict || !chrm) return -1;
+    uint32_t p = name_hash(chrm) & (uint32_t)(db->dictCap - 1);
+    for (;;) {
+        int32_t c = db->dict[p];
+        if (c < 0) return -1;
+        if (strcmp(db->cName[c], chrm) == 0) return c;
+        p = (p + 1) & (uint32_t)(db->dictCap - 1);
+    }
+}
+
+/* --------------------------------------------------------------------------------------- */
+static int read_exact(FILE *fp, void *dst, size_t bytes)
+{
+    return bytes == 0 || fread(dst, 1, bytes, fp) == bytes ? 0 : -1;
+}
+
+igdc_db *igdc_open(const char *igd_path)
+{
+    FILE *fp = fopen(igd_path, "rb");
+    if (!fp) return NULL;
+    igdc_db *db = (igdc_db *)calloc(1, sizeof *db);
+    if (!db) { fclose(fp); return NULL; }
+    int32_t head[3];
+    if (read_exact(fp, head, sizeof head) != 0) goto bad;
+    db->nbp = head[0]; db->gType = head[1]; db->nCtg = head[2];
+    if (db->nbp <= 0 || db->nCtg < 0 || (db->gType != 0 && db->gType != 1)) goto bad;
+    const int32_t m = db->nCtg;
+    db->nTile = (int32_t *)calloc((size_t)m + 1, sizeof(int32_t));
+    if (!db->nTile || read_exact(fp, db->nTile, sizeof(int32_t) * (size_t)m) != 0) goto bad;
+    int64_t nT = 0;
+    for (int32_t c = 0; c < m; c++) {
+        if (db->nTile[c] < 0) goto bad;
+        nT += db->nTile[c];
+    }
+    db->nTileTotal = nT;
+    db->dataOff = 12 + 44 * (int64_t)m + 4 * nT;
+    db->nCntFlat = (int32_t *)calloc((size_t)nT + 1, sizeof(int32_t));
+    db->tIdxFlat = (int64_t *)calloc((size_t)nT + 1, sizeof(int64_t));
+    db->nCnt = (int32_t **)calloc((size_t)m + 1, sizeof(int32_t *));
+    db->tIdx = (int64_t **)calloc((size_t)m + 1, sizeof(int64_t *));
+    db->cName = (char **)calloc((size_t)m + 1, sizeof(char *));
+    if (!db->nCntFlat || !db->tIdxFlat || !db->nCnt || !db->tIdx || !db->cName) goto bad;
+    if (read_exact(fp, db->nCntFlat, sizeof(int32_t) * (size_t)nT) != 0) goto bad;
+    const int64_t recBytes = db->gType == 0 ? 12 : 16;
+    int64_t loc = db->dataOff, t = 0;
+    for (int32_t c = 0; c < m; c++) {
+        db->nCnt[c] = db->nCntFlat + t;
+        db->tIdx[c] = db->tIdxFlat + t;
+        for (int32_t j = 0; j < db->nTile[c]; j++, t++) {
+            if (db->nCntFlat[t] < 0) goto bad;
+            db->tIdxFlat[t] = loc;
+            loc += recBytes * (int64_t)db->nCntFlat[t];
+            db->nRecords += db->nCntFlat[t];
+        }
+    }
+    for (int32_t c = 0; c < m; c++) {
+        db->cName[c] = (char *)calloc(1, 41);
+        if (!db->cName[c] || read_exact(fp, db->cName[c], 40) != 0) goto bad;
+    }
+    fclose(fp);
+    if (dict_build(db) != 0) { igdc_close(db); return NULL; }
+    return db;
+bad:
+    fclose(fp);
+    igdc_close(db);
+    return NULL;
+}
+
+char *igdc_index_path(const char *igd_path)
+{
+    size_t L = strlen(igd_path);
+    char *p = (char *)malloc(L + 16);
+    if (!p) return NULL;
+    memcpy(p, igd_path, L + 1);
+    char *dot = strrchr(p, '.');
+    if (dot) *dot = '\0';
+    strcat(p, "_index.tsv");
+    return p;
+}
+
+/* one dataset per line after the header line: index \t name \t nr \t avg  (nr and avg read
+ * with atol, so avg loses its fraction: src/igd_base.c:258-261) */
+int igdc_load_index(igdc_db *db, const char *tsv_path)
+{
+    FILE *fp = fopen(tsv_path, "r");
+    if (!fp) return -1;
+    char line[1024];
+    int32_t n = 0;
+    if (!fgets(line, sizeof line, fp)) { fclose(fp); return -1; }
+    while (fgets(line, sizeof line, fp)) n++;
+    for (int32_t i = 0; i < db->nFiles; i++) free(db->fileName[i]);
+    free(db->fileName); free(db->fileNr); free(db->fileMd);
+    db->fileName = (char **)calloc((size_t)n + 1, sizeof(char *));
+    db->fileNr = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));
+    db->fileMd = (double *)calloc((size_t)n + 1, sizeof(double));
+    db->nFiles = n;
+    rewind(fp);
+    if (!fgets(line, sizeof line, fp)) { fclose(fp); return -1; }
+    for (int32_t i = 0; i < n && fgets(line, sizeof line, fp); i++) {
+        char *save = NULL;
+        char *col = strtok_r(line, "\t", &save);       /* index: position is what counts */
+        col = strtok_r(NULL, "\t", &save);
+        db->fileName[i] = strdup(col ? col : "");
+        col = strtok_r(NULL, "\t", &save);
+        db->fileNr[i] = col ? (int32_t)atol(col) : 0;
+        col = strtok_r(NULL, "\t", &save);
+        db->fileMd[i] = col ? (double)atol(col) : 0.0;
+    }
+    fclose(fp);
+    return 0;
+}
+
+void igdc_close(igdc_db *db)
+{
+    if (!db) return;
+    if (db->dev) igd_hip_close(db->dev);
+    if (db->cName)
+        for (int32_t c = 0; c < db->nCtg; c++) free(db->cName[c]);
+    if (db->fileName)
+        for (int32_t i = 0; i < db->nFiles; i++) free(db->fileName[i]);
+    free(db->cName); free(db->fileName); free(db->fileNr); free(db->fileMd);
+    free(db->nTile); free(db->nCntFlat); free(db->nCnt); free(db->tIdxFlat); free(db->tIdx);
+    free(db->dict);
+    free(db);
+}
+
+/* --------------------------------------------------------------------------------------- */
+static int attach_records(igdc_db *db, const void *records, int device)
+{
+    igd_hip_desc d;
+    memset(&d, 0, sizeof d);
+    d.nbp = db->nbp; d.gType = db->gType; d.nCtg = db->nCtg; d.nFiles = db->nFiles;
+    d.nTile = db->nTile; d.nCnt = db->nCntFlat; d.records = records; d.nRecords = db->nRecords;
+    if (db->dev) { igd_hip_close(db->dev); db->dev = NULL; }
+    return igd_hip_open(&d, device, &db->dev);
+}
+
+int igdc_attach_path(igdc_db *db, const char *igd_path, int device)
+{
+    const int64_t recBytes = db->gType == 0 ? 12 : 16;
+    const int64_t need = db->dataOff + recBytes * db->nRecords;
+    int fd = open(igd_path, O_RDONLY);
+    if (fd < 0) return IGD_HIP_ERR_ARG;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (int64_t)st.st_size < need) { close(fd); return IGD_HIP_ERR_ARG; }
+    if (db->nRecords == 0) { close(fd); return attach_records(db, NULL, device); }
+    void *map = mmap(NULL, (size_t)need, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return IGD_HIP_ERR_NOMEM;
+    (void)madvise(map, (size_t)need, MADV_SEQUENTIAL);
+    int rc = attach_records(db, (const char *)map + db->dataOff, device);
+    munmap(map, (size_t)need);
+    return rc;
+}
+
+int igdc_attach_fp(igdc_db *db, FILE *fp, int device)
+{
+    const size_t recBytes = db->gType == 0 ? 12 : 16;
+    size_t bytes = recBytes * (size_t)db->nRecords;
+    void *buf = malloc(bytes ? bytes : 1);
+    if (!buf) return IGD_HIP_ERR_NOMEM;
+    long keep = ftell(fp);
+    int ok = fseeko(fp, (off_t)db->dataOff, SEEK_SET) == 0 && read_exact(fp, buf, bytes) == 0;
+    if (keep >= 0) fseek(fp, keep, SEEK_SET);
+    int rc = ok ? attach_records(db, buf, device) : IGD_HIP_ERR_ARG;
+    free(buf);
+    return rc;
+}
+
+/* --------------------------------------------------------------------------------------- */
+char *igdc_parse_bed(char *line, int32_t *st, int32_t *en, int require_chr)
+{
+    char *field[3];
+    int nf = 0;
+    char *p = line;
+    field[nf++] = p;
+    for (; *p; ++p) {
+        if (*p == '\t') {
+            *p = '\0';
+            if (nf < 3) field[nf] = p + 1;
+            nf++;                         /* fields past the third are cut off, not kept */
+        }
+    }
+    int32_t s = -1, e = -1;
+    if (nf >= 2) s = (int32_t)atol(field[1]);
+    if (nf >= 3) e = (int32_t)atol(field[2]);
+    *st = s; *en = e;
+    if (nf < 3) return NULL;
+    if (!require_chr) return field[0];
+    const char *c = field[0];
+    if (c[0] == 'c' && c[1] == 'h' && c[2] == 'r' && strlen(c) < 40 && e > 0) return field[0];
+    return NULL;
+}
+
+struct igdc_lines {
+    gzFile f;
+    char *buf;
+    size_t cap, beg, end;
+    int eof;
+};
+
+igdc_lines *igdc_lines_open(const char *path)
+{
+    gzFile f = gzopen(path, "r");
+    if (!f) return NULL;
+    gzbuffer(f, 1 << 20);
+    igdc_lines *r = (igdc_lines *)calloc(1, sizeof *r);
+    r->f = f;
+    r->cap = 1 << 20;
+    r->buf = (char *)malloc(r->cap + 1);
+    return r;
+}
+
+void igdc_lines_close(igdc_lines *r)
+{
+    if (!r) return;
+    gzclose(r->f);
+    free(r->buf);
+    free(r);
+}
+
+/* Next line without its '\n'; one trailing '\r' is dropped when the line is longer than one
+ * character (src/kseq.h:127).  A final line without '\n' is returned too. */
+char *igdc_lines_next(igdc_lines *r, int64_t *len)
+{
+    for (;;) {
+        char *nl = (r->end > r->beg) ? (char *)memchr(r->buf + r->beg, '\n', r->end - r->beg) : NULL;
+        if (nl || (r->eof && r->end > r->beg)) {
+            char *s = r->buf + r->beg;
+            size_t L = nl ? (size_t)(nl - s) : r->end - r->beg;
+            r->beg += L + (nl ? 1 : 0);
+            if (!nl) r->beg = r->end;
+            if (L > 1 && s[L - 1] == '\r') L--;
+            s[L] = '\0';
+            if (len) *len = (int64_t)L;
+            return s;
+        }
+        if (r->eof) return NULL;
+        /* refill: keep the partial line at the front */
+        size_t have = r->end - r->beg;
+        if (r->beg > 0) {
+            memmove(r->buf, r->buf + r->beg, have);
+            r->beg = 0; r->end = have;
+        }
+        if (r->end == r->cap) {
+            r->cap *= 2;
+            r->buf = (char *)realloc(r->buf, r->cap + 1);
+        }
+        int got = gzread(r->f, r->buf + r->end, (unsigned)(r->cap - r->end));
+        if (got <= 0) r->eof = 1; else r->end += (size_t)got;
+    }
+}
+
+int igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe)
+{
+    if (q->n == q->cap) {
+        int64_t cap = q->cap ? q->cap * 2 : 4096;
+        int32_t *a = (int32_t *)realloc(q->ichr, sizeof(int32_t) * (size_t)cap);
+        int32_t *b = (int32_t *)realloc(q->qs, sizeof(int32_t) * (size_t)cap);
+        int32_t *c = (int32_t *)realloc(q->qe, sizeof(int32_t) * (size_t)cap);
+        if (a) q->ichr = a;
+        if (b) q->qs = b;
+        if (c) q->qe = c;
+        if (!a || !b || !c) return -1;
+        q->cap = cap;
+    }
+    q->ichr[q->n] = ichr; q->qs[q->n] = qs; q->qe[q->n] = qe;
+    q->n++;
+    return 0;
+}
+
+void igdc_queries_free(igdc_queries *q)
+{
+    free(q->ichr); free(q->qs); free(q->qe);
+    memset(q, 0, sizeof *q);
+}
+
+int igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out)
+{
+    memset(out, 0, sizeof *out);
+    igdc_lines *r = igdc_lines_open(qfile);
+    if (!r) return -1;
+    char *line;
+    while ((line = igdc_lines_next(r, NULL)) != NULL) {
+        int32_t st, en;
+        char *chrm = igdc_parse_bed(line, &st, &en, require_chr);
+        if (!chrm) continue;
+        int32_t id = igdc_get_id(db, chrm);
+        if (id < 0) continue;
+        if (igdc_queries_push(out, id, st, en) != 0) { igdc_lines_close(r); return -1; }
+    }
+    igdc_lines_close(r);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------
+ * writer */
+typedef struct { int32_t idx, start, end, value; } rec16;
+
+static void stable_sort_by_start(rec16 *a, rec16 *tmp, int64_t n)
+{
+    /* bottom-up merge sort: stable, so equal starts keep source order */
+    for (int64_t i = 1; i < n; i++) {                     /* short runs by insertion */
+        if ((i & 15) == 0) continue;
+        rec16 x = a[i];
+        int64_t lo = i & ~(int64_t)15, j = i;
+        while (j > lo && a[j - 1].start > x.start) { a[j] = a[j - 1]; j--; }
+        a[j] = x;
+    }
+    rec16 *src = a, *dst = tmp;
+    for (int64_t w = 16; w < n; w <<= 1) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = (src[j].start < src[i].start) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        rec16 *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, sizeof(rec16) * (size_t)n);
+}
+
+int igdc_write_igd(const char *igd_path, int32_t nbp, int32_t gType, int32_t nCtg,
+                   const char *const *ctgNames, int64_t n, const igdc_interval *iv,
+                   int32_t nFiles, const char *const *fileNames, const int32_t *nr,
+                   const double *avg)
+{
+    if (nbp <= 0 || nCtg < 0 || (gType != 0 && gType != 1)) return -1;
+    int32_t *nTile = (int32_t *)calloc((size_t)nCtg + 1, sizeof(int32_t));
+    for (int64_t i = 0; i < n; i++) {
+        const igdc_interval *x = &iv[i];
+        if (x->start >= x->end || x->start <= -nbp || x->ctg < 0 || x->ctg >= nCtg) continue;
+        int32_t n2 = (x->end - 1) / nbp;
+        if (n2 + 1 > nTile[x->ctg]) nTile[x->ctg] = n2 + 1;
+    }
+    int64_t *base = (int64_t *)calloc((size_t)nCtg + 1, sizeof(int64_t));
+    int64_t nT = 0;
+    for (int32_t c = 0; c < nCtg; c++) {
+        /* a contig that only received dropped intervals still exists with one empty tile
+         * (the reference creates mTiles = 1 + n2 on first sight, src/igd_base.c:132-136) */
+        if (nTile[c] == 0) nTile[c] = 1;
+        base[c] = nT;
+        nT += nTile[c];
+    }
+    int64_t *off = (int64_t *)calloc((size_t)nT + 1, sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) {
+        const igdc_interval *x = &iv[i];
+        if (x->start >= x->end || x->start <= -nbp || x->ctg < 0 || x->ctg >= nCtg) continue;
+        int32_t n1 = x->start / nbp, n2 = (x->end - 1) / nbp;
+        for (int32_t j = n1; j <= n2; j++) off[base[x->ctg] + j + 1]++;
+    }
+    int32_t *cnt = (int32_t *)calloc((size_t)nT + 1, sizeof(int32_t));
+    int64_t maxc = 0;
+    for (int64_t t = 0; t < nT; t++) {
+        cnt[t] = (int32_t)off[t + 1];
+        if (off[t + 1] > maxc) maxc = off[t + 1];
+        off[t + 1] += off[t];
+    }
+    const int64_t total = off[nT];
+    rec16 *recs = (rec16 *)malloc(sizeof(rec16) * (size_t)(total ? total : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nT + 1));
+    rec16 *tmp = (rec16 *)malloc(sizeof(rec16) * (size_t)(maxc ? maxc : 1));
+    if (!recs || !cur || !tmp) { free(nTile); free(base); free(off); free(cnt); free(recs); free(cur); free(tmp); return -1; }
+    memcpy(cur, off, sizeof(int64_t) * (size_t)(nT + 1));
+    for (int64_t i = 0; i < n; i++) {
+        const igdc_interval *x = &iv[i];
+        if (x->start >= x->end || x->start <= -nbp || x->ctg < 0 || x->ctg >= nCtg) continue;
+        int32_t n1 = x->start / nbp, n2 = (x->end - 1) / nbp;
+        for (int32_t j = n1; j <= n2; j++) {
+            rec16 *r = &recs[cur[base[x->ctg] + j]++];
+            r->idx = x->file; r->start = x->start; r->end = x->end; r->value = x->value;
+        }
+    }
+    for (int64_t t = 0; t < nT; t++)
+        if (cnt[t] > 1) stable_sort_by_start(recs + off[t], tmp, cnt[t]);
+
+    int rc = -1;
+    FILE *fp = fopen(igd_path, "wb");
+    if (fp) {
+        int32_t head[3] = {nbp, gType, nCtg};
+        fwrite(head, sizeof head, 1, fp);
+        fwrite(nTile, sizeof(int32_t), (size_t)nCtg, fp);
+        fwrite(cnt, sizeof(int32_t), (size_t)nT, fp);
+        for (int32_t c = 0; c < nCtg; c++) {
+            char name[40];
+            memset(name, 0, sizeof name);
+            strncpy(name, ctgNames[c], 39);
+            fwrite(name, 40, 1, fp);
+        }
+        if (gType == 1)
+            fwrite(recs, sizeof(rec16), (size_t)total, fp);
+        else
+            for (int64_t i = 0; i < total; i++) fwrite(&recs[i], 12, 1, fp);
+        rc = (fflush(fp) == 0 && !ferror(fp)) ? 0 : -1;
+        fclose(fp);
+    }
+    free(nTile); free(base); free(off); free(cnt); free(recs); free(cur); free(tmp);
+    if (rc != 0) return rc;
+    char *tsv = igdc_index_path(igd_path);
+    fp = fopen(tsv, "w");
+    free(tsv);
+    if (!fp) return -1;
+    fprintf(fp, "Index\tFile\tNumber of regions\tAvg size\n");
+    for (int32_t i = 0; i < nFiles; i++)
+        fprintf(fp, "%i\t%s\t%i\t%f\n", i, fileNames[i], nr ? nr[i] : 0, avg ? avg[i] : 0.0);
+    fclose(fp);
+    return 0;
+}

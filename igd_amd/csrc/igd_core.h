@@ -1,0 +1,95 @@
+/* igd_core.h -- host-side core shared by the three ABI flavours (CLI, Python handle, R).
+ *
+ * Internal header (not installed): the public faces are include/igd_search.h,
+ * include/igd_py_abi.h and include/igdr_abi.h.  Everything here is plain C99; the only
+ * thing it calls for the search itself is the HIP engine of include/igd_hip.h -- there is
+ * no CPU search path in this library.
+ *
+ * Reference counterparts (databio/IGD, /root/reference):
+ *   igdc_open           get_igdinfo  src/igd_base.c:269-323  (+ whole tile region, once)
+ *   igdc_load_index     get_fileinfo src/igd_base.c:235-267
+ *   igdc_get_id         get_id       src/igd_base.c:325-331  (khash str->int, src/khash.h)
+ *   igdc_parse_bed      parse_bed    src/igd_base.c:53-72
+ *   igdc_lines_*        ks_getuntil  src/kseq.h:82-130 over gzread (src/igd_base.h:192)
+ *   igdc_read_queries   the read/parse/lookup part of getOverlaps src/igd_search.c:708-714
+ *   igdc_write_igd      igd_add + igd_save src/igd_base.c:118-174,396-461 (format only:
+ *                       tests and the benchmark need to MAKE .igd files; `igd create`
+ *                       itself is out of scope)
+ */
+#ifndef IGD_CORE_H
+#define IGD_CORE_H
+#include <stdint.h>
+#include <stdio.h>
+#include "igd_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct igdc_db {
+    int32_t nbp, gType, nCtg, nFiles;
+    int32_t *nTile;          /* [nCtg]                                                  */
+    int32_t *nCntFlat;       /* sum(nTile), contig-major (file order)                   */
+    int32_t **nCnt;          /* [nCtg] -> into nCntFlat                                 */
+    int64_t *tIdxFlat;       /* byte offset of each tile in the .igd                    */
+    int64_t **tIdx;          /* [nCtg] -> into tIdxFlat                                 */
+    char   **cName;          /* [nCtg], each a 40-byte buffer as stored in the file     */
+    char   **fileName;       /* [nFiles]                                                */
+    int32_t *fileNr;
+    double  *fileMd;
+    int64_t  nTileTotal, nRecords, dataOff;
+    int32_t *dict;           /* open-addressing contig dictionary                        */
+    int32_t  dictCap;
+    igd_hip_db *dev;         /* the database resident on the GPU (NULL until attached)   */
+} igdc_db;
+
+/* header tables of an .igd (no tile data is read) */
+igdc_db *igdc_open(const char *igd_path);
+/* "<igd minus last .ext>_index.tsv" */
+char    *igdc_index_path(const char *igd_path);
+int      igdc_load_index(igdc_db *db, const char *tsv_path);
+void     igdc_close(igdc_db *db);
+int32_t  igdc_get_id(const igdc_db *db, const char *chrm);
+
+/* Put the tile region on the GPU (igd_hip_open).  _path maps the file; _fp reads through an
+ * already open stream (the CLI flavour's global fP).  Returns IGD_HIP_OK or an IGD_HIP_ERR_*. */
+int igdc_attach_path(igdc_db *db, const char *igd_path, int device);
+int igdc_attach_fp(igdc_db *db, FILE *fp, int device);
+
+/* BED line -> (contig, start, end).  Mutates `line`.  require_chr=1 is the CLI rule
+ * (name starts with "chr", shorter than 40, end > 0: src/igd_base.c:69); require_chr=0 is
+ * the rule of the Python/R forks (>= 3 fields: src_py/igd_base.c:44). */
+char *igdc_parse_bed(char *line, int32_t *st, int32_t *en, int require_chr);
+
+/* '\n'-separated lines of a plain or gzip file */
+typedef struct igdc_lines igdc_lines;
+igdc_lines *igdc_lines_open(const char *path);
+char       *igdc_lines_next(igdc_lines *r, int64_t *len);   /* NULL at end; buffer is reused */
+void        igdc_lines_close(igdc_lines *r);
+
+/* accepted queries of one file, as arrays */
+typedef struct {
+    int64_t n, cap;
+    int32_t *ichr, *qs, *qe;
+} igdc_queries;
+/* returns 0, or -1 when the file cannot be opened.  Lines whose contig is not in the
+ * database are dropped here (the reference drops them in get_overlaps, :456-457). */
+int  igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out);
+void igdc_queries_free(igdc_queries *q);
+int  igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe);
+
+/* ---- minimal writer (format of SURVEY.md App. A) ------------------------------------- */
+typedef struct { int32_t file, ctg, start, end, value; } igdc_interval;
+/* Intervals in source order (file by file, line by line); start>=end is dropped like
+ * igd_add does (src/igd_base.c:120), and so is start<=-nbp (negative tile index there).  Each interval is copied to
+ * every tile start/nbp..(end-1)/nbp; tiles are stable-sorted by start.  Writes
+ * <igd_path> and its _index.tsv (nr/avg = lines and mean length per file, as given). */
+int igdc_write_igd(const char *igd_path, int32_t nbp, int32_t gType, int32_t nCtg,
+                   const char *const *ctgNames, int64_t n, const igdc_interval *iv,
+                   int32_t nFiles, const char *const *fileNames, const int32_t *nr,
+                   const double *avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

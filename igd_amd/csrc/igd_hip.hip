@@ -1,0 +1,1137 @@
+// igd_hip.hip -- MI355X (gfx950 / CDNA4) overlap-search engine behind include/igd_hip.h.
+//
+// Replaces, for a whole batch of queries at once, the reference's per-query kernels
+//   get_overlaps    /root/reference/src/igd_search.c:454-534   (rule NEST)
+//   get_overlaps_v  /root/reference/src/igd_search.c:623-694   (rule FLAT, value>=v)
+//   get_overlaps0   /root/reference/src/igd_search.c:30-112    (12-byte records)
+//   get_overlaps_f1 /root/reference/src/igd_search.c:537-620   (enumeration)
+// and the hits[] accumulator (:925, :491, :524, :654, :684).
+//
+// Design (DESIGN.md has the long form).  The reference walks queries and, per query, seeks
+// a tile, bisects it for the last start<qe and scans backwards testing end>qs.  Here the
+// loop is turned inside out so that BOTH sides stream:
+//   1. bucket: every (query, visited tile) pair is counting-sorted by tile id
+//      (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); the NEST/FLAT visiting rule and
+//      the "first tile" notion live entirely in this step.
+//   2. scan:   igd_scan_tiles -- one wavefront owns one <=512-record chunk of one tile.  It
+//      loads the chunk's start/end/idx[/value] once, coalesced, into 8 register slots
+//      (record r*64+lane), then runs through the tile's pairs, whose (qs,qe) it fetches 64 at
+//      a time and broadcasts lane by lane with v_readlane.  Per pair and slot the test is
+//            lob <= start < qe  &&  end > qs  [&& value >= v]
+//      (lob = tile start for a non-first tile: that is the reference's tS prefix skip,
+//      :510-511; the upper bound start<qe is what its bisection computes, :479-487), with a
+//      wave-uniform early exit on the sorted starts (slot minimum >= qe).  A hit is one
+//      ds_add_u64 into a per-workgroup LDS copy of hits[] (privatised counters).
+//   3. flush/reduce: each workgroup stores its LDS counters to its own slab row with plain
+//      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].
+// Queries spanning more than IGD_SHORT_TILES tiles skip the bucketing and are walked tile by
+// tile by one wave each at the end of the scan kernel (same compare code).
+// No MFMA anywhere: this is integer compare + count, bound by HBM/LDS, not by math.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <vector>
+
+#include "igd_hip.h"
+
+#define IGD_WAVE 64
+#define IGD_SLOTS 8                          // register slots per array per lane
+#define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (512)
+#define IGD_SHORT_TILES 4                    // queries spanning more tiles take the long path
+#define IGD_WG 512                           // threads per scan workgroup (8 waves)
+#define IGD_MAX_BATCH (1ll << 24)            // queries per device batch
+#define IGD_SCAN_ITEMS 16                    // elements per thread in the tile scan
+#define IGD_SCAN_BLOCK 256
+#define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
+#define IGD_REDUCE_GROUPS 32
+#define IGD_LDS_HITS_MAX_BYTES (128 * 1024)
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local char g_err[512] = "";
+static void set_err(const char *what, hipError_t e, const char *file, int line)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+#define HIPCHK(call)                                                          \
+    do {                                                                      \
+        hipError_t e_ = (call);                                               \
+        if (e_ != hipSuccess) {                                               \
+            set_err(#call, e_, __FILE__, __LINE__);                           \
+            return IGD_HIP_ERR_DEVICE;                                        \
+        }                                                                     \
+    } while (0)
+
+extern "C" const char *igd_hip_last_error(void) { return g_err; }
+
+extern "C" int igd_hip_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_err("hipGetDeviceCount", e, __FILE__, __LINE__);
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int64_t igd_hip_max_batch(void) { return IGD_MAX_BATCH; }
+
+// ------------------------------------------------------------------------------------------
+// device view of one database (passed to kernels by value)
+struct DbView {
+    int32_t nbp, nCtg, nT, nChunks, nFiles;
+    const int32_t *start, *end, *idx, *value;   // SoA over all records, file order
+    const int64_t *tileOff;                     // [nT+1] record offset of each tile
+    const int32_t *tileCnt;                     // [nT]
+    const int32_t *tileBd;                      // [nT] tile start coordinate j*nbp (INT_MIN for j==0)
+    const int32_t *ctgBase;                     // [nCtg] global tile id of the contig's tile 0
+    const int32_t *ctgNTile;                    // [nCtg]
+    const int32_t *chunkTile;                   // [nChunks] tile of each chunk
+    const int32_t *chunkRec0;                   // [nChunks] first record (within the tile)
+};
+
+struct igd_hip_db {
+    int device;
+    int32_t nbp, gType, nCtg, nFiles, nT, nChunks;
+    int64_t nRec;
+    DbView v;
+    // owned device memory of the image
+    int32_t *d_start, *d_end, *d_idx, *d_value;
+    int64_t *d_tileOff;
+    int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_chunkTile, *d_chunkRec0;
+    int64_t resident;
+    // per-batch workspace
+    int32_t *d_pairCnt, *d_pairPos, *d_blockSums;
+    void *d_pairs;                // int2[cap*K] (or int4 for the enumerate path)
+    int32_t *d_long, *d_ctl;      // long-query list; ctl[0]=nLong
+    int64_t wsQueries;            // capacity in queries
+    int pairBytes;
+    u64 *d_slab;
+    int grid, ldsBytes;
+    bool ldsHits;
+    // host-API staging
+    int32_t *d_qc, *d_qs, *d_qe;
+    int64_t qcap;
+    int64_t *d_hits, *d_total;
+    hipStream_t stream;
+    // profiling
+    std::vector<hipEvent_t> ev;   // 4 per launch: pipeline start, scan start, scan stop, pipeline stop
+    int evMax, evUsed;
+    bool evOn;
+};
+
+// ------------------------------------------------------------------------------------------
+// upload: AoS (file order) -> SoA.  One record per lane: a 16-byte gdata_t is one dwordx4
+// load (src/igd_base.h:41-46: idx,start,end,value); 12-byte gdata0_t three dword loads.
+__global__ void k_aos_to_soa16(const int4 *__restrict__ aos, int64_t n, int32_t *__restrict__ start,
+                               int32_t *__restrict__ end, int32_t *__restrict__ idx,
+                               int32_t *__restrict__ value)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int4 r = aos[i];
+        idx[i] = r.x; start[i] = r.y; end[i] = r.z; value[i] = r.w;
+    }
+}
+__global__ void k_aos_to_soa12(const int32_t *__restrict__ aos, int64_t n, int32_t *__restrict__ start,
+                               int32_t *__restrict__ end, int32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        idx[i] = aos[3 * i]; start[i] = aos[3 * i + 1]; end[i] = aos[3 * i + 2];
+    }
+}
+
+// hits[] is indexed by idx without a bounds check in the reference (src/igd_search.c:491); on
+// the GPU an out-of-range idx would corrupt LDS, so the image is validated once at open.
+__global__ void k_idx_range(const int32_t *__restrict__ idx, int64_t n, int32_t nFiles, int32_t *__restrict__ bad)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int b = 0;
+    for (; i < n; i += stride) b |= (idx[i] < 0) | (idx[i] >= nFiles);
+    if (b) atomicOr(bad, 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Tile span of one query = the prologue of every reference kernel (src/igd_search.c:455-467):
+// n1=qs/nbp, n2=(qe-1)/nbp (C division), n1>mTile -> nothing, n2 clamped, and for rule NEST an
+// empty first tile ends the query (:468).  Returns false when the query visits nothing.
+__device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int qe, int rule,
+                                           int &gt0, int &ntl)
+{
+    if (c < 0 || c >= db.nCtg) return false;
+    int n1 = qs / db.nbp;
+    int n2 = (int)((unsigned)qe - 1u) / db.nbp;
+    int mT = db.ctgNTile[c] - 1;
+    if (n1 < 0 || n1 > mT) return false;      // n1<0: out-of-bounds read in the reference
+    if (n2 > mT) n2 = mT;
+    gt0 = db.ctgBase[c] + n1;
+    if (rule == IGD_HIP_RULE_NEST && db.tileCnt[gt0] == 0) return false;
+    ntl = n2 > n1 ? n2 - n1 + 1 : 1;
+    return true;
+}
+
+// bucket step 1: per-tile pair counts (+ the list of long queries)
+__global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
+                              const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
+                              int nq, int rule, int32_t *__restrict__ pairCnt,
+                              int32_t *__restrict__ longList, int32_t *__restrict__ ctl)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int gt0, ntl;
+    if (!query_span(db, ichr[i], qs[i], qe[i], rule, gt0, ntl)) return;
+    if (ntl > IGD_SHORT_TILES) {
+        int p = atomicAdd(&ctl[0], 1);
+        longList[p] = i;
+        return;
+    }
+    for (int k = 0; k < ntl; k++)
+        if (db.tileCnt[gt0 + k] > 0) atomicAdd(&pairCnt[gt0 + k], 1);
+}
+
+// bucket step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol)
+__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_block_sums(const int32_t *__restrict__ in,
+                                                                    int n, int32_t *__restrict__ blockSums)
+{
+    __shared__ int32_t red[IGD_SCAN_BLOCK / IGD_WAVE];
+    int base = blockIdx.x * IGD_SCAN_TILE + threadIdx.x * IGD_SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++)
+        if (base + k < n) s += in[base + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < IGD_SCAN_BLOCK / IGD_WAVE; w++) t += red[w];
+        blockSums[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(const int32_t *__restrict__ in, int n,
+                                                               const int32_t *__restrict__ blockSums,
+                                                               int32_t *__restrict__ out)
+{
+    __shared__ int32_t red[IGD_SCAN_BLOCK / IGD_WAVE];
+    __shared__ int32_t wsum[IGD_SCAN_BLOCK / IGD_WAVE];
+    // prefix of the earlier blocks' sums (every block recomputes it; a few hundred values)
+    int pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += IGD_SCAN_BLOCK) pre += blockSums[b];
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
+    // local items
+    int base = blockIdx.x * IGD_SCAN_TILE + threadIdx.x * IGD_SCAN_ITEMS;
+    int v[IGD_SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    // inclusive scan of s across the wave
+    int inc = s;
+    int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int blockPre = 0;
+    for (int w = 0; w < IGD_SCAN_BLOCK / IGD_WAVE; w++) blockPre += red[w];
+    int wavePre = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wavePre += wsum[w];
+    int run = blockPre + wavePre + inc - s;
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// bucket step 3: scatter (qs,qe[,q]) of every pair to its tile's slot range.  After this kernel
+// pairPos[t] is the END of tile t's range.  WITH_Q: the enumerate path also needs the query id.
+template <bool WITH_Q>
+__global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
+                                const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
+                                int nq, int rule, int32_t *__restrict__ pairPos,
+                                void *__restrict__ pairs)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int gt0, ntl;
+    int s = qs[i], e = qe[i];
+    if (!query_span(db, ichr[i], s, e, rule, gt0, ntl)) return;
+    if (ntl > IGD_SHORT_TILES) return;
+    for (int k = 0; k < ntl; k++) {
+        if (db.tileCnt[gt0 + k] > 0) {
+            int p = atomicAdd(&pairPos[gt0 + k], 1);
+            if (WITH_Q) ((int4 *)pairs)[p] = make_int4(s, e, i, k);
+            else ((int2 *)pairs)[p] = make_int2(s, e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The scan kernel.
+//
+// Records of one chunk sit in registers: slot r of lane l is record rec0 + r*64 + l of the tile
+// (coalesced dword loads; unused positions hold start=INT_MAX,end=INT_MIN so they never match).
+// smin[r] = first start of slot r (wave-uniform): tiles are sorted by start, so once
+// smin[r] >= qe no later slot can hold start<qe -- the reference's bisection bound, as a
+// wave-uniform loop exit.
+struct Chunk {
+    int32_t s[IGD_SLOTS], e[IGD_SLOTS], x[IGD_SLOTS], w[IGD_SLOTS];
+    int32_t smin[IGD_SLOTS];
+    int nslots;
+};
+
+template <bool USE_V>
+__device__ __forceinline__ void load_chunk(const DbView &db, int64_t off, int n, int lane, Chunk &c)
+{
+    c.nslots = (n + IGD_WAVE - 1) / IGD_WAVE;
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        int i = r * IGD_WAVE + lane;
+        bool ok = i < n;
+        c.s[r] = ok ? db.start[off + i] : INT_MAX;
+        c.e[r] = ok ? db.end[off + i] : INT_MIN;
+        c.x[r] = ok ? db.idx[off + i] : 0;
+        if (USE_V) c.w[r] = ok ? db.value[off + i] : INT_MIN;
+    }
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) c.smin[r] = __builtin_amdgcn_readfirstlane(c.s[r]);
+}
+
+// one (query, chunk): count hits into `hits` (LDS or global u64 counters)
+template <bool USE_V>
+__device__ __forceinline__ void match_chunk(const Chunk &c, int qs, int qe, int lob, int v, u64 *hits)
+{
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        if (r >= c.nslots || c.smin[r] >= qe) break;     // wave-uniform
+        bool hit = (c.s[r] < qe) & (c.s[r] >= lob) & (c.e[r] > qs);
+        if (USE_V) hit = hit & (c.w[r] >= v);
+        if (hit) atomicAdd(&hits[c.x[r]], 1ull);
+    }
+}
+
+template <bool USE_V, bool LDS_HITS>
+__global__ __launch_bounds__(IGD_WG) void igd_scan_tiles(
+    DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
+    const int2 *__restrict__ pairs, const int32_t *__restrict__ longList,
+    const int32_t *__restrict__ ctl, const int32_t *__restrict__ q_ichr,
+    const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe, int v,
+    u64 *__restrict__ slab /* [grid][nFiles] when LDS_HITS, else the global hits[] */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *hits = LDS_HITS ? (u64 *)smem : slab;
+    if (LDS_HITS) {
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int wavesPerWG = IGD_WG / IGD_WAVE;
+    const int gwave = blockIdx.x * wavesPerWG + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * wavesPerWG;
+    Chunk c;
+
+    // ---- phase 1: bucketed pairs, one chunk of one tile per wave iteration ----
+    for (int ch = gwave; ch < db.nChunks; ch += nwaves) {
+        const int t = __builtin_amdgcn_readfirstlane(db.chunkTile[ch]);
+        const int np = __builtin_amdgcn_readfirstlane(pairCnt[t]);
+        if (np == 0) continue;                           // tile not visited by this batch
+        const int pend = __builtin_amdgcn_readfirstlane(pairPos[t]);
+        const int rec0 = __builtin_amdgcn_readfirstlane(db.chunkRec0[ch]);
+        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+        const int bd = __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+        const int64_t off = db.tileOff[t] + rec0;
+        int n = tcnt - rec0;
+        if (n > IGD_CHUNK) n = IGD_CHUNK;
+        load_chunk<USE_V>(db, off, n, lane, c);
+        for (int p = pend - np; p < pend; p += IGD_WAVE) {
+            int m = pend - p;
+            if (m > IGD_WAVE) m = IGD_WAVE;
+            int2 mine = (lane < m) ? pairs[p + lane] : make_int2(0, INT_MIN);
+            for (int k = 0; k < m; k++) {
+                const int qs = __builtin_amdgcn_readlane(mine.x, k);
+                const int qe = __builtin_amdgcn_readlane(mine.y, k);
+                // first tile of this query <=> qs lies at/after the tile start (tile 0: always)
+                const int lob = (qs >= bd) ? INT_MIN : bd;
+                match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+            }
+        }
+    }
+
+    // ---- phase 2: long queries, one wave walks all tiles of one query ----
+    const int nLong = __builtin_amdgcn_readfirstlane(ctl[0]);
+    for (int li = gwave; li < nLong; li += nwaves) {
+        const int q = __builtin_amdgcn_readfirstlane(longList[li]);
+        const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
+        const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
+        const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
+        const int n1 = qs / db.nbp;
+        int n2 = (int)((unsigned)qe - 1u) / db.nbp;
+        const int mT = db.ctgNTile[cc] - 1;
+        if (n2 > mT) n2 = mT;
+        const int base = db.ctgBase[cc];
+        for (int j = n1; j <= n2; j++) {
+            const int t = base + j;
+            const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+            if (tcnt == 0) continue;
+            const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+            const int64_t toff = db.tileOff[t];
+            for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
+                int n = tcnt - rec0;
+                if (n > IGD_CHUNK) n = IGD_CHUNK;
+                load_chunk<USE_V>(db, toff + rec0, n, lane, c);
+                if (c.smin[0] >= qe) break;              // sorted: nothing further in this tile
+                match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+            }
+        }
+    }
+
+    if (LDS_HITS) {
+        __syncthreads();
+        u64 *row = slab + (size_t)blockIdx.x * db.nFiles;
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
+    }
+}
+
+// slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
+__global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ slab, int rows, int nFiles,
+                                                      u64 *__restrict__ hits, u64 *__restrict__ total)
+{
+    __shared__ u64 red[4];
+    int f = blockIdx.x * 256 + threadIdx.x;
+    u64 s = 0;
+    if (f < nFiles)
+        for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s += slab[(size_t)g * nFiles + f];
+    if (s) atomicAdd(&hits[f], s);
+    if (total) {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 t = red[0] + red[1] + red[2] + red[3];
+            if (t) atomicAdd(total, t);
+        }
+    }
+}
+
+// without LDS counters the batch total is the growth of sum(hits): measured around the launch
+__global__ __launch_bounds__(256) void k_sum_hits(const u64 *__restrict__ hits, int nFiles,
+                                                  u64 *__restrict__ total, int sign)
+{
+    __shared__ u64 red[4];
+    u64 s = 0;
+    for (int f = threadIdx.x; f < nFiles; f += 256) s += hits[f];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = red[0] + red[1] + red[2] + red[3];
+        if (sign > 0) atomicAdd(total, t);
+        else atomicAdd(total, (u64)(-(int64_t)t));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// `-f` enumeration.  Same bucketing (pairs carry the query id q and k = tile - n1); the tile
+// is the unit (a wave walks its chunks from the LAST to the first so that record indices come
+// out descending, as the reverse scans at src/igd_search.c:575-579 and :608-612 emit them).
+//   pass COUNT: pcount[q*K + k] = hits of pair (q, tile n1+k)
+//   host/scan : qoff = exclusive scan over q of sum_k pcount
+//   pass FILL : record i of pair (q,k) goes to out[qoff[q] + sum_{k'<k} pcount[q*K+k'] + rank]
+// Long queries: one wave per query, tiles ascending, same two passes with a running offset.
+template <bool FILL>
+__global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
+    DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
+    const int4 *__restrict__ pairs, const int32_t *__restrict__ longList,
+    const int32_t *__restrict__ ctl, const int32_t *__restrict__ q_ichr,
+    const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe,
+    int32_t *__restrict__ pcount /* [nq*K] */, int64_t *__restrict__ qlong /* [nq] long totals */,
+    const int64_t *__restrict__ qoff, igd_hip_hit *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wavesPerWG = IGD_WG / IGD_WAVE;
+    const int gwave = blockIdx.x * wavesPerWG + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * wavesPerWG;
+    const u64 above = (lane == 63) ? 0ull : (~0ull << (lane + 1));   // lanes with a higher record index
+
+    for (int t = gwave; t < db.nT; t += nwaves) {
+        const int np = __builtin_amdgcn_readfirstlane(pairCnt[t]);
+        if (np == 0) continue;
+        const int pend = __builtin_amdgcn_readfirstlane(pairPos[t]);
+        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+        const int bd = __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+        const int64_t toff = db.tileOff[t];
+        for (int p = pend - np; p < pend; p++) {
+            const int4 pr = pairs[p];                     // wave-uniform address
+            const int qs = pr.x, qe = pr.y, q = pr.z, k = pr.w;
+            const int lob = (qs >= bd) ? INT_MIN : bd;
+            int64_t base = 0;
+            if (FILL) {
+                base = qoff[q];
+                for (int kk = 0; kk < k; kk++) base += pcount[(size_t)q * IGD_SHORT_TILES + kk];
+            }
+            int cnt = 0;
+            // records from the end of the tile towards the front, 64 at a time
+            for (int hi = tcnt; hi > 0; hi -= IGD_WAVE) {
+                const int i = hi - IGD_WAVE + lane;       // lane 63 = highest index of this step
+                const bool ok = i >= 0;
+                const int s = ok ? db.start[toff + i] : INT_MAX;
+                const int e = ok ? db.end[toff + i] : INT_MIN;
+                const bool hit = (s < qe) & (s >= lob) & (e > qs);
+                const u64 m = __ballot(hit);
+                if (FILL && hit) {
+                    igd_hip_hit h;
+                    h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
+                    out[base + cnt + __popcll(m & above)] = h;
+                }
+                cnt += __popcll(m);
+                // all starts in this step are below lob => so is everything before it
+                const int smax = __builtin_amdgcn_readlane(s, 63);
+                if (smax < lob) break;
+            }
+            if (!FILL && lane == 0) pcount[(size_t)q * IGD_SHORT_TILES + k] = cnt;
+        }
+    }
+
+    const int nLong = __builtin_amdgcn_readfirstlane(ctl[0]);
+    for (int li = gwave; li < nLong; li += nwaves) {
+        const int q = __builtin_amdgcn_readfirstlane(longList[li]);
+        const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
+        const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
+        const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
+        const int n1 = qs / db.nbp;
+        int n2 = (int)((unsigned)qe - 1u) / db.nbp;
+        const int mT = db.ctgNTile[cc] - 1;
+        if (n2 > mT) n2 = mT;
+        const int tb = db.ctgBase[cc];
+        int64_t cnt = 0;
+        const int64_t base = FILL ? qoff[q] : 0;
+        for (int j = n1; j <= n2; j++) {
+            const int t = tb + j;
+            const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+            if (tcnt == 0) continue;
+            const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+            const int64_t toff = db.tileOff[t];
+            for (int hi = tcnt; hi > 0; hi -= IGD_WAVE) {
+                const int i = hi - IGD_WAVE + lane;
+                const bool ok = i >= 0;
+                const int s = ok ? db.start[toff + i] : INT_MAX;
+                const int e = ok ? db.end[toff + i] : INT_MIN;
+                const bool hit = (s < qe) & (s >= lob) & (e > qs);
+                const u64 m = __ballot(hit);
+                if (FILL && hit) {
+                    igd_hip_hit h;
+                    h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
+                    out[base + cnt + __popcll(m & above)] = h;
+                }
+                cnt += __popcll(m);
+                const int smax = __builtin_amdgcn_readlane(s, 63);
+                if (smax < lob) break;
+            }
+        }
+        if (!FILL && lane == 0) qlong[q] = cnt;
+    }
+}
+
+// per-query totals -> qcount (int64) ; the scan to qoff is done by k_scan64 below
+__global__ void k_enum_qcount(const int32_t *__restrict__ pcount, const int64_t *__restrict__ qlong,
+                              int nq, int64_t *__restrict__ qcount)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int64_t s = qlong[i];
+    for (int k = 0; k < IGD_SHORT_TILES; k++) s += pcount[(size_t)i * IGD_SHORT_TILES + k];
+    qcount[i] = s;
+}
+
+// single-workgroup exclusive scan of int64 (nq <= 2^24: at most a few ms; the -f path is
+// bound by its output, not by this)
+__global__ __launch_bounds__(1024) void k_scan64(const int64_t *__restrict__ in, int n,
+                                                 int64_t *__restrict__ out /* n+1 */)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        int64_t v = i < n ? in[i] : 0;
+        int64_t inc = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            int64_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int64_t pre = carry;
+        for (int k = 0; k < w; k++) pre += wsum[k];
+        if (i < n) out[i] = pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+// ------------------------------------------------------------------------------------------
+// instrumentation: exact terms of the algorithmic byte model, thread per query.
+__device__ __forceinline__ int lower_bound_start(const int32_t *s, int n, int key)
+{
+    int lo = 0, hi = n;          // first index with s[i] >= key
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (s[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_batch_stats(DbView db, const int32_t *__restrict__ ichr,
+                              const int32_t *__restrict__ qs, const int32_t *__restrict__ qe, int nq,
+                              int rule, u64 *__restrict__ acc /* queries,pairs,S,B */)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 nqv = 0, pairs = 0, S = 0, B = 0;
+    if (i < nq) {
+        int gt0, ntl;
+        int c = ichr[i];
+        // "reached the tile logic": valid contig and n1 in range (before the NEST test)
+        if (c >= 0 && c < db.nCtg) {
+            int n1 = qs[i] / db.nbp;
+            if (n1 >= 0 && n1 <= db.ctgNTile[c] - 1) nqv = 1;
+        }
+        if (query_span(db, c, qs[i], qe[i], rule, gt0, ntl)) {
+            for (int k = 0; k < ntl; k++) {
+                int t = gt0 + k;
+                int cnt = db.tileCnt[t];
+                if (cnt == 0) continue;
+                const int32_t *s = db.start + db.tileOff[t];
+                if (!(qe[i] > s[0])) continue;
+                int hi = lower_bound_start(s, cnt, qe[i]);
+                int lo = (k == 0) ? 0 : lower_bound_start(s, cnt, db.tileBd[t]);
+                pairs++;
+                S += hi > lo ? (u64)(hi - lo) : 0;
+                int b = 0;
+                while ((1ll << b) < (long long)cnt + 1) b++;
+                B += b;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        nqv += __shfl_down(nqv, o); pairs += __shfl_down(pairs, o);
+        S += __shfl_down(S, o); B += __shfl_down(B, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nqv) atomicAdd(&acc[0], nqv);
+        if (pairs) atomicAdd(&acc[1], pairs);
+        if (S) atomicAdd(&acc[2], S);
+        if (B) atomicAdd(&acc[3], B);
+    }
+}
+
+// ==========================================================================================
+// host side
+template <typename T>
+static int dalloc(T **p, size_t n, int64_t *acct)
+{
+    *p = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc((void **)p, n * sizeof(T));
+    if (e != hipSuccess) {
+        set_err("hipMalloc", e, __FILE__, __LINE__);
+        return IGD_HIP_ERR_NOMEM;
+    }
+    if (acct) *acct += (int64_t)(n * sizeof(T));
+    return IGD_HIP_OK;
+}
+
+extern "C" void igd_hip_close(igd_hip_db *db)
+{
+    if (!db) return;
+    (void)hipSetDevice(db->device);
+    void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_chunkTile, db->d_chunkRec0,
+                    db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_ctl,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (hipEvent_t e : db->ev) (void)hipEventDestroy(e);
+    if (db->stream) (void)hipStreamDestroy(db->stream);
+    delete db;
+}
+
+extern "C" int igd_hip_device(const igd_hip_db *db) { return db ? db->device : -1; }
+extern "C" int32_t igd_hip_nfiles(const igd_hip_db *db) { return db ? db->nFiles : 0; }
+extern "C" int64_t igd_hip_resident_bytes(const igd_hip_db *db) { return db ? db->resident : 0; }
+extern "C" void igd_hip_free(void *p) { free(p); }
+extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_tiles"; }
+
+extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
+{
+    if (!d || !out || d->nbp <= 0 || d->nCtg < 0 || d->nFiles < 0 || d->nRecords < 0 ||
+        (d->gType != 0 && d->gType != 1) || (d->nCtg > 0 && (!d->nTile || !d->nCnt)) ||
+        (d->nRecords > 0 && !d->records)) {
+        snprintf(g_err, sizeof g_err, "igd_hip_open: bad descriptor");
+        return IGD_HIP_ERR_ARG;
+    }
+    int ndev = igd_hip_device_count();
+    if (ndev <= 0) {
+        if (!g_err[0]) snprintf(g_err, sizeof g_err, "igd_hip_open: no HIP device");
+        return IGD_HIP_ERR_DEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        snprintf(g_err, sizeof g_err, "igd_hip_open: device %d out of range (%d visible)", device, ndev);
+        return IGD_HIP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(device));
+    igd_hip_db *db = new igd_hip_db();   // value-initialised: every field zero
+    db->device = device;
+    db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
+    db->nRec = d->nRecords;
+
+    // host-side tables
+    int64_t nT = 0;
+    for (int c = 0; c < d->nCtg; c++) nT += d->nTile[c];
+    if (nT > INT_MAX - 1) {
+        snprintf(g_err, sizeof g_err, "igd_hip_open: too many tiles");
+        delete db;
+        return IGD_HIP_ERR_ARG;
+    }
+    db->nT = (int32_t)nT;
+    std::vector<int64_t> tileOff((size_t)nT + 1);
+    std::vector<int32_t> tileCnt((size_t)nT + 1), tileBd((size_t)nT + 1), ctgBase((size_t)d->nCtg + 1),
+        ctgNTile((size_t)d->nCtg + 1), chunkTile, chunkRec0;
+    int64_t off = 0;
+    int32_t maxIdxCheck = 0;
+    (void)maxIdxCheck;
+    {
+        int64_t t = 0;
+        for (int c = 0; c < d->nCtg; c++) {
+            ctgBase[c] = (int32_t)t;
+            ctgNTile[c] = d->nTile[c];
+            for (int j = 0; j < d->nTile[c]; j++, t++) {
+                int32_t cnt = d->nCnt[t];
+                if (cnt < 0) cnt = 0;
+                tileOff[t] = off;
+                tileCnt[t] = cnt;
+                // tile start coordinate; computed with wrap like `bd` at src/igd_search.c:496,529
+                tileBd[t] = (j == 0) ? INT_MIN : (int32_t)((uint32_t)d->nbp * (uint32_t)j);
+                for (int32_t r0 = 0; r0 < cnt; r0 += IGD_CHUNK) {
+                    chunkTile.push_back((int32_t)t);
+                    chunkRec0.push_back(r0);
+                }
+                off += cnt;
+            }
+        }
+        tileOff[nT] = off;
+    }
+    if (off != d->nRecords) {
+        snprintf(g_err, sizeof g_err, "igd_hip_open: nRecords %lld != sum(nCnt) %lld",
+                 (long long)d->nRecords, (long long)off);
+        delete db;
+        return IGD_HIP_ERR_ARG;
+    }
+    db->nChunks = (int32_t)chunkTile.size();
+
+    int rc;
+    int64_t *acct = &db->resident;
+#define TRY(x) do { rc = (x); if (rc != IGD_HIP_OK) { igd_hip_close(db); return rc; } } while (0)
+#define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); igd_hip_close(db); return IGD_HIP_ERR_DEVICE; } } while (0)
+    TRYHIP(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
+    size_t n = (size_t)d->nRecords;
+    TRY(dalloc(&db->d_start, n, acct));
+    TRY(dalloc(&db->d_end, n, acct));
+    TRY(dalloc(&db->d_idx, n, acct));
+    if (d->gType == 1) TRY(dalloc(&db->d_value, n, acct));
+    TRY(dalloc(&db->d_tileOff, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_tileCnt, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_tileBd, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_ctgBase, (size_t)d->nCtg + 1, acct));
+    TRY(dalloc(&db->d_ctgNTile, (size_t)d->nCtg + 1, acct));
+    TRY(dalloc(&db->d_chunkTile, chunkTile.size(), acct));
+    TRY(dalloc(&db->d_chunkRec0, chunkRec0.size(), acct));
+    TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_pairPos, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_blockSums, (size_t)(nT / IGD_SCAN_TILE + 2), acct));
+    TRY(dalloc(&db->d_ctl, 16, acct));
+    TRY(dalloc(&db->d_hits, (size_t)d->nFiles + 1, acct));
+    TRY(dalloc(&db->d_total, 4, acct));
+    TRYHIP(hipMemcpy(db->d_tileOff, tileOff.data(), ((size_t)nT + 1) * 8, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(db->d_tileCnt, tileCnt.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(db->d_tileBd, tileBd.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(db->d_ctgBase, ctgBase.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
+    if (!chunkTile.empty()) {
+        TRYHIP(hipMemcpy(db->d_chunkTile, chunkTile.data(), chunkTile.size() * 4, hipMemcpyHostToDevice));
+        TRYHIP(hipMemcpy(db->d_chunkRec0, chunkRec0.data(), chunkRec0.size() * 4, hipMemcpyHostToDevice));
+    }
+    // records: upload the AoS region in slices and transpose on the GPU
+    if (n > 0) {
+        const size_t recBytes = d->gType == 1 ? 16 : 12;
+        const size_t slice = (size_t)1 << 24;            // records per slice (256 MiB of gdata_t)
+        void *d_aos = nullptr;
+        size_t sl = n < slice ? n : slice;
+        TRYHIP(hipMalloc(&d_aos, sl * recBytes));
+        for (size_t r0 = 0; r0 < n; r0 += slice) {
+            size_t m = n - r0 < slice ? n - r0 : slice;
+            hipError_t e = hipMemcpy(d_aos, (const char *)d->records + r0 * recBytes, m * recBytes,
+                                     hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                int blocks = (int)((m + 255) / 256);
+                if (blocks > 256 * 32) blocks = 256 * 32;
+                if (d->gType == 1)
+                    k_aos_to_soa16<<<blocks, 256, 0, db->stream>>>((const int4 *)d_aos, (int64_t)m,
+                        db->d_start + r0, db->d_end + r0, db->d_idx + r0, db->d_value + r0);
+                else
+                    k_aos_to_soa12<<<blocks, 256, 0, db->stream>>>((const int32_t *)d_aos, (int64_t)m,
+                        db->d_start + r0, db->d_end + r0, db->d_idx + r0);
+                e = hipStreamSynchronize(db->stream);
+            }
+            if (e != hipSuccess) {
+                set_err("upload/transpose", e, __FILE__, __LINE__);
+                (void)hipFree(d_aos);
+                igd_hip_close(db);
+                return IGD_HIP_ERR_DEVICE;
+            }
+        }
+        (void)hipFree(d_aos);
+        TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
+        k_idx_range<<<256 * 8, 256, 0, db->stream>>>(db->d_idx, (int64_t)n, d->nFiles, db->d_ctl);
+        int32_t bad = 0;
+        TRYHIP(hipStreamSynchronize(db->stream));
+        TRYHIP(hipMemcpy(&bad, db->d_ctl, 4, hipMemcpyDeviceToHost));
+        if (bad) {
+            snprintf(g_err, sizeof g_err, "igd_hip_open: a record's dataset index is outside [0,%d) "
+                     "(the _index.tsv does not match the .igd)", d->nFiles);
+            igd_hip_close(db);
+            return IGD_HIP_ERR_ARG;
+        }
+    }
+    TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
+
+    // launch geometry of the scan kernel
+    hipDeviceProp_t prop;
+    TRYHIP(hipGetDeviceProperties(&prop, device));
+    int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    db->ldsBytes = (int)((size_t)d->nFiles * 8);
+    db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
+    int perCU = 4;                                       // 4 x 512 threads = 32 waves/CU
+    if (db->ldsHits && db->ldsBytes > 0) {
+        int fit = (160 * 1024) / (db->ldsBytes + 256);
+        if (fit < 1) fit = 1;
+        if (fit < perCU) perCU = fit;
+    }
+    db->grid = cus * perCU;
+    if (db->ldsHits) {
+        TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1), acct));
+        if (db->ldsBytes > 64 * 1024) {
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+        }
+    }
+#undef TRY
+#undef TRYHIP
+    DbView &v = db->v;
+    v.nbp = db->nbp; v.nCtg = db->nCtg; v.nT = db->nT; v.nChunks = db->nChunks; v.nFiles = db->nFiles;
+    v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
+    v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
+    v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile;
+    v.chunkTile = db->d_chunkTile; v.chunkRec0 = db->d_chunkRec0;
+    *out = db;
+    return IGD_HIP_OK;
+}
+
+// workspace for `nq` queries with `pairBytes` per pair slot
+static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
+{
+    if (nq <= db->wsQueries && pairBytes <= db->pairBytes) return IGD_HIP_OK;
+    HIPCHK(hipDeviceSynchronize());
+    int64_t cap = nq > db->wsQueries ? nq : db->wsQueries;
+    int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
+    if (db->d_pairs) (void)hipFree(db->d_pairs);
+    if (db->d_long) (void)hipFree(db->d_long);
+    db->d_pairs = nullptr; db->d_long = nullptr;
+    db->wsQueries = 0;
+    int rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr);
+    if (rc != IGD_HIP_OK) return rc;
+    rc = dalloc(&db->d_long, (size_t)cap, nullptr);
+    if (rc != IGD_HIP_OK) return rc;
+    db->wsQueries = cap;
+    db->pairBytes = pb;
+    return IGD_HIP_OK;
+}
+
+// the bucket step shared by search and enumerate
+template <bool WITH_Q>
+static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
+                         int nq, int rule, hipStream_t st)
+{
+    const int nT = db->nT;
+    HIPCHK(hipMemsetAsync(db->d_pairCnt, 0, (size_t)nT * 4, st));
+    HIPCHK(hipMemsetAsync(db->d_ctl, 0, 16 * 4, st));
+    const int qb = (nq + 255) / 256;
+    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairCnt, db->d_long, db->d_ctl);
+    const int sb = (nT + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE;
+    k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums);
+    k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos);
+    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairPos, db->d_pairs);
+    HIPCHK(hipGetLastError());
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
+                                  const int32_t *d_qe, int64_t nq, int32_t v, int rule,
+                                  int64_t *d_hits, int64_t *d_total, void *stream)
+{
+    if (!db || !d_hits || nq < 0 || nq > IGD_MAX_BATCH || (rule != IGD_HIP_RULE_NEST && rule != IGD_HIP_RULE_FLAT)) {
+        snprintf(g_err, sizeof g_err, "igd_hip_search_dev: bad argument");
+        return IGD_HIP_ERR_ARG;
+    }
+    if (nq == 0 || db->nT == 0 || db->nFiles == 0) return IGD_HIP_OK;
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = stream ? (hipStream_t)stream : db->stream;
+    int rc = ensure_workspace(db, nq, 8);
+    if (rc != IGD_HIP_OK) return rc;
+    const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
+    int slot = -1;
+    if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
+    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
+    rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, st);
+    if (rc != IGD_HIP_OK) return rc;
+    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
+    if (db->ldsHits) {
+        if (useV)
+            igd_scan_tiles<true, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
+                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, db->d_slab);
+        else
+            igd_scan_tiles<false, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
+                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, db->d_slab);
+        if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+        dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
+        k_reduce_slabs<<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total);
+    } else {
+        if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
+        if (useV)
+            igd_scan_tiles<true, false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
+                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, (u64 *)d_hits);
+        else
+            igd_scan_tiles<false, false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
+                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, (u64 *)d_hits);
+        if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+        if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
+    }
+    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
+    HIPCHK(hipGetLastError());
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_sync(igd_hip_db *db, void *stream)
+{
+    if (!db) return IGD_HIP_ERR_ARG;
+    HIPCHK(hipSetDevice(db->device));
+    HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : db->stream));
+    HIPCHK(hipGetLastError());
+    return IGD_HIP_OK;
+}
+
+static int ensure_qstage(igd_hip_db *db, int64_t nq)
+{
+    if (nq <= db->qcap) return IGD_HIP_OK;
+    HIPCHK(hipDeviceSynchronize());
+    if (db->d_qc) (void)hipFree(db->d_qc);
+    if (db->d_qs) (void)hipFree(db->d_qs);
+    if (db->d_qe) (void)hipFree(db->d_qe);
+    db->d_qc = db->d_qs = db->d_qe = nullptr;
+    db->qcap = 0;
+    int rc;
+    if ((rc = dalloc(&db->d_qc, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&db->d_qs, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&db->d_qe, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+    db->qcap = nq;
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                              int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total)
+{
+    if (!db || !hits || nq < 0 || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_search: bad argument");
+        return IGD_HIP_ERR_ARG;
+    }
+    if (total) *total = 0;
+    if (nq == 0 || db->nFiles == 0) return IGD_HIP_OK;
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = db->stream;
+    HIPCHK(hipMemsetAsync(db->d_hits, 0, (size_t)db->nFiles * 8, st));
+    HIPCHK(hipMemsetAsync(db->d_total, 0, 8, st));
+    for (int64_t q0 = 0; q0 < nq; q0 += IGD_MAX_BATCH) {
+        int64_t m = nq - q0 < IGD_MAX_BATCH ? nq - q0 : IGD_MAX_BATCH;
+        int rc = ensure_qstage(db, m);
+        if (rc != IGD_HIP_OK) return rc;
+        HIPCHK(hipMemcpyAsync(db->d_qc, ichr + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db->d_qs, qs + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(db->d_qe, qe + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, db->d_hits, db->d_total, st);
+        if (rc != IGD_HIP_OK) return rc;
+        HIPCHK(hipStreamSynchronize(st));                 // staging buffers are reused
+    }
+    std::vector<int64_t> h((size_t)db->nFiles);
+    int64_t tot = 0;
+    HIPCHK(hipMemcpy(h.data(), db->d_hits, (size_t)db->nFiles * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&tot, db->d_total, 8, hipMemcpyDeviceToHost));
+    for (int32_t f = 0; f < db->nFiles; f++) hits[f] += h[f];
+    if (total) *total = tot;
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                                 int64_t nq, int64_t *qoff, igd_hip_hit **out, int64_t *total)
+{
+    if (!db || !qoff || !out || nq < 0 || nq > IGD_MAX_BATCH || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate: bad argument (batch limit %lld)", (long long)IGD_MAX_BATCH);
+        return IGD_HIP_ERR_ARG;
+    }
+    *out = nullptr;
+    if (total) *total = 0;
+    for (int64_t i = 0; i <= nq; i++) qoff[i] = 0;
+    if (nq == 0 || db->nT == 0) return IGD_HIP_OK;
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = db->stream;
+    int rc = ensure_qstage(db, nq);
+    if (rc != IGD_HIP_OK) return rc;
+    rc = ensure_workspace(db, nq, 16);
+    if (rc != IGD_HIP_OK) return rc;
+    int32_t *d_pcount = nullptr;
+    int64_t *d_qlong = nullptr, *d_qcount = nullptr, *d_qoff = nullptr;
+    igd_hip_hit *d_out = nullptr;
+    auto cleanup = [&]() {
+        if (d_pcount) (void)hipFree(d_pcount);
+        if (d_qlong) (void)hipFree(d_qlong);
+        if (d_qcount) (void)hipFree(d_qcount);
+        if (d_qoff) (void)hipFree(d_qoff);
+        if (d_out) (void)hipFree(d_out);
+    };
+#define EH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; } } while (0)
+    if ((rc = dalloc(&d_pcount, (size_t)nq * IGD_SHORT_TILES, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+    if ((rc = dalloc(&d_qlong, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+    if ((rc = dalloc(&d_qcount, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+    if ((rc = dalloc(&d_qoff, (size_t)nq + 1, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+    EH(hipMemcpyAsync(db->d_qc, ichr, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    EH(hipMemcpyAsync(db->d_qs, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    EH(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    EH(hipMemsetAsync(d_pcount, 0, (size_t)nq * IGD_SHORT_TILES * 4, st));
+    EH(hipMemsetAsync(d_qlong, 0, (size_t)nq * 8, st));
+    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, st);
+    if (rc != IGD_HIP_OK) { cleanup(); return rc; }
+    igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos, (const int4 *)db->d_pairs,
+        db->d_long, db->d_ctl, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
+    k_enum_qcount<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_pcount, d_qlong, (int)nq, d_qcount);
+    k_scan64<<<1, 1024, 0, st>>>(d_qcount, (int)nq, d_qoff);
+    EH(hipMemcpyAsync(qoff, d_qoff, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    EH(hipStreamSynchronize(st));
+    int64_t tot = qoff[nq];
+    if (total) *total = tot;
+    if (tot > 0) {
+        if ((rc = dalloc(&d_out, (size_t)tot, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+        igd_enum_tiles<true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos, (const int4 *)db->d_pairs,
+            db->d_long, db->d_ctl, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_out);
+        igd_hip_hit *h = (igd_hip_hit *)malloc((size_t)tot * sizeof(igd_hip_hit));
+        if (!h) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_enumerate: host malloc"); return IGD_HIP_ERR_NOMEM; }
+        hipError_t e = hipMemcpyAsync(h, d_out, (size_t)tot * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { free(h); set_err("enumerate fill", e, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; }
+        *out = h;
+    }
+#undef EH
+    cleanup();
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
+                                   const int32_t *d_qe, int64_t nq, int32_t v, int rule, igd_hip_stats *out)
+{
+    if (!db || !out || nq < 0 || nq > IGD_MAX_BATCH) return IGD_HIP_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    if (nq == 0) return IGD_HIP_OK;
+    HIPCHK(hipSetDevice(db->device));
+    u64 *d_acc = nullptr;
+    int64_t *d_h = nullptr, *d_t = nullptr;
+    int rc;
+    if ((rc = dalloc(&d_acc, 4, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&d_h, (size_t)db->nFiles + 1, nullptr)) != IGD_HIP_OK) { (void)hipFree(d_acc); return rc; }
+    if ((rc = dalloc(&d_t, 1, nullptr)) != IGD_HIP_OK) { (void)hipFree(d_acc); (void)hipFree(d_h); return rc; }
+    hipStream_t st = db->stream;
+    (void)hipMemsetAsync(d_acc, 0, 32, st);
+    (void)hipMemsetAsync(d_h, 0, ((size_t)db->nFiles + 1) * 8, st);
+    (void)hipMemsetAsync(d_t, 0, 8, st);
+    k_batch_stats<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, d_acc);
+    bool saved = db->evOn;
+    db->evOn = false;
+    rc = igd_hip_search_dev(db, d_ichr, d_qs, d_qe, nq, v, rule, d_h, d_t, st);
+    db->evOn = saved;
+    u64 acc[4] = {0, 0, 0, 0};
+    int64_t tot = 0;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(acc, d_acc, 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&tot, d_t, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_acc); (void)hipFree(d_h); (void)hipFree(d_t);
+    if (rc != IGD_HIP_OK) return rc;
+    if (e != hipSuccess) { set_err("batch_stats", e, __FILE__, __LINE__); return IGD_HIP_ERR_DEVICE; }
+    out->queries = (int64_t)acc[0]; out->pairs = (int64_t)acc[1];
+    out->S = (int64_t)acc[2]; out->B = (int64_t)acc[3]; out->H = tot;
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_profile_begin(igd_hip_db *db, int max_launches)
+{
+    if (!db || max_launches <= 0) return IGD_HIP_ERR_ARG;
+    HIPCHK(hipSetDevice(db->device));
+    while ((int)db->ev.size() < 4 * max_launches) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        db->ev.push_back(e);
+    }
+    db->evMax = max_launches;
+    db->evUsed = 0;
+    db->evOn = true;
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_scan_ms, double *avg_pipeline_ms)
+{
+    if (!db) return IGD_HIP_ERR_ARG;
+    HIPCHK(hipSetDevice(db->device));
+    db->evOn = false;
+    int n = db->evUsed;
+    double scan = 0, pipe = 0;
+    for (int i = 0; i < n; i++) {
+        HIPCHK(hipEventSynchronize(db->ev[4 * i + 3]));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, db->ev[4 * i + 1], db->ev[4 * i + 2]));
+        HIPCHK(hipEventElapsedTime(&b, db->ev[4 * i + 0], db->ev[4 * i + 3]));
+        scan += a; pipe += b;
+    }
+    if (n_launches) *n_launches = n;
+    if (avg_scan_ms) *avg_scan_ms = n ? scan / n : 0.0;
+    if (avg_pipeline_ms) *avg_pipeline_ms = n ? pipe / n : 0.0;
+    db->evUsed = 0;
+    return IGD_HIP_OK;
+}

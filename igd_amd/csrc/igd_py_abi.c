@@ -1,0 +1,109 @@
+/* igd_py_abi.c -- handle-based flavour (include/igd_py_abi.h) for the Cython wrapper of
+ * /root/reference/src_py.  Thin shim over igd_core + the HIP engine; no CPU search. */
+#define _GNU_SOURCE
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sysexits.h>
+
+#include "igd_py_abi.h"
+#include "igd_core.h"
+#include "igd_create_min.h"
+
+struct iGD_t {
+    igdc_db *core;          /* NULL until open_iGD */
+};
+
+static int device_from_env(void)
+{
+    const char *e = getenv("IGD_DEVICE");
+    return e && *e ? atoi(e) : 0;
+}
+
+static void die_no_gpu(const char *where, int rc)
+{
+    fprintf(stderr, "igd_py: %s: GPU engine unavailable (code %d): %s\n"
+                    "igd_py: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
+    exit(EX_UNAVAILABLE);
+}
+
+iGD_t *iGD_init(void)
+{
+    return (iGD_t *)calloc(1, sizeof(iGD_t));
+}
+
+int32_t get_nFiles(iGD_t *iGD)
+{
+    return iGD && iGD->core ? iGD->core->nFiles : 0;
+}
+
+void open_iGD(iGD_t *iGD, char *igdFile)
+{
+    if (!iGD) return;
+    if (iGD->core) { igdc_close(iGD->core); iGD->core = NULL; }
+    igdc_db *core = igdc_open(igdFile);
+    if (!core) {
+        printf("Can't open file %s", igdFile);
+        return;
+    }
+    char *tsv = igdc_index_path(igdFile);
+    if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
+    free(tsv);
+    int rc = igdc_attach_path(core, igdFile, device_from_env());
+    if (rc != IGD_HIP_OK) { igdc_close(core); die_no_gpu("open_iGD", rc); }
+    iGD->core = core;
+}
+
+void close_iGD(iGD_t *iGD)
+{
+    if (!iGD) return;
+    if (iGD->core) igdc_close(iGD->core);
+    free(iGD);
+}
+
+void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_size)
+{
+    (void)iGD;
+    size_t lo = strlen(oPath), li = strlen(iPath);
+    if (lo && oPath[lo - 1] != '/') strcat(oPath, "/");
+    if (li && iPath[li - 1] == '/') strcat(iPath, "*");
+    else if (li && iPath[li - 1] != '*') strcat(iPath, "/*");
+    size_t L = strlen(oPath) + strlen(igdName) + 8;
+    char *probe = (char *)malloc(L);
+    snprintf(probe, L, "%s%s.igd", oPath, igdName);
+    struct stat st;
+    if (stat(probe, &st) == 0) {
+        printf("The igd database file %s exists!\n", probe);
+        free(probe);
+        return;
+    }
+    free(probe);
+    igdc_create_from_beds(iPath, oPath, igdName, tile_size > 0 ? tile_size : 16384, 1);
+}
+
+void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
+{
+    if (!iGD || !iGD->core) return;
+    int32_t ichr = igdc_get_id(iGD->core, chrm);
+    if (ichr < 0) return;
+    int rc = igd_hip_search(iGD->core->dev, &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
+                            IGD_HIP_RULE_NEST, hits, NULL);
+    if (rc != IGD_HIP_OK) die_no_gpu("get_overlaps", rc);
+}
+
+int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
+{
+    if (!iGD || !iGD->core) return 0;
+    igdc_queries q;
+    if (igdc_read_queries(iGD->core, qFile, 0, &q) != 0) return 0;
+    if (q.n > 0) {
+        int rc = igd_hip_search(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                IGD_HIP_RULE_NEST, hits, NULL);
+        if (rc != IGD_HIP_OK) die_no_gpu("getOverlaps", rc);
+    }
+    igdc_queries_free(&q);
+    int64_t nols = 0;
+    for (int32_t i = 0; i < iGD->core->nFiles; i++) nols += hits[i];
+    return nols;
+}

@@ -1,0 +1,172 @@
+"""Python face of one .igd resident on one MI355X.
+
+Mirrors what the reference's front-ends do around the hot path -- load header + index
+(get_igdinfo / get_fileinfo), map contig names (get_id), read query files (parse_bed loop) --
+and hands every search to the HIP engine (include/igd_hip.h).  numpy arrays for host
+batches; raw device pointers (e.g. torch tensors' data_ptr()) for resident batches."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class IgdError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise IgdError("%s failed (code %d): %s" % (what, rc, N.hip().igd_hip_last_error().decode()))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Database:
+    def __init__(self, igd_path, device=0):
+        self._L = N.cli()
+        self._H = N.hip()
+        self.path = igd_path
+        self._core = self._L.igdc_open(igd_path.encode())
+        if not self._core:
+            raise IgdError("cannot read .igd header of %s" % igd_path)
+        tsv = self._L.igdc_index_path(igd_path.encode())
+        rc = self._L.igdc_load_index(self._core, C.cast(tsv, C.c_char_p))
+        N.free(tsv)
+        if rc != 0:
+            self._L.igdc_close(self._core)
+            self._core = None
+            raise IgdError("cannot read the _index.tsv next to %s" % igd_path)
+        c = self._core.contents
+        self.nbp, self.gtype, self.nctg, self.nfiles = c.nbp, c.gType, c.nCtg, c.nFiles
+        self.nrecords, self.ntiles = c.nRecords, c.nTileTotal
+        self.contig_names = [c.cName[i].decode() for i in range(self.nctg)]
+        self.file_names = [c.fileName[i].decode() for i in range(self.nfiles)]
+        self.file_nr = [c.fileNr[i] for i in range(self.nfiles)]
+        self.ntile = [c.nTile[i] for i in range(self.nctg)]
+        rc = self._L.igdc_attach_path(self._core, igd_path.encode(), int(device))
+        if rc != 0:
+            err = self._H.igd_hip_last_error().decode()
+            self._L.igdc_close(self._core)
+            self._core = None
+            raise IgdError("cannot put %s on GPU %d (code %d): %s -- there is no CPU search path"
+                           % (igd_path, device, rc, err))
+        self.dev = C.c_void_p(self._core.contents.dev)
+        self.device = int(device)
+
+    # ---- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_core", None):
+            self._L.igdc_close(self._core)
+            self._core = None
+            self.dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def resident_bytes(self):
+        return self._H.igd_hip_resident_bytes(self.dev)
+
+    # ---- host helpers (reference: get_id, parse_bed loop) ---------------------------
+    def contig_id(self, name):
+        return self._L.igdc_get_id(self._core, name.encode())
+
+    def read_queries(self, qfile, require_chr=True):
+        q = N.CoreQueries()
+        if self._L.igdc_read_queries(self._core, qfile.encode(), 1 if require_chr else 0, C.byref(q)) != 0:
+            raise IOError("cannot open query file %s" % qfile)
+        n = q.n
+        if n:
+            out = tuple(np.ctypeslib.as_array(p, shape=(n,)).copy() for p in (q.ichr, q.qs, q.qe))
+        else:
+            out = tuple(np.zeros(0, np.int32) for _ in range(3))
+        self._L.igdc_queries_free(C.byref(q))
+        return out
+
+    @staticmethod
+    def cli_dispatch(gtype, v):
+        """(rule, engine v) that `igd search -q ... -v V` selects (src/igd_search.c:1023-1030)."""
+        if gtype != 0 and v > 0:
+            return N.IGD_HIP_RULE_FLAT, int(v)
+        return N.IGD_HIP_RULE_NEST, N.IGD_HIP_NO_VALUE_FILTER
+
+    # ---- searches ---------------------------------------------------------------------
+    def search(self, ichr, qs, qe, v=0, rule=None, value_filter=None, hits=None):
+        """Host batch.  Default: the CLI dispatch for `-v v`.  Returns (hits int64[nfiles], total)."""
+        ichr, qs, qe = _i32(ichr), _i32(qs), _i32(qe)
+        if rule is None:
+            rule, vf = self.cli_dispatch(self.gtype, v)
+        else:
+            vf = N.IGD_HIP_NO_VALUE_FILTER if value_filter is None else int(value_filter)
+        if hits is None:
+            hits = np.zeros(max(self.nfiles, 1), np.int64)
+        total = C.c_int64(0)
+        _chk(self._H.igd_hip_search(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, len(qs),
+                                    vf, rule, hits.ctypes.data, C.byref(total)), "igd_hip_search")
+        return hits[: self.nfiles], total.value
+
+    def search_dev(self, d_ichr, d_qs, d_qe, nq, d_hits, d_total=None, v=0, rule=None,
+                   value_filter=None, stream=None):
+        """Resident batch: arguments are device pointers (ints).  Asynchronous."""
+        if rule is None:
+            rule, vf = self.cli_dispatch(self.gtype, v)
+        else:
+            vf = N.IGD_HIP_NO_VALUE_FILTER if value_filter is None else int(value_filter)
+        _chk(self._H.igd_hip_search_dev(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, d_hits,
+                                        d_total, stream), "igd_hip_search_dev")
+
+    def sync(self, stream=None):
+        _chk(self._H.igd_hip_sync(self.dev, stream), "igd_hip_sync")
+
+    def enumerate(self, ichr, qs, qe):
+        """`-f`: returns (qoff int64[nq+1], records int32[n,4] = q,idx,start,end) in reference order."""
+        ichr, qs, qe = _i32(ichr), _i32(qs), _i32(qe)
+        nq = len(qs)
+        qoff = np.zeros(nq + 1, np.int64)
+        out = C.POINTER(N.HipHit)()
+        total = C.c_int64(0)
+        _chk(self._H.igd_hip_enumerate(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq,
+                                       qoff.ctypes.data, C.byref(out), C.byref(total)), "igd_hip_enumerate")
+        n = total.value
+        if n:
+            rec = np.ctypeslib.as_array(C.cast(out, N.i32p), shape=(n * 4,)).reshape(n, 4).copy()
+            self._H.igd_hip_free(out)
+        else:
+            rec = np.zeros((0, 4), np.int32)
+        return qoff, rec
+
+    def batch_stats(self, d_ichr, d_qs, d_qe, nq, v=0):
+        rule, vf = self.cli_dispatch(self.gtype, v)
+        st = N.HipStats()
+        _chk(self._H.igd_hip_batch_stats(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, C.byref(st)),
+             "igd_hip_batch_stats")
+        return dict(queries=st.queries, pairs=st.pairs, S=st.S, B=st.B, H=st.H)
+
+    def algorithmic_bytes(self, stats, nq, mode="hits"):
+        """bytes one launch has to touch, by the reference's own work terms."""
+        b = 4 * stats["S"] + 4 * stats["H"] + 4 * stats["B"] + 16 * stats["pairs"] + 12 * nq + 8 * self.nfiles
+        if mode == "v":
+            b += 4 * stats["S"]
+        elif mode == "f":
+            b += 4 * stats["H"] + 16 * stats["H"] + 8 * nq
+        return b
+
+    def profile_begin(self, max_launches):
+        _chk(self._H.igd_hip_profile_begin(self.dev, int(max_launches)), "igd_hip_profile_begin")
+
+    def profile_end(self):
+        n, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        _chk(self._H.igd_hip_profile_end(self.dev, C.byref(n), C.byref(a), C.byref(b)), "igd_hip_profile_end")
+        return dict(launches=n.value, scan_ms=a.value, pipeline_ms=b.value)

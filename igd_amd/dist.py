@@ -1,0 +1,38 @@
+"""Multi-GPU: one process per GPU, queries sharded, ONE collective -- the all-reduce of the
+nFiles-long int64 hits vector (RCCL over xGMI when the backend is "nccl"; gloo on CPU for
+tests).  Exactness: hits[] is a sum over queries of non-negative integers, so any partition
+of the queries gives the identical vector."""
+import os
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous slab [lo, hi) of n queries for `rank` (slabs differ by at most one query)."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """torch.distributed process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allreduce_hits(hits_tensor):
+    """In-place SUM all-reduce of the per-rank hits vector (int64).  No-op for world size 1."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hits_tensor, op=dist.ReduceOp.SUM)
+    return hits_tensor

@@ -1,0 +1,128 @@
+/* igd_hip.h -- C ABI of the MI355X (gfx950) overlap-search engine.
+ *
+ * This is the device-side boundary that the three host flavours of the reference's
+ * igd_search.h (include/igd_search.h, include/igd_py_abi.h, include/igdr_abi.h) are built
+ * on.  Plain C: opaque handle, pointers and sizes only, no C++/torch types.
+ *
+ * What it replaces in the reference (databio/IGD, /root/reference):
+ *   igd_hip_search / _dev    the per-query loops  getOverlaps   src/igd_search.c:696-719
+ *                                                 getOverlaps_v src/igd_search.c:746-769
+ *                                                 getOverlaps0  src/igd_search.c:202-225
+ *                            over the kernels     get_overlaps   src/igd_search.c:454-534
+ *                                                 get_overlaps_v src/igd_search.c:623-694
+ *                                                 get_overlaps0  src/igd_search.c:30-112
+ *                            and the hits[] accumulator          src/igd_search.c:925,491,524,654,684
+ *   igd_hip_enumerate        getOverlaps_f1/_f0 src/igd_search.c:721-744,227-250 over
+ *                            get_overlaps_f1/_f0 src/igd_search.c:537-620,114-200
+ *   igd_hip_open             the per-tile fseek/fread of src/igd_search.c:469-476 (the whole
+ *                            tile region is uploaded once, transposed AoS->SoA on the GPU)
+ *
+ * There is NO CPU fallback behind any of these entry points: without a usable HIP device
+ * they return an error code and igd_hip_last_error() says why.
+ */
+#ifndef IGD_HIP_H
+#define IGD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGD_HIP_OK          0
+#define IGD_HIP_ERR_DEVICE  (-1)   /* no device / HIP runtime error          */
+#define IGD_HIP_ERR_ARG     (-2)   /* bad argument                            */
+#define IGD_HIP_ERR_NOMEM   (-3)   /* host or device allocation failed        */
+
+/* Tile-visiting rules. */
+#define IGD_HIP_RULE_NEST 0  /* get_overlaps / get_overlaps0 / _f0 / _f1: an EMPTY first tile
+                                ends the query (loop nested in `if(nCnt[n1]>0)`, :468-532)   */
+#define IGD_HIP_RULE_FLAT 1  /* get_overlaps_v: every tile n1..n2 visited (:635-691)          */
+
+typedef struct igd_hip_db igd_hip_db;          /* opaque: one .igd resident on one GPU      */
+
+/* Host description of an .igd (the header tables of iGD_t, src/igd_base.h:96-105, plus the
+ * raw tile region of the file).  Nothing is retained after igd_hip_open returns. */
+typedef struct {
+    int32_t nbp;              /* tile width in bp                                           */
+    int32_t gType;            /* 1: 16-byte {idx,start,end,value}; 0: 12-byte {idx,start,end}*/
+    int32_t nCtg;
+    int32_t nFiles;           /* length of hits[] (from _index.tsv)                          */
+    const int32_t *nTile;     /* [nCtg]                                                     */
+    const int32_t *nCnt;      /* contig-major, sum(nTile) entries (file order)               */
+    const void *records;      /* host pointer: all tile records in file order (AoS)          */
+    int64_t nRecords;         /* = sum(nCnt)                                                */
+} igd_hip_desc;
+
+/* One emitted overlap of the `-f` path: query number (position in the batch), then the
+ * record as the reference prints it (src/igd_search.c:577,610). */
+typedef struct { int32_t q, idx, start, end; } igd_hip_hit;
+
+/* Exact work statistics of one batch under one rule -- the terms of the algorithmic byte
+ * model.  Instrumentation; not part of a search. */
+typedef struct {
+    int64_t queries;  /* queries with a valid contig and n1 in range                         */
+    int64_t pairs;    /* (query,tile) pairs with cnt>0 && qe > first start                   */
+    int64_t S;        /* sum of scan lengths                                                */
+    int64_t B;        /* sum of ceil(log2(cnt+1))                                           */
+    int64_t H;        /* hits                                                               */
+} igd_hip_stats;
+
+int         igd_hip_device_count(void);               /* <=0: none usable                    */
+const char *igd_hip_last_error(void);                 /* thread-local, never NULL            */
+
+int  igd_hip_open(const igd_hip_desc *desc, int device, igd_hip_db **out);
+void igd_hip_close(igd_hip_db *db);
+int  igd_hip_device(const igd_hip_db *db);
+int32_t igd_hip_nfiles(const igd_hip_db *db);
+int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA image + tables  */
+
+/* `v` of the search calls: records with value < v are not counted (get_overlaps_v's
+ * `value>=v`, src/igd_search.c:652,682).  IGD_HIP_NO_VALUE_FILTER switches the predicate
+ * off (get_overlaps).  Ignored for gType 0, which stores no value (:1024-1025).  Whether a
+ * CLI `-v N` selects the filtered kernel (only N>0, :1027) is the HOST's decision. */
+#define IGD_HIP_NO_VALUE_FILTER INT32_MIN
+
+/* Host-buffer search.  ichr[i] = contig index (as get_id returns; <0 or >=nCtg: skipped).
+ * hits[0..nFiles) is caller-allocated and is ADDED to (reference semantics :491).
+ * *total (may be NULL) receives the number of overlaps of this batch.  Blocking. */
+int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                   int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total);
+
+/* Device-resident search: all pointers are device pointers on db's GPU; d_hits
+ * (int64[nFiles]) is ADDED to; d_total (int64[1], may be NULL) is ADDED to.  Enqueues on
+ * `stream` (a hipStream_t; NULL = the engine's own stream) and returns without waiting.
+ * nq must be <= igd_hip_max_batch(). */
+int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
+                       const int32_t *d_qe, int64_t nq, int32_t v, int rule,
+                       int64_t *d_hits, int64_t *d_total, void *stream);
+int64_t igd_hip_max_batch(void);
+int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
+
+/* `-f`: full enumeration in reference order (queries in batch order; per query tiles
+ * ascending, record index DESCENDING inside a tile; rule NEST, no value filter).
+ * qoff[0..nq] receives the exclusive scan of per-query counts; *out is malloc'd by the
+ * callee (free with igd_hip_free) and holds qoff[nq] records.  Blocking. */
+int  igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs,
+                       const int32_t *qe, int64_t nq, int64_t *qoff, igd_hip_hit **out,
+                       int64_t *total);
+void igd_hip_free(void *p);
+
+/* Instrumentation ------------------------------------------------------------------- */
+/* Exact algorithmic-work terms for a device-resident batch (blocking). */
+int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
+                        const int32_t *d_qe, int64_t nq, int32_t v, int rule,
+                        igd_hip_stats *out);
+/* HIP-event timing of the launches made by igd_hip_search_dev on their own stream:
+ * begin() arms up to max_launches slots, end() waits and returns the number of launches
+ * seen plus the average duration (ms) of the dominant scan kernel and of the whole
+ * pipeline (bucket + scan + reduce). */
+int igd_hip_profile_begin(igd_hip_db *db, int max_launches);
+int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_scan_ms,
+                        double *avg_pipeline_ms);
+/* Name of the dominant kernel as rocprofv3 --kernel-trace prints it (for profiles/). */
+const char *igd_hip_scan_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

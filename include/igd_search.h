@@ -1,0 +1,49 @@
+/* igd_search.h -- CLI/libigd flavour of the overlap-search API: same names, argument
+ * meaning, return values and error behaviour as /root/reference/src/igd_search.h:15-41,
+ * executed on an MI355X through include/igd_hip.h.
+ *
+ * Contract kept from the reference:
+ *   - preconditions are the globals of igd_base.h: IGD/hc set by get_igdinfo(), fP opened on
+ *     the .igd by the caller (src/igd_search.c:974);
+ *   - `hits` is caller-allocated (nFiles int64), caller-zeroed, and is ADDED to;
+ *   - unknown contig, tile past the end, unopenable query file: silent, returns 0;
+ *   - get_overlaps/getOverlaps(/0) return 0 (the reference never increments its counter
+ *     there, src/igd_search.c:533), get_overlaps_v/getOverlaps_v return the overlap count;
+ *   - not thread-safe (process-wide state), like the reference.
+ * New, and the only observable difference: the first search call uploads the whole tile
+ * region to the GPU (instead of fseek/fread per tile, :469-476); if no HIP device can be
+ * used the call prints the reason on stderr and aborts -- there is no CPU fallback.
+ * GPU selection: environment variable IGD_DEVICE (default 0).
+ *
+ * Out of scope (declared by the reference, not provided here):
+ * seq_overlaps/seqOverlaps (Seqpare), getMap/getMap_v (hit map).
+ */
+#ifndef __IGD_SEARCH_H__
+#define __IGD_SEARCH_H__
+#include "igd_base.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* one query -------------------------------------------------------------------------- */
+int32_t get_overlaps  (char *chrm, int32_t qs, int32_t qe, int64_t *hits);             /* :454-534 */
+int32_t get_overlaps_v(char *chrm, int32_t qs, int32_t qe, int32_t v, int64_t *hits);  /* :623-694 */
+int32_t get_overlaps0 (char *chrm, int32_t qs, int32_t qe, int64_t *hits);             /* :30-112  */
+int32_t get_overlaps_f1(char *chrm, int32_t qs, int32_t qe);                           /* :537-620 */
+int32_t get_overlaps_f0(char *chrm, int32_t qs, int32_t qe);                           /* :114-200 */
+
+/* a BED / BED.gz file of queries ----------------------------------------------------- */
+int64_t getOverlaps  (char *qFile, int64_t *hits);                                     /* :696-719 */
+int64_t getOverlaps_v(char *qFile, int64_t *hits, int32_t v);                          /* :746-769 */
+int64_t getOverlaps0 (char *qFile, int64_t *hits);                                     /* :202-225 */
+int64_t getOverlaps_f1(char *qFile);                                                   /* :721-744 */
+int64_t getOverlaps_f0(char *qFile);                                                   /* :227-250 */
+
+/* `igd search <db.igd> [-q file | -r chr s e] [-v N] [-f] [-o name] [-c]`             :889-1079 */
+int igd_search(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

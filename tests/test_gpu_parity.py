@@ -1,0 +1,161 @@
+"""GPU parity: the HIP engine (through the C ABI of include/igd_hip.h and the host flavours)
+against the CPU oracle on the same inputs.  Integer work: every comparison is bit-exact.
+
+Databases here are written by the INDEPENDENT numpy writer of tests/helpers.py (not by the
+product's writer) unless a test says otherwise."""
+import os
+import random
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, Oracle, run_oracle_cli, short_tmpdir, write_bed, write_igd_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workdir():
+    d = short_tmpdir("igp")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _random_db(rng, d, name, nbp, gtype, nfiles, nctg, span_tiles, dens, hot=0):
+    """files -> list of (chrom,start,end,value); returns path"""
+    ctgs = ["chr%d" % (i + 1) for i in range(nctg)]
+    span = nbp * span_tiles
+    files = []
+    for f in range(nfiles):
+        rows = []
+        for _ in range(dens):
+            c = rng.choice(ctgs)
+            if rng.random() < 0.5:
+                L = rng.choice([1, 5, nbp // 3, nbp, 3 * nbp + 7, 6 * nbp + 1])
+            else:
+                L = rng.randint(1, 2 * nbp)
+            s = rng.randrange(0, span)
+            if rng.random() < 0.2:
+                s = (s // nbp) * nbp
+            rows.append((c, s, s + L, rng.randint(0, 1000)))
+        for _ in range(hot):  # a very dense tile: > 512 records -> several chunks per tile
+            s = 5 * nbp + rng.randrange(0, nbp)
+            rows.append((ctgs[0], s, s + rng.randint(1, nbp // 2), rng.randint(0, 1000)))
+        files.append(rows)
+    path = os.path.join(d, name + ".igd")
+    write_igd_numpy(path, files, nbp=nbp, gtype=gtype)
+    return path, ctgs, span
+
+
+def _random_queries(rng, ctg_ids, nbp, span, n):
+    ichr = np.array([rng.choice(ctg_ids + [-1, 99]) for _ in range(n)], np.int32)
+    qs = np.array([rng.randrange(0, span + 3 * nbp) for _ in range(n)], np.int32)
+    ln = np.array([rng.choice([0, 1, nbp, 5 * nbp, 9 * nbp + 3, rng.randint(1, 3 * nbp), -rng.randint(1, 50)])
+                   for _ in range(n)], np.int32)
+    return ichr, qs, qs + ln
+
+
+CASES = [
+    # nbp, gtype, nfiles, nctg, span_tiles, dens, hot
+    (1 << 11, 1, 5, 2, 8, 3, 0),        # sparse: many empty tiles -> rule NEST vs FLAT differ
+    (1 << 11, 1, 12, 1, 3, 200, 0),     # dense small
+    (1 << 12, 0, 7, 3, 40, 20, 0),      # gType 0
+    (1 << 14, 1, 9, 2, 8, 40, 150),     # hot tile with > 512 records (multi-chunk)
+    (1 << 12, 1, 3, 1, 40, 1, 0),       # nearly empty
+    (1 << 11, 1, 33, 3, 20, 60, 40),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_counts_match_oracle(case, workdir):
+    from igd_amd import Database
+    rng = random.Random(4242 + case)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[case]
+    path, ctgs, span = _random_db(rng, workdir, "c%d" % case, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        assert (db.nfiles, db.nctg, db.nbp, db.gtype) == (orc.nfiles, orc.nctg, orc.nbp, orc.gtype)
+        ichr, qs, qe = _random_queries(rng, list(range(nctg)), nbp, span, 3000)
+        for v in (0, 1, 300, 500, 1000, 1001):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            got, gtot = db.search(ichr, qs, qe, v)
+            assert gtot == wtot, (case, v)
+            np.testing.assert_array_equal(got, want, err_msg="case %d v %d" % (case, v))
+        # the two rules differ exactly where the oracle says they do (empty first tile)
+        if gtype == 1:
+            nest, _ = db.search(ichr, qs, qe, 0)
+            flat, _ = db.search(ichr, qs, qe, 1)     # v=1 keeps value>=1: compare against oracle only
+            w_flat, _ = orc.search(ichr, qs, qe, 1)
+            np.testing.assert_array_equal(flat, w_flat)
+            assert nest.sum() <= orc.search(ichr, qs, qe, 0)[0].sum()
+    finally:
+        db.close()
+        orc.close()
+
+
+@pytest.mark.parametrize("case", [0, 1, 3, 5])
+def test_enumerate_matches_oracle(case, workdir):
+    from igd_amd import Database
+    rng = random.Random(777 + case)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[case]
+    path, ctgs, span = _random_db(rng, workdir, "e%d" % case, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, list(range(nctg)), nbp, span, 1500)
+        wqoff, wrec = orc.enumerate(ichr, qs, qe)
+        gqoff, grec = db.enumerate(ichr, qs, qe)
+        np.testing.assert_array_equal(gqoff, wqoff)
+        np.testing.assert_array_equal(grec[:, 1:], wrec)          # idx,start,end in reference order
+        # q column = owning query
+        owner = np.repeat(np.arange(len(qs)), np.diff(wqoff))
+        np.testing.assert_array_equal(grec[:, 0], owner)
+    finally:
+        db.close()
+        orc.close()
+
+
+def test_accumulates_into_caller_hits(workdir):
+    """hits is caller-zeroed and ADDED to (src/igd_search.c:491): two calls sum up."""
+    from igd_amd import Database
+    rng = random.Random(5)
+    path, ctgs, span = _random_db(rng, workdir, "acc", 1 << 12, 1, 6, 2, 10, 50)
+    db = Database(path)
+    orc = Oracle(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, [0, 1], 1 << 12, span, 500)
+        h = np.zeros(db.nfiles, np.int64)
+        db.search(ichr, qs, qe, hits=h)
+        db.search(ichr, qs, qe, hits=h)
+        np.testing.assert_array_equal(h, 2 * orc.search(ichr, qs, qe)[0])
+    finally:
+        db.close()
+        orc.close()
+
+
+def test_cli_text_identical_to_oracle_cli(workdir):
+    """bin/igd search -q / -v / -f / -r prints exactly what the reference prints (the oracle CLI
+    is pinned to the reference's stdout by tests/test_oracle_vs_ref.py and tests/golden)."""
+    rng = random.Random(99)
+    nbp = 1 << 12
+    path, ctgs, span = _random_db(rng, workdir, "cli", nbp, 1, 11, 3, 12, 30)
+    rows = []
+    for _ in range(400):
+        c = rng.choice(ctgs + ["chr7", "2"])
+        s = rng.randrange(0, span + 2 * nbp)
+        L = rng.choice([0, 1, nbp, 5 * nbp, rng.randint(1, 3 * nbp), -rng.randint(1, 50)])
+        rows.append((c, s, s + L))
+    qf = os.path.join(workdir, "cli_q.bed")
+    write_bed(qf, rows)
+    exe = os.path.join(ROOT, "bin", "igd")
+    for extra in ([], ["-v", "1"], ["-v", "500"], ["-f"]):
+        args = ["search", path, "-q", qf] + extra
+        got = subprocess.run([exe] + args, stdout=subprocess.PIPE, check=True).stdout.decode()
+        assert got == run_oracle_cli(args), extra
+    for extra in ([], ["-v", "400"], ["-f"]):
+        args = ["search", path, "-r", ctgs[1], "5000", "30000"] + extra
+        got = subprocess.run([exe] + args, stdout=subprocess.PIPE, check=True).stdout.decode()
+        assert got == run_oracle_cli(args), extra
