@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark of BASELINE.json: query-intervals/s of the overlap
+search (igd search -q, hits-only) on a roadmap-scale synthetic .igd, on N MI355X of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of Q device-resident queries per GPU:
+bucket (count/scan/scatter) -> igd_scan_tiles -> slab reduce, then (N>1) ONE RCCL all-reduce of
+the nFiles-long int64 hits vector.  Weak scaling: every rank owns the same database and its
+own Q queries.  Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     : dominant kernel (igd_scan_tiles) -- algorithmic bytes per launch (SURVEY.md 8d
+                 terms, computed exactly on the GPU by igd_hip_batch_stats) / its HIP-event time
+  cpu_baseline : the REAL reference `igd search -q` (oracle/_ref/igd, kind "reference") on the
+                 same .igd and the same queries as BED text, 1 thread; falls back to the oracle
+                 port (kind "port") when the prebuilt reference binary did not travel.
+The oracle / reference are used here ONLY for that baseline and to check the GPU totals.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def ensure_db(path, files, per_file, rank, world, barrier):
+    """rank 0 generates the .igd (deterministic, ~20 s for the roadmap scale); others wait."""
+    from igd_amd import synth
+    done = path + ".done"
+    if rank == 0 and not (os.path.exists(path) and os.path.exists(done)):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        t = time.time()
+        synth.make_db(path, files=files, per_file=per_file, seed=1000, nbp_log=14, genome=synth.HG38)
+        open(done, "w").write("ok")
+        log("[bench] generated %s in %.1f s" % (path, time.time() - t))
+    barrier()
+    while not os.path.exists(done):
+        time.sleep(0.2)
+
+
+def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5):
+    """Reference CLI on the host, single thread, page cache warm, best of `repeats`."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "igd")
+    port = os.path.join(ROOT, "oracle", "_build", "igd_oracle")
+    if os.path.exists(ref) and len(igd_path) < 60:
+        exe, kind = ref, "reference"
+    else:
+        if not os.path.exists(port):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        exe, kind = port, "port"
+    best, total = None, None
+    for _ in range(repeats):
+        t = time.perf_counter()
+        out = subprocess.run([exe, "search", igd_path, "-q", bed_path], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, check=True).stdout
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+        for line in out.decode().splitlines()[-2:]:
+            if line.startswith("Total:"):
+                total = int(line.split(":")[1])
+    ok = (total == expect_total)
+    return {"value": nq / best, "unit": "query-intervals/s", "cores": 1, "kind": kind,
+            "sample": "all %d position-sorted queries of the workload as BED text through `%s search -q`, "
+                      "end to end (parse+search+print), best of %d, page cache warm; Total %s GPU (%s)"
+                      % (nq, os.path.basename(exe), repeats, "==" if ok else "!=", total),
+            "seconds": best, "totals_match_gpu": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--queries", type=int, default=1000000, help="queries per GPU per step")
+    ap.add_argument("--files", type=int, default=1900)
+    ap.add_argument("--per-file", type=int, default=26316)
+    ap.add_argument("--shuffled", action="store_true", help="queries in generation order, not position-sorted")
+    ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
+    ap.add_argument("--dir", default="/tmp/igdb")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from igd_amd import Database, synth
+    from igd_amd.dist import allreduce_hits, init_from_env
+
+    rank, world, local = init_from_env()
+    if world != args.gpus:
+        log("[bench] note: WORLD_SIZE=%d, --gpus=%d (using WORLD_SIZE)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: igd_amd has no CPU search path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    igd_path = os.path.join(args.dir, "rm%dx%d.igd" % (args.files, args.per_file))
+    ensure_db(igd_path, args.files, args.per_file, rank, world, barrier)
+
+    t = time.time()
+    db = Database(igd_path, device=local)
+    open_s = time.time() - t
+    Q = args.queries
+    ichr, qs, qe = synth.make_queries(Q, seed=7 + rank, genome=synth.HG38, sorted_=not args.shuffled)
+    d_ichr = torch.from_numpy(ichr).to(dev)
+    d_qs = torch.from_numpy(qs).to(dev)
+    d_qe = torch.from_numpy(qe).to(dev)
+    d_hits = torch.zeros(max(db.nfiles, 1), dtype=torch.int64, device=dev)
+    d_acc = torch.zeros_like(d_hits)
+    # One explicit (non-default) stream carries everything: torch's memsets/adds, the engine's
+    # kernels (it enqueues on the hipStream_t it is given) and the RCCL all-reduce.
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize(dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
+
+    def step():
+        d_hits.zero_()
+        db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
+                      v=args.v, stream=stream)
+        allreduce_hits(d_hits)              # the one collective of the path (no-op at N=1)
+        d_acc.add_(d_hits)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    d_acc.zero_()
+    barrier()
+    torch.cuda.synchronize(dev)
+    db.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    prof = db.profile_end()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # exact algorithmic work of one launch on this rank's batch (outside the timed region)
+    st = db.batch_stats(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, v=args.v)
+    mode = "v" if (args.v > 0 and db.gtype == 1) else "hits"
+    algo_bytes = db.algorithmic_bytes(st, Q, mode)
+    hits_one = (d_acc // max(args.steps, 1)).cpu().numpy()
+
+    if rank == 0:
+        value = world * Q * args.steps / elapsed
+        scan_s = prof["scan_ms"] * 1e-3
+        achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
+        line = {
+            "metric": "query-intervals/sec (igd search -q, hits-only) on roadmap-scale synthetic .igd",
+            "value": value, "unit": "query-intervals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "roadmap-scale synthetic IGD: %d files x %d intervals (%d tile records, "
+                                   "%d tiles of 16384 bp, hg38 contigs) + %d %s queries per GPU per step, "
+                                   "%s, queries and DB resident in HBM"
+                                   % (args.files, args.per_file, db.nrecords, db.ntiles, Q,
+                                      "generation-order" if args.shuffled else "position-sorted",
+                                      "-v %d signal filter" % args.v if mode == "v" else "hits-only"),
+                       "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world,
+                       "collective": "all-reduce int64[%d] per step" % db.nfiles if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "bytes_per_query": algo_bytes / Q, "kernel_ms": prof["scan_ms"],
+                         "pipeline_ms": prof["pipeline_ms"], "launches_timed": prof["launches"],
+                         "work": st},
+            "hits_per_step_total": int(hits_one.sum()) if world == 1 else None,
+            "db_open_s": open_s,
+        }
+        if world == 1 and not args.no_cpu:
+            bed = os.path.join(args.dir, "q%d_%s.bed" % (Q, "shuf" if args.shuffled else "sorted"))
+            if not os.path.exists(bed):
+                synth.write_bed(bed, synth.HG38, ichr, qs, qe)
+            extra = ["-v", str(args.v)] if mode == "v" else []
+            if not extra:
+                line["cpu_baseline"] = cpu_baseline(igd_path, bed, Q, int(hits_one.sum()))
+        print(json.dumps(line), flush=True)
+    db.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
