@@ -12,10 +12,10 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
 CFLAGS  ?= -O2 -g -std=gnu99 -Wall -Wextra -Wno-unused-parameter -fPIC
-HIPFLAGS?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function
+HIPFLAGS?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function $(EXTRA)
 INC     := -Iinclude -Iigd_amd/csrc
 SRC     := igd_amd/csrc
-LIB     := igd_amd/lib
+LIB     ?= igd_amd/lib
 RPATH   := -Wl,-rpath,'$$ORIGIN' -Wl,-Bsymbolic
 
 all: $(LIB)/libigd_hip.so $(LIB)/libigd.so $(LIB)/libigd_py.so $(LIB)/libigdr.so \

@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--grouping", choices=["auto", "sorted", "bucket"], default="auto",
+                    help="auto: the device checks the query order and picks merge-join or bucketing (default); "
+                         "sorted: promise (contig,start) order, verified on the device; bucket: always counting-sort")
     args = ap.parse_args()
 
     import numpy as np
@@ -128,10 +131,12 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
+    gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping]
+
     def step():
         d_hits.zero_()
         db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
-                      v=args.v, stream=stream)
+                      v=args.v, stream=stream, flags=gflags)
         allreduce_hits(d_hits)              # the one collective of the path (no-op at N=1)
         d_acc.add_(d_hits)
 
@@ -148,6 +153,7 @@ def main():
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
+    db.sync(stream)                      # surfaces a broken --grouping sorted promise
     prof = db.profile_end()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -175,7 +181,7 @@ def main():
                                    % (args.files, args.per_file, db.nrecords, db.ntiles, Q,
                                       "generation-order" if args.shuffled else "position-sorted",
                                       "-v %d signal filter" % args.v if mode == "v" else "hits-only"),
-                       "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world,
+                       "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
                        "collective": "all-reduce int64[%d] per step" % db.nfiles if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

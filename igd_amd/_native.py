@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("IGD_AMD_LIBDIR") or os.path.join(HERE, "lib")   # override: kernel-variant experiments
 
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
@@ -23,6 +23,25 @@ def build(verbose=False):
     """Compile every native target for gfx950 (hipcc cross-compiles without a GPU)."""
     out = None if verbose else subprocess.DEVNULL
     subprocess.check_call(["make", "-C", ROOT, "all"], stdout=out)
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process cannot both own the GPU, so when torch is installed but not imported
+    yet, map ITS runtime first; libigd_hip.so's NEEDED libamdhip64.so.7 then binds to it by
+    SONAME and a later `import torch` finds its own file already mapped."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("IGD_AMD_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
 
 
 def _load(name):
@@ -66,6 +85,9 @@ class CoreQueries(C.Structure):
 IGD_HIP_RULE_NEST = 0
 IGD_HIP_RULE_FLAT = 1
 IGD_HIP_NO_VALUE_FILTER = -(2 ** 31)
+IGD_HIP_FLAG_SORTED = 1
+IGD_HIP_FLAG_BUCKET = 2
+IGD_HIP_ERR_UNSORTED = -4
 
 _hip = None
 _cli = None
@@ -78,6 +100,7 @@ def hip():
     """libigd_hip.so -- include/igd_hip.h"""
     global _hip
     if _hip is None:
+        _share_hip_runtime_with_torch()
         L = _load("libigd_hip.so")
         L.igd_hip_device_count.restype = C.c_int
         L.igd_hip_last_error.restype = C.c_char_p
@@ -89,8 +112,10 @@ def hip():
         L.igd_hip_resident_bytes.restype = C.c_int64
         L.igd_hip_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                      C.c_int32, C.c_int, C.c_void_p, i64p]
+        L.igd_hip_search_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_int, C.c_int, C.c_void_p, i64p]
         L.igd_hip_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                         C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                                         C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.igd_hip_max_batch.restype = C.c_int64
         L.igd_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.igd_hip_enumerate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

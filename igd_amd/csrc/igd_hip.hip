@@ -10,9 +10,16 @@
 // Design (DESIGN.md has the long form).  The reference walks queries and, per query, seeks
 // a tile, bisects it for the last start<qe and scans backwards testing end>qs.  Here the
 // loop is turned inside out so that BOTH sides stream:
-//   1. bucket: every (query, visited tile) pair is counting-sorted by tile id
-//      (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); the NEST/FLAT visiting rule and
-//      the "first tile" notion live entirely in this step.
+//   1. group the queries by tile.  Two ways, chosen ON THE DEVICE per batch:
+//      a. queries already ordered by (contig, start) -- what a position-sorted BED gives:
+//         k_query_bounds finds, in one pass and without atomics, the first query of every
+//         tile (firstQ[]) and verifies the order; the scan kernel then reads the queries of
+//         tile t and of the up-to-3 tiles before it straight from the caller's arrays
+//         (a merge join: both sides stream);
+//      b. any other order: every (query, visited tile) pair is counting-sorted by tile id
+//         (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); these kernels return at once
+//         when (a) holds.
+//      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
 //   2. scan:   igd_scan_tiles -- one wavefront owns one <=512-record chunk of one tile.  It
 //      loads the chunk's start/end/idx[/value] once, coalesced, into 8 register slots
 //      (record r*64+lane), then runs through the tile's pairs, whose (qs,qe) it fetches 64 at
@@ -38,8 +45,8 @@
 #include "igd_hip.h"
 
 #define IGD_WAVE 64
-#define IGD_SLOTS 8                          // register slots per array per lane
-#define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (512)
+#define IGD_SLOTS 6                          // register slots per array per lane
+#define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (384)
 #define IGD_SHORT_TILES 4                    // queries spanning more tiles take the long path
 #define IGD_WG 512                           // threads per scan workgroup (8 waves)
 #define IGD_MAX_BATCH (1ll << 24)            // queries per device batch
@@ -50,6 +57,11 @@
 #define IGD_LDS_HITS_MAX_BYTES (128 * 1024)
 
 typedef unsigned long long u64;
+
+// tuning / experiment knobs (defaults are the shipped configuration)
+#ifndef IGD_EXP_NOATOMIC
+#define IGD_EXP_NOATOMIC 0    // measurement only: drop the LDS atomics (wrong results)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -84,8 +96,25 @@ extern "C" int64_t igd_hip_max_batch(void) { return IGD_MAX_BATCH; }
 
 // ------------------------------------------------------------------------------------------
 // device view of one database (passed to kernels by value)
+// One unit of scan work: a chunk of <= IGD_CHUNK records of one tile (32 bytes, one s_load_dwordx8).
+// Every tile has at least one unit; an empty tile gets a placeholder with n == 0 so that the
+// long queries that START in it still have an owner in the sorted path.
+struct __attribute__((aligned(32))) Unit {
+    int64_t off;      // index of the unit's first record in the SoA arrays
+    int32_t tile;     // global tile id
+    int32_t n;        // records in this unit
+    int32_t bd;       // tile start coordinate j*nbp (INT_MIN for j == 0)
+    int32_t jf;       // (j << 4) | flags; j = tile index inside its contig;
+                      // flag bit 0: first unit of its tile; bit k (1..3): tile j-k of the contig is EMPTY
+    int32_t ctg;      // contig index
+    int32_t mT;       // last tile index of the contig (nTile - 1)
+};
+#define UNIT_J(u) ((u).jf >> 4)
+#define UNIT_FLAGS(u) ((u).jf & 15)
+
 struct DbView {
-    int32_t nbp, nCtg, nT, nChunks, nFiles;
+    int32_t nbp, shift, nCtg, nT, nChunks, nUnits, nFiles;
+    const Unit *units;
     const int32_t *start, *end, *idx, *value;   // SoA over all records, file order
     const int64_t *tileOff;                     // [nT+1] record offset of each tile
     const int32_t *tileCnt;                     // [nT]
@@ -105,7 +134,12 @@ struct igd_hip_db {
     int32_t *d_start, *d_end, *d_idx, *d_value;
     int64_t *d_tileOff;
     int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_chunkTile, *d_chunkRec0;
+    Unit *d_units;
+    int32_t nUnits;
     int64_t resident;
+    int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
+    int32_t epoch;                // batch counter: device-side flags are compared against it
+    int32_t promised;             // epoch of the last batch launched under IGD_HIP_FLAG_SORTED (0: none)
     // per-batch workspace
     int32_t *d_pairCnt, *d_pairPos, *d_blockSums;
     void *d_pairs;                // int2[cap*K] (or int4 for the enumerate path)
@@ -162,6 +196,17 @@ __global__ void k_idx_range(const int32_t *__restrict__ idx, int64_t n, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// coordinate -> tile index with C semantics (truncation toward zero), src/igd_search.c:459
+__device__ __forceinline__ int tile_of(const DbView &db, int x)
+{
+    if (db.shift >= 0) {
+        unsigned m = x < 0 ? 0u - (unsigned)x : (unsigned)x;
+        int t = (int)(m >> db.shift);
+        return x < 0 ? -t : t;
+    }
+    return x / db.nbp;
+}
+
 // Tile span of one query = the prologue of every reference kernel (src/igd_search.c:455-467):
 // n1=qs/nbp, n2=(qe-1)/nbp (C division), n1>mTile -> nothing, n2 clamped, and for rule NEST an
 // empty first tile ends the query (:468).  Returns false when the query visits nothing.
@@ -169,8 +214,8 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
                                            int &gt0, int &ntl)
 {
     if (c < 0 || c >= db.nCtg) return false;
-    int n1 = qs / db.nbp;
-    int n2 = (int)((unsigned)qe - 1u) / db.nbp;
+    int n1 = tile_of(db, qs);
+    int n2 = tile_of(db, (int)((unsigned)qe - 1u));
     int mT = db.ctgNTile[c] - 1;
     if (n1 < 0 || n1 > mT) return false;      // n1<0: out-of-bounds read in the reference
     if (n2 > mT) n2 = mT;
@@ -180,18 +225,80 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
     return true;
 }
 
-// bucket step 1: per-tile pair counts (+ the list of long queries)
+// Control words shared by the kernels of one batch (int32 ctl[16]):
+//   ctl[1] = epoch of the last batch whose queries were NOT ordered by tile
+//   ctl[2] = epoch of the last batch that broke a caller's IGD_HIP_FLAG_SORTED promise
+//   ctl[4 + (epoch & 1)] = number of long queries listed by k_count_pairs in this batch
+#define CTL_UNSORTED 1
+#define CTL_BROKEN 2
+#define CTL_NLONG 4
+
+// Sorted path, step 1.  key(i) = global tile id of query i's FIRST tile, clamped into the
+// tile range of its contig (unknown contigs go to the ends), so a batch ordered by
+// (contig, start) has non-decreasing keys.  firstQ[t] = first i with key(i) >= t, for
+// t = 0..nT (firstQ[nT] = nq).  A decreasing key marks the batch unsorted (ctl[1] = epoch).
+__device__ __forceinline__ int tile_key(const DbView &db, int c, int qs)
+{
+    if (c < 0) return 0;
+    if (c >= db.nCtg) return db.nT - 1;
+    int n1 = tile_of(db, qs);
+    int mT = db.ctgNTile[c] - 1;
+    n1 = n1 < 0 ? 0 : (n1 > mT ? mT : n1);
+    return db.ctgBase[c] + n1;
+}
+
+__global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
+                                                      const int32_t *__restrict__ qs, int nq,
+                                                      int32_t *__restrict__ firstQ,
+                                                      int32_t *__restrict__ ctl, int epoch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;     // next batch's long-query counter
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
+    int val = i;
+    if (i < nq) {
+        const int k = tile_key(db, ichr[i], qs[i]);
+        const int prev = i ? tile_key(db, ichr[i - 1], qs[i - 1]) : -1;
+        if (k < prev) ctl[CTL_UNSORTED] = epoch;
+        lo = prev + 1; hi = k;
+        if (i == nq - 1 && k < prev) { lo = 0; hi = -1; }
+    }
+    // short gaps by the owner, long gaps by the whole wave
+    const bool big = hi - lo >= 8;
+    if (!big) for (int t = lo; t <= hi; t++) firstQ[t] = val;
+    unsigned long long m = __ballot(big);
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        m &= m - 1;
+        const int l2 = __builtin_amdgcn_readlane(lo, src), h2 = __builtin_amdgcn_readlane(hi, src);
+        const int v2 = __builtin_amdgcn_readlane(val, src);
+        for (int t = l2 + lane; t <= h2; t += IGD_WAVE) firstQ[t] = v2;
+    }
+    // the tail: tiles after the last query's key (done by the last wave)
+    if (nq > 0 && (nq - 1) / IGD_WAVE == i / IGD_WAVE) {
+        const int kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
+        for (int t = kl + 1 + lane; t <= db.nT; t += IGD_WAVE) firstQ[t] = nq;
+    }
+}
+
+// Bucket path (any query order).  `gate`: 0 = always run; otherwise run only when
+// ctl[CTL_UNSORTED] == gate, i.e. when k_query_bounds found this batch unsorted.
+// step 1: per-tile pair counts (+ the list of long queries)
 __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
                               const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                               int nq, int rule, int32_t *__restrict__ pairCnt,
-                              int32_t *__restrict__ longList, int32_t *__restrict__ ctl)
+                              int32_t *__restrict__ longList, int32_t *__restrict__ ctl,
+                              int gate, int epoch)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gate == 0 && i == 0) ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+    if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     if (i >= nq) return;
     int gt0, ntl;
     if (!query_span(db, ichr[i], qs[i], qe[i], rule, gt0, ntl)) return;
     if (ntl > IGD_SHORT_TILES) {
-        int p = atomicAdd(&ctl[0], 1);
+        int p = atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1);
         longList[p] = i;
         return;
     }
@@ -199,10 +306,13 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
         if (db.tileCnt[gt0 + k] > 0) atomicAdd(&pairCnt[gt0 + k], 1);
 }
 
-// bucket step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol)
+// step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol).  The
+// apply kernel also moves the counts to pairN and leaves pairCnt zeroed for the next batch.
 __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_block_sums(const int32_t *__restrict__ in,
-                                                                    int n, int32_t *__restrict__ blockSums)
+                                                                    int n, int32_t *__restrict__ blockSums,
+                                                                    const int32_t *__restrict__ ctl, int gate)
 {
+    if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     __shared__ int32_t red[IGD_SCAN_BLOCK / IGD_WAVE];
     int base = blockIdx.x * IGD_SCAN_TILE + threadIdx.x * IGD_SCAN_ITEMS;
     int s = 0;
@@ -219,10 +329,13 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_block_sums(const int32_
     }
 }
 
-__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(const int32_t *__restrict__ in, int n,
+__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(int32_t *__restrict__ in, int n,
                                                                const int32_t *__restrict__ blockSums,
-                                                               int32_t *__restrict__ out)
+                                                               int32_t *__restrict__ out,
+                                                               int32_t *__restrict__ copy,
+                                                               const int32_t *__restrict__ ctl, int gate)
 {
+    if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     __shared__ int32_t red[IGD_SCAN_BLOCK / IGD_WAVE];
     __shared__ int32_t wsum[IGD_SCAN_BLOCK / IGD_WAVE];
     // prefix of the earlier blocks' sums (every block recomputes it; a few hundred values)
@@ -255,19 +368,23 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(const int32_t *__
     int run = blockPre + wavePre + inc - s;
 #pragma unroll
     for (int k = 0; k < IGD_SCAN_ITEMS; k++) {
-        if (base + k < n) out[base + k] = run;
+        if (base + k < n) {
+            out[base + k] = run;
+            if (copy) { copy[base + k] = v[k]; in[base + k] = 0; }
+        }
         run += v[k];
     }
 }
 
-// bucket step 3: scatter (qs,qe[,q]) of every pair to its tile's slot range.  After this kernel
+// step 3: scatter (qs,qe[,q]) of every pair to its tile's slot range.  After this kernel
 // pairPos[t] is the END of tile t's range.  WITH_Q: the enumerate path also needs the query id.
 template <bool WITH_Q>
 __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
                                 const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                 int nq, int rule, int32_t *__restrict__ pairPos,
-                                void *__restrict__ pairs)
+                                void *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate)
 {
+    if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     int gt0, ntl;
@@ -286,7 +403,7 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 // ------------------------------------------------------------------------------------------
 // The scan kernel.
 //
-// Records of one chunk sit in registers: slot r of lane l is record rec0 + r*64 + l of the tile
+// Records of one unit sit in registers: slot r of lane l is record r*64 + l of the unit
 // (coalesced dword loads; unused positions hold start=INT_MAX,end=INT_MIN so they never match).
 // smin[r] = first start of slot r (wave-uniform): tiles are sorted by start, so once
 // smin[r] >= qe no later slot can hold start<qe -- the reference's bisection bound, as a
@@ -294,13 +411,11 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 struct Chunk {
     int32_t s[IGD_SLOTS], e[IGD_SLOTS], x[IGD_SLOTS], w[IGD_SLOTS];
     int32_t smin[IGD_SLOTS];
-    int nslots;
 };
 
 template <bool USE_V>
 __device__ __forceinline__ void load_chunk(const DbView &db, int64_t off, int n, int lane, Chunk &c)
 {
-    c.nslots = (n + IGD_WAVE - 1) / IGD_WAVE;
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
         int i = r * IGD_WAVE + lane;
@@ -310,6 +425,9 @@ __device__ __forceinline__ void load_chunk(const DbView &db, int64_t off, int n,
         c.x[r] = ok ? db.idx[off + i] : 0;
         if (USE_V) c.w[r] = ok ? db.value[off + i] : INT_MIN;
     }
+}
+__device__ __forceinline__ void chunk_mins(Chunk &c)
+{
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) c.smin[r] = __builtin_amdgcn_readfirstlane(c.s[r]);
 }
@@ -320,99 +438,194 @@ __device__ __forceinline__ void match_chunk(const Chunk &c, int qs, int qe, int 
 {
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
-        if (r >= c.nslots || c.smin[r] >= qe) break;     // wave-uniform
+        if (c.smin[r] >= qe) break;                      // wave-uniform (empty slots hold INT_MAX)
         bool hit = (c.s[r] < qe) & (c.s[r] >= lob) & (c.e[r] > qs);
         if (USE_V) hit = hit & (c.w[r] >= v);
+#if IGD_EXP_NOATOMIC
+        if (__ballot(hit) == 0x1234567ull) atomicAdd(&hits[c.x[r]], 1ull);
+#else
         if (hit) atomicAdd(&hits[c.x[r]], 1ull);
+#endif
     }
 }
 
-template <bool USE_V, bool LDS_HITS>
-__global__ __launch_bounds__(IGD_WG) void igd_scan_tiles(
-    DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
-    const int2 *__restrict__ pairs, const int32_t *__restrict__ longList,
-    const int32_t *__restrict__ ctl, const int32_t *__restrict__ q_ichr,
-    const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe, int v,
-    u64 *__restrict__ slab /* [grid][nFiles] when LDS_HITS, else the global hits[] */)
+// all tiles j0..j1 of one contig against one query (long queries); destroys `c`
+template <bool USE_V>
+__device__ __forceinline__ void walk_tiles(const DbView &db, int tbase, int j0, int j1, int n1, int qs,
+                                           int qe, int v, int lane, Chunk &c, u64 *hits)
 {
+    for (int j = j0; j <= j1; j++) {
+        const int t = tbase + j;
+        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+        if (tcnt == 0) continue;
+        const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+        const int64_t toff = db.tileOff[t];
+        for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
+            int n = tcnt - rec0;
+            if (n > IGD_CHUNK) n = IGD_CHUNK;
+            load_chunk<USE_V>(db, toff + rec0, n, lane, c);
+            chunk_mins(c);
+            if (c.smin[0] >= qe) break;                  // sorted: nothing further in this tile
+            match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+        }
+    }
+}
+
+struct ScanArgs {
+    const int32_t *firstQ;       // sorted path: [nT+1]
+    const int32_t *pairN;        // bucket path: pairs per tile
+    const int32_t *pairPos;      //              end of each tile's range in `pairs`
+    const int2 *pairs;
+    const int32_t *longList;
+    const int32_t *ctl;
+    const int32_t *q_ichr, *q_qs, *q_qe;
+    int nq, v, rule, epoch;
+    int mode;                    // 0: device decides (ctl[CTL_UNSORTED]); 1: sorted promised; 2: bucket
+    u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
+};
+
+// SORTED = true : merge join over the caller's ordered arrays (firstQ[])
+// SORTED = false: bucketed pairs
+// In the device-decides mode both are enqueued and the one that does not apply returns at once.
+template <bool SORTED, bool USE_V, bool LDS_HITS>
+__global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs a)
+{
+    {
+        const bool uns = __builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch;
+        if (SORTED ? uns : (a.mode == 0 && !uns)) return;     // not this kernel's batch
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *hits = LDS_HITS ? (u64 *)smem : slab;
+    u64 *hits = LDS_HITS ? (u64 *)smem : a.out;
     if (LDS_HITS) {
         for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
     const int wavesPerWG = IGD_WG / IGD_WAVE;
-    const int gwave = blockIdx.x * wavesPerWG + (threadIdx.x >> 6);
+    // readfirstlane: tell the compiler the wave index is uniform, so that everything derived from
+    // it (unit descriptors, query ranges) lives in SGPRs and is fetched with scalar loads
+    const int gwave = blockIdx.x * wavesPerWG + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * wavesPerWG;
     Chunk c;
 
-    // ---- phase 1: bucketed pairs, one chunk of one tile per wave iteration ----
-    for (int ch = gwave; ch < db.nChunks; ch += nwaves) {
-        const int t = __builtin_amdgcn_readfirstlane(db.chunkTile[ch]);
-        const int np = __builtin_amdgcn_readfirstlane(pairCnt[t]);
-        if (np == 0) continue;                           // tile not visited by this batch
-        const int pend = __builtin_amdgcn_readfirstlane(pairPos[t]);
-        const int rec0 = __builtin_amdgcn_readfirstlane(db.chunkRec0[ch]);
-        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
-        const int bd = __builtin_amdgcn_readfirstlane(db.tileBd[t]);
-        const int64_t off = db.tileOff[t] + rec0;
-        int n = tcnt - rec0;
-        if (n > IGD_CHUNK) n = IGD_CHUNK;
-        load_chunk<USE_V>(db, off, n, lane, c);
-        for (int p = pend - np; p < pend; p += IGD_WAVE) {
-            int m = pend - p;
-            if (m > IGD_WAVE) m = IGD_WAVE;
-            int2 mine = (lane < m) ? pairs[p + lane] : make_int2(0, INT_MIN);
-            for (int k = 0; k < m; k++) {
-                const int qs = __builtin_amdgcn_readlane(mine.x, k);
-                const int qe = __builtin_amdgcn_readlane(mine.y, k);
-                // first tile of this query <=> qs lies at/after the tile start (tile 0: always)
-                const int lob = (qs >= bd) ? INT_MIN : bd;
-                match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+    if (SORTED) {
+        // ---- merge join over the caller's (contig,start)-ordered arrays --------------------
+        for (int ui = gwave; ui < db.nUnits; ui += nwaves) {
+            const Unit u = db.units[ui];                 // uniform address: one s_load_dwordx8
+            const int uj = UNIT_J(u), uf = UNIT_FLAGS(u);
+            const int lb = uj < IGD_SHORT_TILES - 1 ? uj : IGD_SHORT_TILES - 1;
+            // an empty tile's placeholder only matters for the long queries that start in it
+            const int qa = a.firstQ[u.tile - (u.n > 0 ? lb : 0)];
+            const int qb = a.firstQ[u.tile + 1];
+            if (qb <= qa) continue;                      // no query reaches this tile
+            if (u.n == 0 && a.rule != IGD_HIP_RULE_FLAT) continue;
+            if (u.n > 0) {
+                load_chunk<USE_V>(db, u.off, u.n, lane, c);
+                chunk_mins(c);
+            }
+            // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); which
+            // of the previous tiles are empty is a property of the database (flag bits 1..3)
+            const int deadk = a.rule == IGD_HIP_RULE_NEST ? uf : 0;
+            unsigned long long anyLong = 0;
+            for (int p = qa; p < qb; p += IGD_WAVE) {
+                const int i = p + lane;
+                const bool in = i < qb;
+                const int qc = in ? a.q_ichr[i] : -1;
+                const int qs_ = in ? a.q_qs[i] : 0;
+                const int qe_ = in ? a.q_qe[i] : 0;
+                const int n1 = tile_of(db, qs_);
+                const int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
+                const int k = uj - n1;                   // 0: this is the query's first tile
+                const bool mine = qc == u.ctg && n1 >= 0;
+                // queries that START here and span more than IGD_SHORT_TILES tiles: the tiles beyond
+                // the look-back window are walked below by the first unit of this tile
+                anyLong |= __ballot(mine && k == 0 && (uf & 1) && (n2 < u.mT ? n2 : u.mT) - n1 >= IGD_SHORT_TILES);
+                if (u.n == 0) continue;
+                const bool covers = mine && (k == 0 || (k > 0 && k < IGD_SHORT_TILES && n2 >= uj && !((deadk >> k) & 1)));
+                unsigned long long m = __ballot(covers);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int qs = __builtin_amdgcn_readlane(qs_, src);
+                    const int qe = __builtin_amdgcn_readlane(qe_, src);
+                    const int lob = (qs >= u.bd) ? INT_MIN : u.bd;
+                    match_chunk<USE_V>(c, qs, qe, lob, a.v, hits);
+                }
+            }
+            if (anyLong) {                               // rare: the chunk registers are free again
+                for (int p = a.firstQ[u.tile]; p < qb; p += IGD_WAVE) {
+                    const int i = p + lane;
+                    const bool in = i < qb;
+                    const int qc = in ? a.q_ichr[i] : -1;
+                    const int qs_ = in ? a.q_qs[i] : 0;
+                    const int qe_ = in ? a.q_qe[i] : 0;
+                    const int n1 = tile_of(db, qs_);
+                    int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
+                    if (n2 > u.mT) n2 = u.mT;
+                    unsigned long long m = __ballot(qc == u.ctg && n1 == uj && n2 - n1 >= IGD_SHORT_TILES);
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        walk_tiles<USE_V>(db, u.tile - uj, uj + IGD_SHORT_TILES, __builtin_amdgcn_readlane(n2, src),
+                                          uj, __builtin_amdgcn_readlane(qs_, src),
+                                          __builtin_amdgcn_readlane(qe_, src), a.v, lane, c, hits);
+                    }
+                }
             }
         }
-    }
-
-    // ---- phase 2: long queries, one wave walks all tiles of one query ----
-    const int nLong = __builtin_amdgcn_readfirstlane(ctl[0]);
-    for (int li = gwave; li < nLong; li += nwaves) {
-        const int q = __builtin_amdgcn_readfirstlane(longList[li]);
-        const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
-        const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
-        const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
-        const int n1 = qs / db.nbp;
-        int n2 = (int)((unsigned)qe - 1u) / db.nbp;
-        const int mT = db.ctgNTile[cc] - 1;
-        if (n2 > mT) n2 = mT;
-        const int base = db.ctgBase[cc];
-        for (int j = n1; j <= n2; j++) {
-            const int t = base + j;
-            const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
-            if (tcnt == 0) continue;
-            const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
-            const int64_t toff = db.tileOff[t];
-            for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
-                int n = tcnt - rec0;
-                if (n > IGD_CHUNK) n = IGD_CHUNK;
-                load_chunk<USE_V>(db, toff + rec0, n, lane, c);
-                if (c.smin[0] >= qe) break;              // sorted: nothing further in this tile
-                match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+    } else {
+        // ---- bucketed pairs: one chunk of one tile per wave iteration ----------------------
+        for (int ui = gwave; ui < db.nUnits; ui += nwaves) {
+            const Unit u = db.units[ui];
+            if (u.n == 0) continue;
+            const int np = a.pairN[u.tile];
+            if (np == 0) continue;                       // tile not visited by this batch
+            const int pend = a.pairPos[u.tile];
+            load_chunk<USE_V>(db, u.off, u.n, lane, c);
+            chunk_mins(c);
+            for (int p = pend - np; p < pend; p += IGD_WAVE) {
+                int m = pend - p;
+                if (m > IGD_WAVE) m = IGD_WAVE;
+                const int2 mine = (lane < m) ? a.pairs[p + lane] : make_int2(0, INT_MIN);
+                for (int k = 0; k < m; k++) {
+                    const int qs = __builtin_amdgcn_readlane(mine.x, k);
+                    const int qe = __builtin_amdgcn_readlane(mine.y, k);
+                    // first tile of this query <=> qs lies at/after the tile start (tile 0: always)
+                    const int lob = (qs >= u.bd) ? INT_MIN : u.bd;
+                    match_chunk<USE_V>(c, qs, qe, lob, a.v, hits);
+                }
             }
+        }
+        // long queries (listed by k_count_pairs): one wave walks all tiles of one query
+        const int nLong = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NLONG + (a.epoch & 1)]);
+        for (int li = gwave; li < nLong; li += nwaves) {
+            const int q = __builtin_amdgcn_readfirstlane(a.longList[li]);
+            const int qs = __builtin_amdgcn_readfirstlane(a.q_qs[q]);
+            const int qe = __builtin_amdgcn_readfirstlane(a.q_qe[q]);
+            const int cc = __builtin_amdgcn_readfirstlane(a.q_ichr[q]);
+            const int n1 = tile_of(db, qs);
+            int n2 = tile_of(db, (int)((unsigned)qe - 1u));
+            const int mT = db.ctgNTile[cc] - 1;
+            if (n2 > mT) n2 = mT;
+            walk_tiles<USE_V>(db, db.ctgBase[cc], n1, n2, n1, qs, qe, a.v, lane, c, hits);
         }
     }
 
     if (LDS_HITS) {
         __syncthreads();
-        u64 *row = slab + (size_t)blockIdx.x * db.nFiles;
+        u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
         for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
     }
 }
 
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
 __global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ slab, int rows, int nFiles,
-                                                      u64 *__restrict__ hits, u64 *__restrict__ total)
+                                                      u64 *__restrict__ hits, u64 *__restrict__ total,
+                                                      const int32_t *__restrict__ ctl, int brokenIf)
 {
+    // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
+    // scan kernel wrote no slab, so nothing may be added
+    if (brokenIf != 0 && ctl[CTL_UNSORTED] == brokenIf) return;
     __shared__ u64 red[4];
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
@@ -459,7 +672,7 @@ template <bool FILL>
 __global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
     DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
     const int4 *__restrict__ pairs, const int32_t *__restrict__ longList,
-    const int32_t *__restrict__ ctl, const int32_t *__restrict__ q_ichr,
+    const int32_t *__restrict__ ctl, int epoch, const int32_t *__restrict__ q_ichr,
     const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe,
     int32_t *__restrict__ pcount /* [nq*K] */, int64_t *__restrict__ qlong /* [nq] long totals */,
     const int64_t *__restrict__ qoff, igd_hip_hit *__restrict__ out)
@@ -509,14 +722,14 @@ __global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
         }
     }
 
-    const int nLong = __builtin_amdgcn_readfirstlane(ctl[0]);
+    const int nLong = __builtin_amdgcn_readfirstlane(ctl[CTL_NLONG + (epoch & 1)]);
     for (int li = gwave; li < nLong; li += nwaves) {
         const int q = __builtin_amdgcn_readfirstlane(longList[li]);
         const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
         const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
         const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
-        const int n1 = qs / db.nbp;
-        int n2 = (int)((unsigned)qe - 1u) / db.nbp;
+        const int n1 = tile_of(db, qs);
+        int n2 = tile_of(db, (int)((unsigned)qe - 1u));
         const int mT = db.ctgNTile[cc] - 1;
         if (n2 > mT) n2 = mT;
         const int tb = db.ctgBase[cc];
@@ -668,6 +881,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_chunkTile, db->d_chunkRec0,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_ctl,
+                    db->d_units, db->d_firstQ, db->d_pairN,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -708,7 +922,9 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     // host-side tables
     int64_t nT = 0;
     for (int c = 0; c < d->nCtg; c++) nT += d->nTile[c];
-    if (nT > INT_MAX - 1) {
+    bool jfits = true;
+    for (int c = 0; c < d->nCtg; c++) jfits = jfits && d->nTile[c] < (1 << 27);
+    if (nT > INT_MAX - 1 || !jfits) {
         snprintf(g_err, sizeof g_err, "igd_hip_open: too many tiles");
         delete db;
         return IGD_HIP_ERR_ARG;
@@ -717,6 +933,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     std::vector<int64_t> tileOff((size_t)nT + 1);
     std::vector<int32_t> tileCnt((size_t)nT + 1), tileBd((size_t)nT + 1), ctgBase((size_t)d->nCtg + 1),
         ctgNTile((size_t)d->nCtg + 1), chunkTile, chunkRec0;
+    std::vector<Unit> units;
     int64_t off = 0;
     int32_t maxIdxCheck = 0;
     (void)maxIdxCheck;
@@ -736,6 +953,20 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                     chunkTile.push_back((int32_t)t);
                     chunkRec0.push_back(r0);
                 }
+                for (int32_t r0 = 0; r0 < cnt || r0 == 0; r0 += IGD_CHUNK) {
+                    Unit u;
+                    u.off = off + r0;
+                    u.tile = (int32_t)t;
+                    u.n = cnt - r0 < IGD_CHUNK ? cnt - r0 : IGD_CHUNK;
+                    u.bd = tileBd[t];
+                    int fl = r0 == 0 ? 1 : 0;
+                    for (int k = 1; k < IGD_SHORT_TILES && k <= j; k++)
+                        if (d->nCnt[t - k] <= 0) fl |= 1 << k;
+                    u.jf = (j << 4) | fl;
+                    u.ctg = c;
+                    u.mT = d->nTile[c] - 1;
+                    units.push_back(u);
+                }
                 off += cnt;
             }
         }
@@ -748,6 +979,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         return IGD_HIP_ERR_ARG;
     }
     db->nChunks = (int32_t)chunkTile.size();
+    db->nUnits = (int32_t)units.size();
 
     int rc;
     int64_t *acct = &db->resident;
@@ -766,6 +998,9 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_ctgNTile, (size_t)d->nCtg + 1, acct));
     TRY(dalloc(&db->d_chunkTile, chunkTile.size(), acct));
     TRY(dalloc(&db->d_chunkRec0, chunkRec0.size(), acct));
+    TRY(dalloc(&db->d_units, units.size(), acct));
+    TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
+    TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_pairPos, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_blockSums, (size_t)(nT / IGD_SCAN_TILE + 2), acct));
@@ -777,6 +1012,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRYHIP(hipMemcpy(db->d_tileBd, tileBd.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgBase, ctgBase.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
+    if (!units.empty())
+        TRYHIP(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(Unit), hipMemcpyHostToDevice));
     if (!chunkTile.empty()) {
         TRYHIP(hipMemcpy(db->d_chunkTile, chunkTile.data(), chunkTile.size() * 4, hipMemcpyHostToDevice));
         TRYHIP(hipMemcpy(db->d_chunkRec0, chunkRec0.data(), chunkRec0.size() * 4, hipMemcpyHostToDevice));
@@ -824,6 +1061,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
     }
     TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
+    TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
 
     // launch geometry of the scan kernel
     hipDeviceProp_t prop;
@@ -841,9 +1079,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     if (db->ldsHits) {
         TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1), acct));
         if (db->ldsBytes > 64 * 1024) {
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, true>,
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, false, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, true>,
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, true, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, true, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
         }
     }
@@ -851,6 +1093,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 #undef TRYHIP
     DbView &v = db->v;
     v.nbp = db->nbp; v.nCtg = db->nCtg; v.nT = db->nT; v.nChunks = db->nChunks; v.nFiles = db->nFiles;
+    v.shift = -1;
+    for (int b = 0; b < 31; b++)
+        if (db->nbp == (1 << b)) v.shift = b;
+    v.units = db->d_units; v.nUnits = db->nUnits;
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
     v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
     v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile;
@@ -879,29 +1125,41 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     return IGD_HIP_OK;
 }
 
-// the bucket step shared by search and enumerate
+// The bucket step (count -> scan -> scatter).  gate != 0: every kernel returns at once unless
+// k_query_bounds marked this batch unsorted (ctl[CTL_UNSORTED] == gate).  Leaves the pair
+// counts in d_pairN, the range ends in d_pairPos, and d_pairCnt zeroed again.
 template <bool WITH_Q>
 static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
-                         int nq, int rule, hipStream_t st)
+                         int nq, int rule, int gate, hipStream_t st)
 {
     const int nT = db->nT;
-    HIPCHK(hipMemsetAsync(db->d_pairCnt, 0, (size_t)nT * 4, st));
-    HIPCHK(hipMemsetAsync(db->d_ctl, 0, 16 * 4, st));
     const int qb = (nq + 255) / 256;
-    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairCnt, db->d_long, db->d_ctl);
+    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairCnt, db->d_long, db->d_ctl,
+                                      gate, db->epoch);
     const int sb = (nT + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE;
-    k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums);
-    k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos);
-    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairPos, db->d_pairs);
+    k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_ctl, gate);
+    k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos, db->d_pairN,
+                                                db->d_ctl, gate);
+    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairPos, db->d_pairs,
+                                                db->d_ctl, gate);
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
 
+template <bool USE_V, bool LDS_HITS>
+static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
+{
+    const size_t lds = LDS_HITS ? db->ldsBytes : 0;
+    if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+}
+
 extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
-                                  const int32_t *d_qe, int64_t nq, int32_t v, int rule,
+                                  const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                                   int64_t *d_hits, int64_t *d_total, void *stream)
 {
-    if (!db || !d_hits || nq < 0 || nq > IGD_MAX_BATCH || (rule != IGD_HIP_RULE_NEST && rule != IGD_HIP_RULE_FLAT)) {
+    if (!db || !d_hits || nq < 0 || nq > IGD_MAX_BATCH || (rule != IGD_HIP_RULE_NEST && rule != IGD_HIP_RULE_FLAT) ||
+        ((flags & IGD_HIP_FLAG_SORTED) && (flags & IGD_HIP_FLAG_BUCKET))) {
         snprintf(g_err, sizeof g_err, "igd_hip_search_dev: bad argument");
         return IGD_HIP_ERR_ARG;
     }
@@ -911,34 +1169,39 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     int rc = ensure_workspace(db, nq, 8);
     if (rc != IGD_HIP_OK) return rc;
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
+    const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
+    db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
     int slot = -1;
     if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
-    rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, st);
-    if (rc != IGD_HIP_OK) return rc;
+    if (mode != 2)
+        k_query_bounds<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, (int)nq, db->d_firstQ,
+                                                              db->d_ctl, db->epoch);
+    if (mode != 1) {
+        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, st);
+        if (rc != IGD_HIP_OK) return rc;
+    }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
+    ScanArgs a;
+    a.firstQ = db->d_firstQ; a.pairN = db->d_pairN; a.pairPos = db->d_pairPos; a.pairs = (const int2 *)db->d_pairs;
+    a.longList = db->d_long; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe;
+    a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     if (db->ldsHits) {
-        if (useV)
-            igd_scan_tiles<true, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
-                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, db->d_slab);
-        else
-            igd_scan_tiles<false, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
-                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, db->d_slab);
+        a.out = db->d_slab;
+        if (useV) launch_scan<true, true>(db, a, st); else launch_scan<false, true>(db, a, st);
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
-        k_reduce_slabs<<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total);
+        k_reduce_slabs<<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                                           db->d_ctl, mode == 1 ? db->epoch : 0);
     } else {
+        a.out = (u64 *)d_hits;
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
-        if (useV)
-            igd_scan_tiles<true, false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
-                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, (u64 *)d_hits);
-        else
-            igd_scan_tiles<false, false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos,
-                (const int2 *)db->d_pairs, db->d_long, db->d_ctl, d_ichr, d_qs, d_qe, v, (u64 *)d_hits);
+        if (useV) launch_scan<true, false>(db, a, st); else launch_scan<false, false>(db, a, st);
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
+    if (mode == 1) db->promised = db->epoch;
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
@@ -949,6 +1212,18 @@ extern "C" int igd_hip_sync(igd_hip_db *db, void *stream)
     HIPCHK(hipSetDevice(db->device));
     HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : db->stream));
     HIPCHK(hipGetLastError());
+    if (db->promised) {
+        // a batch ran under IGD_HIP_FLAG_SORTED: the device recorded whether the promise held
+        int32_t ctl[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpy(ctl, db->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));
+        const bool broken = ctl[CTL_UNSORTED] == db->promised;
+        db->promised = 0;
+        if (broken) {
+            snprintf(g_err, sizeof g_err, "igd_hip: queries passed with IGD_HIP_FLAG_SORTED were not ordered by "
+                     "(contig, start); that batch added nothing to hits");
+            return IGD_HIP_ERR_UNSORTED;
+        }
+    }
     return IGD_HIP_OK;
 }
 
@@ -972,6 +1247,13 @@ static int ensure_qstage(igd_hip_db *db, int64_t nq)
 extern "C" int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                               int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total)
 {
+    return igd_hip_search_ex(db, ichr, qs, qe, nq, v, rule, 0, hits, total);
+}
+
+extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                                 int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total)
+{
+    flags &= ~IGD_HIP_FLAG_SORTED;    // the blocking call always lets the device decide
     if (!db || !hits || nq < 0 || (nq > 0 && (!ichr || !qs || !qe))) {
         snprintf(g_err, sizeof g_err, "igd_hip_search: bad argument");
         return IGD_HIP_ERR_ARG;
@@ -989,7 +1271,7 @@ extern "C" int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t
         HIPCHK(hipMemcpyAsync(db->d_qc, ichr + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(db->d_qs, qs + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(db->d_qe, qe + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
-        rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, db->d_hits, db->d_total, st);
+        rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, flags, db->d_hits, db->d_total, st);
         if (rc != IGD_HIP_OK) return rc;
         HIPCHK(hipStreamSynchronize(st));                 // staging buffers are reused
     }
@@ -1039,10 +1321,11 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     EH(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemsetAsync(d_pcount, 0, (size_t)nq * IGD_SHORT_TILES * 4, st));
     EH(hipMemsetAsync(d_qlong, 0, (size_t)nq * 8, st));
-    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, st);
+    db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
+    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, 0, st);
     if (rc != IGD_HIP_OK) { cleanup(); return rc; }
-    igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos, (const int4 *)db->d_pairs,
-        db->d_long, db->d_ctl, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
+    igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
+        db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
     k_enum_qcount<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_pcount, d_qlong, (int)nq, d_qcount);
     k_scan64<<<1, 1024, 0, st>>>(d_qcount, (int)nq, d_qoff);
     EH(hipMemcpyAsync(qoff, d_qoff, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1051,8 +1334,8 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     if (total) *total = tot;
     if (tot > 0) {
         if ((rc = dalloc(&d_out, (size_t)tot, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-        igd_enum_tiles<true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairCnt, db->d_pairPos, (const int4 *)db->d_pairs,
-            db->d_long, db->d_ctl, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_out);
+        igd_enum_tiles<true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
+            db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_out);
         igd_hip_hit *h = (igd_hip_hit *)malloc((size_t)tot * sizeof(igd_hip_hit));
         if (!h) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_enumerate: host malloc"); return IGD_HIP_ERR_NOMEM; }
         hipError_t e = hipMemcpyAsync(h, d_out, (size_t)tot * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, st);
@@ -1085,7 +1368,7 @@ extern "C" int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const 
     k_batch_stats<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, d_acc);
     bool saved = db->evOn;
     db->evOn = false;
-    rc = igd_hip_search_dev(db, d_ichr, d_qs, d_qe, nq, v, rule, d_h, d_t, st);
+    rc = igd_hip_search_dev(db, d_ichr, d_qs, d_qe, nq, v, rule, 0, d_h, d_t, st);
     db->evOn = saved;
     u64 acc[4] = {0, 0, 0, 0};
     int64_t tot = 0;

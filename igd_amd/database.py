@@ -103,8 +103,9 @@ class Database:
         return N.IGD_HIP_RULE_NEST, N.IGD_HIP_NO_VALUE_FILTER
 
     # ---- searches ---------------------------------------------------------------------
-    def search(self, ichr, qs, qe, v=0, rule=None, value_filter=None, hits=None):
-        """Host batch.  Default: the CLI dispatch for `-v v`.  Returns (hits int64[nfiles], total)."""
+    def search(self, ichr, qs, qe, v=0, rule=None, value_filter=None, hits=None, flags=0):
+        """Host batch.  Default: the CLI dispatch for `-v v`.  Returns (hits int64[nfiles], total).
+        flags: 0 (device picks merge-join or bucketing) or IGD_HIP_FLAG_BUCKET."""
         ichr, qs, qe = _i32(ichr), _i32(qs), _i32(qe)
         if rule is None:
             rule, vf = self.cli_dispatch(self.gtype, v)
@@ -113,18 +114,19 @@ class Database:
         if hits is None:
             hits = np.zeros(max(self.nfiles, 1), np.int64)
         total = C.c_int64(0)
-        _chk(self._H.igd_hip_search(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, len(qs),
-                                    vf, rule, hits.ctypes.data, C.byref(total)), "igd_hip_search")
+        _chk(self._H.igd_hip_search_ex(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, len(qs),
+                                       vf, rule, int(flags), hits.ctypes.data, C.byref(total)), "igd_hip_search")
         return hits[: self.nfiles], total.value
 
     def search_dev(self, d_ichr, d_qs, d_qe, nq, d_hits, d_total=None, v=0, rule=None,
-                   value_filter=None, stream=None):
-        """Resident batch: arguments are device pointers (ints).  Asynchronous."""
+                   value_filter=None, stream=None, flags=0):
+        """Resident batch: arguments are device pointers (ints).  Asynchronous.
+        flags: 0, IGD_HIP_FLAG_SORTED (verified promise; sync() raises if broken) or IGD_HIP_FLAG_BUCKET."""
         if rule is None:
             rule, vf = self.cli_dispatch(self.gtype, v)
         else:
             vf = N.IGD_HIP_NO_VALUE_FILTER if value_filter is None else int(value_filter)
-        _chk(self._H.igd_hip_search_dev(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, d_hits,
+        _chk(self._H.igd_hip_search_dev(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, int(flags), d_hits,
                                         d_total, stream), "igd_hip_search_dev")
 
     def sync(self, stream=None):

@@ -32,6 +32,7 @@ extern "C" {
 #define IGD_HIP_ERR_DEVICE  (-1)   /* no device / HIP runtime error          */
 #define IGD_HIP_ERR_ARG     (-2)   /* bad argument                            */
 #define IGD_HIP_ERR_NOMEM   (-3)   /* host or device allocation failed        */
+#define IGD_HIP_ERR_UNSORTED (-4)  /* IGD_HIP_FLAG_SORTED promised, order violated */
 
 /* Tile-visiting rules. */
 #define IGD_HIP_RULE_NEST 0  /* get_overlaps / get_overlaps0 / _f0 / _f1: an EMPTY first tile
@@ -82,18 +83,33 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  * CLI `-v N` selects the filtered kernel (only N>0, :1027) is the HOST's decision. */
 #define IGD_HIP_NO_VALUE_FILTER INT32_MIN
 
+/* How the engine groups a batch's queries by tile (flags of the search calls):
+ *   0                     the device decides: one pass checks whether the batch is ordered by
+ *                         (contig index, start) -- a position-sorted BED -- and, if so, reads
+ *                         the queries in place (merge join); otherwise it counting-sorts the
+ *                         (query,tile) pairs.  Same result either way.
+ *   IGD_HIP_FLAG_SORTED   the caller PROMISES that order, which skips enqueueing the bucket
+ *                         kernels.  The promise is verified on the device: if it does not hold,
+ *                         that batch adds nothing and igd_hip_sync returns IGD_HIP_ERR_UNSORTED.
+ *   IGD_HIP_FLAG_BUCKET   always counting-sort (tests / measurements). */
+#define IGD_HIP_FLAG_SORTED 1
+#define IGD_HIP_FLAG_BUCKET 2
+
 /* Host-buffer search.  ichr[i] = contig index (as get_id returns; <0 or >=nCtg: skipped).
  * hits[0..nFiles) is caller-allocated and is ADDED to (reference semantics :491).
  * *total (may be NULL) receives the number of overlaps of this batch.  Blocking. */
 int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                    int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total);
+/* same with `flags` (IGD_HIP_FLAG_BUCKET only; the blocking call never trusts a promise) */
+int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                      int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
 
 /* Device-resident search: all pointers are device pointers on db's GPU; d_hits
  * (int64[nFiles]) is ADDED to; d_total (int64[1], may be NULL) is ADDED to.  Enqueues on
  * `stream` (a hipStream_t; NULL = the engine's own stream) and returns without waiting.
- * nq must be <= igd_hip_max_batch(). */
+ * nq must be <= igd_hip_max_batch().  One call at a time per database (shared workspace). */
 int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
-                       const int32_t *d_qe, int64_t nq, int32_t v, int rule,
+                       const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                        int64_t *d_hits, int64_t *d_total, void *stream);
 int64_t igd_hip_max_batch(void);
 int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
