@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
     ap.add_argument("--grouping", choices=["auto", "sorted", "bucket"], default="auto",
                     help="auto: the device checks the query order and picks merge-join or bucketing (default); "
                          "sorted: promise (contig,start) order, verified on the device; bucket: always counting-sort")
@@ -131,7 +132,7 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
-    gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping]
+    gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
 
     def step():
         d_hits.zero_()

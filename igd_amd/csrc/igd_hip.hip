@@ -45,8 +45,8 @@
 #include "igd_hip.h"
 
 #define IGD_WAVE 64
-#define IGD_SLOTS 6                          // register slots per array per lane
-#define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (384)
+#define IGD_SLOTS 5                          // register slots per array per lane
+#define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (320)
 #define IGD_SHORT_TILES 4                    // queries spanning more tiles take the long path
 #define IGD_WG 512                           // threads per scan workgroup (8 waves)
 #define IGD_MAX_BATCH (1ll << 24)            // queries per device batch
@@ -61,6 +61,9 @@ typedef unsigned long long u64;
 // tuning / experiment knobs (defaults are the shipped configuration)
 #ifndef IGD_EXP_NOATOMIC
 #define IGD_EXP_NOATOMIC 0    // measurement only: drop the LDS atomics (wrong results)
+#endif
+#ifndef IGD_EXP_NOMATCH
+#define IGD_EXP_NOMATCH 0     // measurement only: load everything, compare nothing (wrong results)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -115,7 +118,11 @@ struct __attribute__((aligned(32))) Unit {
 struct DbView {
     int32_t nbp, shift, nCtg, nT, nChunks, nUnits, nFiles;
     const Unit *units;
-    const int32_t *start, *end, *idx, *value;   // SoA over all records, file order
+    const int32_t *start, *end, *idx, *value;   // SoA over all records, file order (exact)
+    // compact tile-relative image of the same records (6 bytes each), see k_pack_units:
+    const uint32_t *pse;                        // s' | e' << 16
+    const uint16_t *px;                         // idx
+    const int16_t *pv;                          // value (only when every value fits 16 bits)
     const int64_t *tileOff;                     // [nT+1] record offset of each tile
     const int32_t *tileCnt;                     // [nT]
     const int32_t *tileBd;                      // [nT] tile start coordinate j*nbp (INT_MIN for j==0)
@@ -132,6 +139,10 @@ struct igd_hip_db {
     DbView v;
     // owned device memory of the image
     int32_t *d_start, *d_end, *d_idx, *d_value;
+    uint32_t *d_pse;
+    uint16_t *d_px;
+    int16_t *d_pv;
+    bool packed, packedV;         // compact image usable (nbp<=32768, nFiles<=65536) / values fit int16
     int64_t *d_tileOff;
     int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_chunkTile, *d_chunkRec0;
     Unit *d_units;
@@ -143,7 +154,8 @@ struct igd_hip_db {
     // per-batch workspace
     int32_t *d_pairCnt, *d_pairPos, *d_blockSums;
     void *d_pairs;                // int2[cap*K] (or int4 for the enumerate path)
-    int32_t *d_long, *d_ctl;      // long-query list; ctl[0]=nLong
+    int2 *d_long, *d_fix;         // exact-walk lists: bucket path / merge-join path
+    int32_t *d_ctl;               // control words (CTL_*)
     int64_t wsQueries;            // capacity in queries
     int pairBytes;
     u64 *d_slab;
@@ -228,10 +240,17 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 // Control words shared by the kernels of one batch (int32 ctl[16]):
 //   ctl[1] = epoch of the last batch whose queries were NOT ordered by tile
 //   ctl[2] = epoch of the last batch that broke a caller's IGD_HIP_FLAG_SORTED promise
-//   ctl[4 + (epoch & 1)] = number of long queries listed by k_count_pairs in this batch
+//   ctl[4 + (epoch & 1)] = entries of the bucket path's exact-walk list (k_count_pairs)
+//   ctl[6 + (epoch & 1)] = entries of the merge-join path's exact-walk list (k_query_bounds)
 #define CTL_UNSORTED 1
 #define CTL_BROKEN 2
 #define CTL_NLONG 4
+#define CTL_NFIX 6
+// Exact-walk list entries (int2: query index, kind).  The scan kernels handle the common case
+// only; what they leave out is listed by the grouping kernels and done by k_exact_walk:
+#define WALK_BEYOND 0   // merge join: tiles n1+IGD_SHORT_TILES .. n2 of a long query
+#define WALK_FIRST 1    // tile n1 only: first-tile query with qe <= tile start (compact image cannot express it)
+#define WALK_ALL 2      // bucket path: every tile n1 .. n2 of a long query
 
 // Sorted path, step 1.  key(i) = global tile id of query i's FIRST tile, clamped into the
 // tile range of its contig (unknown contigs go to the ends), so a batch ordered by
@@ -248,21 +267,38 @@ __device__ __forceinline__ int tile_key(const DbView &db, int c, int qs)
 }
 
 __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
-                                                      const int32_t *__restrict__ qs, int nq,
-                                                      int32_t *__restrict__ firstQ,
-                                                      int32_t *__restrict__ ctl, int epoch)
+                                                      const int32_t *__restrict__ qs,
+                                                      const int32_t *__restrict__ qe, int nq, int rule,
+                                                      int packed, int32_t *__restrict__ firstQ,
+                                                      int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;     // next batch's long-query counter
+    if (i == 0) {                                           // next batch's list counters
+        ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+    }
     const int lane = threadIdx.x & 63;
     int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
     int val = i;
     if (i < nq) {
-        const int k = tile_key(db, ichr[i], qs[i]);
+        const int c = ichr[i], s0 = qs[i];
+        const int k = tile_key(db, c, s0);
         const int prev = i ? tile_key(db, ichr[i - 1], qs[i - 1]) : -1;
         if (k < prev) ctl[CTL_UNSORTED] = epoch;
         lo = prev + 1; hi = k;
-        if (i == nq - 1 && k < prev) { lo = 0; hi = -1; }
+        // what the scan kernel leaves to k_exact_walk
+        if (c >= 0 && c < db.nCtg) {
+            const int n1 = tile_of(db, s0);
+            const int mT = db.ctgNTile[c] - 1;
+            if (n1 >= 0 && n1 <= mT) {
+                const int e0 = qe[i];
+                int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
+                if (n2 > mT) n2 = mT;
+                if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
+                if (packed && e0 <= (int)((unsigned)n1 * (unsigned)db.nbp))
+                    fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
+            }
+        }
     }
     // short gaps by the owner, long gaps by the whole wave
     const bool big = hi - lo >= 8;
@@ -284,22 +320,34 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
 
 // Bucket path (any query order).  `gate`: 0 = always run; otherwise run only when
 // ctl[CTL_UNSORTED] == gate, i.e. when k_query_bounds found this batch unsorted.
-// step 1: per-tile pair counts (+ the list of long queries)
+// Queries the bucket path does not turn into pairs: long ones, and (compact image) first-tile
+// queries with qe <= tile start.  Returns the exact-walk kind or -1.
+__device__ __forceinline__ int walk_kind(const DbView &db, int qs, int qe, int ntl, int packed)
+{
+    if (ntl > IGD_SHORT_TILES) return WALK_ALL;
+    if (packed && qe <= (int)((unsigned)tile_of(db, qs) * (unsigned)db.nbp)) return WALK_FIRST;
+    return -1;
+}
+
+// step 1: per-tile pair counts (+ the exact-walk list)
 __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
                               const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
-                              int nq, int rule, int32_t *__restrict__ pairCnt,
-                              int32_t *__restrict__ longList, int32_t *__restrict__ ctl,
+                              int nq, int rule, int packed, int32_t *__restrict__ pairCnt,
+                              int2 *__restrict__ longList, int32_t *__restrict__ ctl,
                               int gate, int epoch)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gate == 0 && i == 0) ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+    if (gate == 0 && i == 0) {
+        ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+    }
     if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     if (i >= nq) return;
     int gt0, ntl;
     if (!query_span(db, ichr[i], qs[i], qe[i], rule, gt0, ntl)) return;
-    if (ntl > IGD_SHORT_TILES) {
-        int p = atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1);
-        longList[p] = i;
+    const int kind = walk_kind(db, qs[i], qe[i], ntl, packed);
+    if (kind >= 0) {
+        longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
         return;
     }
     for (int k = 0; k < ntl; k++)
@@ -381,7 +429,7 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(int32_t *__restri
 template <bool WITH_Q>
 __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
                                 const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
-                                int nq, int rule, int32_t *__restrict__ pairPos,
+                                int nq, int rule, int packed, int32_t *__restrict__ pairPos,
                                 void *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate)
 {
     if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
@@ -390,7 +438,7 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
     int gt0, ntl;
     int s = qs[i], e = qe[i];
     if (!query_span(db, ichr[i], s, e, rule, gt0, ntl)) return;
-    if (ntl > IGD_SHORT_TILES) return;
+    if (walk_kind(db, s, e, ntl, packed) >= 0) return;
     for (int k = 0; k < ntl; k++) {
         if (db.tileCnt[gt0 + k] > 0) {
             int p = atomicAdd(&pairPos[gt0 + k], 1);
@@ -401,93 +449,305 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 }
 
 // ------------------------------------------------------------------------------------------
-// The scan kernel.
-//
-// Records of one unit sit in registers: slot r of lane l is record r*64 + l of the unit
-// (coalesced dword loads; unused positions hold start=INT_MAX,end=INT_MIN so they never match).
-// smin[r] = first start of slot r (wave-uniform): tiles are sorted by start, so once
-// smin[r] >= qe no later slot can hold start<qe -- the reference's bisection bound, as a
-// wave-uniform loop exit.
-struct Chunk {
-    int32_t s[IGD_SLOTS], e[IGD_SLOTS], x[IGD_SLOTS], w[IGD_SLOTS];
-    int32_t smin[IGD_SLOTS];
-};
-
-template <bool USE_V>
-__device__ __forceinline__ void load_chunk(const DbView &db, int64_t off, int n, int lane, Chunk &c)
+// Compact image.  Everything the COUNT of a (query, tile) pair depends on is relative to the
+// tile: with T = tile start, W = tile width, a record of tile j is reduced to
+//     s' = start < T ? 0 : start - T + 1        in [0, W]    (0: "starts before this tile")
+//     e' = min(end - T, W)                       in [1, W]    (W: "reaches the tile's end")
+// and a query visiting the tile to
+//     qe' = min(qe - T, W) + 1,   qs' = first ? max(qs - T + 1, 1) : 1,   lob' = first ? 0 : 1
+// so that   lob' <= s' < qe'  &&  e' >= qs'   <=>   lob <= start < qe  &&  end > qs
+// for every query with qe > T (the conditions of SURVEY App. B.3; proof in DESIGN.md).
+// Stored word:  (65535 - s') | e' << 16.  With the query word  (65536 - qe') | qs' << 16  the
+// test  s' < qe' && e' >= qs'  is "both 16-bit halves >= the query's halves": one v_pk_max_u16
+// and one compare.  The remaining condition s' >= lob' only excludes records that start before
+// the tile (s' = 0) from queries for which this is not the first tile; since EVERY such query
+// matches EVERY such record on the other two conditions, it is applied once per unit as a
+// correction (hits -= number of non-first queries) instead of once per record and query.  A
+// first-tile query with qe <= T (an inverted query reaching back over the tile start) is the one
+// case that needs the exact starts: the grouping kernels list it for k_exact_walk (WALK_FIRST).
+// 6 bytes per record (4 + 2; 8 with the 16-bit value) instead of 12 (16).
+__global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restrict__ pse,
+                                                    uint16_t *__restrict__ px, int16_t *__restrict__ pv,
+                                                    int32_t *__restrict__ flag /* bit 0: a value needs > 16 bits; bit 1: malformed tile */)
 {
-#pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) {
-        int i = r * IGD_WAVE + lane;
-        bool ok = i < n;
-        c.s[r] = ok ? db.start[off + i] : INT_MAX;
-        c.e[r] = ok ? db.end[off + i] : INT_MIN;
-        c.x[r] = ok ? db.idx[off + i] : 0;
-        if (USE_V) c.w[r] = ok ? db.value[off + i] : INT_MIN;
-    }
-}
-__device__ __forceinline__ void chunk_mins(Chunk &c)
-{
-#pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) c.smin[r] = __builtin_amdgcn_readfirstlane(c.s[r]);
-}
-
-// one (query, chunk): count hits into `hits` (LDS or global u64 counters)
-template <bool USE_V>
-__device__ __forceinline__ void match_chunk(const Chunk &c, int qs, int qe, int lob, int v, u64 *hits)
-{
-#pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) {
-        if (c.smin[r] >= qe) break;                      // wave-uniform (empty slots hold INT_MAX)
-        bool hit = (c.s[r] < qe) & (c.s[r] >= lob) & (c.e[r] > qs);
-        if (USE_V) hit = hit & (c.w[r] >= v);
-#if IGD_EXP_NOATOMIC
-        if (__ballot(hit) == 0x1234567ull) atomicAdd(&hits[c.x[r]], 1ull);
-#else
-        if (hit) atomicAdd(&hits[c.x[r]], 1ull);
-#endif
-    }
-}
-
-// all tiles j0..j1 of one contig against one query (long queries); destroys `c`
-template <bool USE_V>
-__device__ __forceinline__ void walk_tiles(const DbView &db, int tbase, int j0, int j1, int n1, int qs,
-                                           int qe, int v, int lane, Chunk &c, u64 *hits)
-{
-    for (int j = j0; j <= j1; j++) {
-        const int t = tbase + j;
-        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
-        if (tcnt == 0) continue;
-        const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
-        const int64_t toff = db.tileOff[t];
-        for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
-            int n = tcnt - rec0;
-            if (n > IGD_CHUNK) n = IGD_CHUNK;
-            load_chunk<USE_V>(db, toff + rec0, n, lane, c);
-            chunk_mins(c);
-            if (c.smin[0] >= qe) break;                  // sorted: nothing further in this tile
-            match_chunk<USE_V>(c, qs, qe, lob, v, hits);
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nw = (gridDim.x * blockDim.x) >> 6;
+    int wide = 0;
+    for (int ui = gw; ui < db.nUnits; ui += nw) {
+        const Unit u = db.units[ui];
+        const int T = (int)((unsigned)UNIT_J(u) * (unsigned)db.nbp);
+        for (int i = lane; i < u.n; i += IGD_WAVE) {
+            const int64_t r = u.off + i;
+            const int st = db.start[r], en = db.end[r];
+            const unsigned sp = st < T ? 0u : (unsigned)(st - T) + 1u;
+            long long ed = (long long)en - T;
+            if (ed > db.nbp) ed = db.nbp;
+            if (ed < 1) ed = 1;
+            pse[r] = (65535u - sp) | ((unsigned)ed << 16);
+            px[r] = (uint16_t)db.idx[r];
+            if (pv) {
+                const int v = db.value[r];
+                wide |= (v < -32768) | (v > 32767);
+                pv[r] = (int16_t)v;
+            }
+            // a record that does not belong to its tile (malformed file): keep the exact path
+            if (!(st < T + db.nbp && en > T)) wide |= 2;
         }
     }
+    if (wide) atomicOr(flag, wide);
+}
+
+// ------------------------------------------------------------------------------------------
+// The scan kernel.
+//
+// Work unit = <= IGD_CHUNK records of one tile.  A wave owns units gwave, gwave+nwaves, ...
+//  * Descriptors: the Unit and the query range (merge join: firstQ[]; bucket: pairN/pairPos)
+//    of the wave's next 64 units are fetched ONE PER LANE -- a two-level dependent load done
+//    once, in parallel -- and broadcast with v_readlane when their turn comes, so no scalar-load
+//    round trip sits in the per-unit path.
+//  * Records: slot r of lane l is record r*64+l of the unit (coalesced loads).  PACKED: the
+//    compact words are compared in place with 16-bit compares (s' low half, e' high half), 2
+//    VGPRs per slot, and every wave keeps TWO units in flight (the loads of unit k+1 are issued
+//    before unit k is compared: twice the bytes outstanding, compares overlap loads).  Exact
+//    arrays (3 VGPRs per slot): one unit at a time.
+//  * Compare, per (query, slot): lob <= start < qe && end > qs [&& value >= v]; lob = tile start
+//    for a non-first tile is the reference's tS prefix skip (:510-511), start < qe is what its
+//    bisection computes (:479-487).  Tiles are sorted by start, so once the first start of a
+//    slot is >= qe the remaining slots cannot match: a wave-uniform loop exit.
+//  * A hit is one ds_add_u64 into the workgroup's private LDS copy of hits[].
+struct Raw {
+    uint32_t a[IGD_SLOTS];       // PACKED: s' | e' << 16        exact: start
+    int32_t b[IGD_SLOTS];        //                              exact: end
+    int32_t x[IGD_SLOTS];        // idx, then idx * 8 (byte offset of the counter)
+    int32_t w[IGD_SLOTS];        // value (USE_V)
+    int32_t q0, q1, q2;          // first 64 candidates: merge join ichr,qs,qe ; bucket qs,qe,-
+};
+
+// A Unit held one-per-lane in VGPRs, and its wave-uniform broadcast.
+struct UnitRegs { int32_t offLo, offHi, tile, n, bd, jf, ctg, mT; };
+__device__ __forceinline__ UnitRegs load_unit_regs(const Unit *p)
+{
+    const int4 a = ((const int4 *)p)[0], b = ((const int4 *)p)[1];
+    UnitRegs r;
+    r.offLo = a.x; r.offHi = a.y; r.tile = a.z; r.n = a.w;
+    r.bd = b.x; r.jf = b.y; r.ctg = b.z; r.mT = b.w;
+    return r;
 }
 
 struct ScanArgs {
-    const int32_t *firstQ;       // sorted path: [nT+1]
+    const int32_t *firstQ;       // merge join: [nT+1]
     const int32_t *pairN;        // bucket path: pairs per tile
     const int32_t *pairPos;      //              end of each tile's range in `pairs`
     const int2 *pairs;
-    const int32_t *longList;
+    const int2 *walkList;        // exact-walk list of this batch's path (k_exact_walk only)
     const int32_t *ctl;
     const int32_t *q_ichr, *q_qs, *q_qe;
     int nq, v, rule, epoch;
     int mode;                    // 0: device decides (ctl[CTL_UNSORTED]); 1: sorted promised; 2: bucket
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
+    u64 *total;                  // k_exact_walk: batch total (may be null)
 };
+
+// Issue the loads of unit kk.  BRANCH-FREE on purpose: every call issues exactly the same
+// number of loads (out-of-range lanes and unvisited units read element 0 of an array instead of
+// being skipped), so that the compiler can count them and wait for unit k with s_waitcnt
+// vmcnt(N) while the loads of unit k+1 stay in flight.  A conditional load would force vmcnt(0)
+// and serialise the two buffers.  The masking happens in compute_unit.
+template <bool SORTED, bool USE_V, bool PACKED>
+__device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, const UnitRegs &L, int Lr0,
+                                           int Lr1, int kk, int lane, Raw &R)
+{
+    const int r0 = __builtin_amdgcn_readlane(Lr0, kk), r1 = __builtin_amdgcn_readlane(Lr1, kk);
+    const bool active = SORTED ? (r1 > r0) : (r0 > 0);
+    const int n = active ? __builtin_amdgcn_readlane(L.n, kk) : 0;
+    const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(L.offHi, kk) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane(L.offLo, kk));
+    const int64_t base = active ? off : 0;
+    // uniform base pointers + (slot*64 + lane): the loads need no per-lane address arithmetic.
+    // Lanes past the unit's last record read the next unit's records (the arrays are padded by
+    // one chunk); compute_unit discards them.
+    const uint32_t *pa = db.pse + base;
+    const uint16_t *pxx = db.px + base;
+    const int16_t *pvv = USE_V ? db.pv + base : nullptr;
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        const int i = r * IGD_WAVE + lane;
+        const int64_t at = base + (i < n ? i : 0);
+        if (PACKED) {
+            R.a[r] = pa[i];
+            R.x[r] = (int)pxx[i];
+            if (USE_V) R.w[r] = (int)pvv[i];
+        } else {
+            R.a[r] = (uint32_t)db.start[at];
+            R.b[r] = db.end[at];
+            R.x[r] = db.idx[at];
+            if (USE_V) R.w[r] = db.value[at];
+        }
+    }
+    if (SORTED) {
+        int i = r0 + lane;
+        i = (active && i < r1) ? i : 0;
+        R.q0 = a.q_ichr[i];
+        R.q1 = a.q_qs[i];
+        R.q2 = a.q_qe[i];
+    } else {
+        const int i = (active && lane < r0) ? r1 - r0 + lane : 0;
+        const int2 pr = a.pairs[i];
+        R.q0 = pr.x; R.q1 = pr.y;
+    }
+}
+
+// Per-query parameters of the compare, computed for 64 candidate queries at once (one per lane)
+// and broadcast to the wave one query at a time.
+// PACKED: ONE word  (65536 - qe') | qs' << 16  (see k_pack_units); a record matches when both
+//         halves of its word are >= the halves of the query word.
+// exact : p0 = lob (INT_MIN first tile / tile start), p1 = qe - lob, p2 = qs; a record matches
+//         when (unsigned)(start - p0) < p1 && end > p2 -- one subtraction and one unsigned compare
+//         give lob <= start < qe together.
+// No scalar-ALU work is needed per record slot, which matters: a CU has a single scalar unit.
+typedef unsigned short igd_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int W)
+{
+    int qe2 = qe - T;
+    qe2 = (qe2 < W ? qe2 : W) + 1;                       // s' < qe2   <=> start < qe
+    int qs2 = first ? qs - T + 1 : 1;                    // e' >= qs2  <=> end > qs   (e' >= 1 always)
+    if (qs2 < 1) qs2 = 1;
+    return (int)((unsigned)(65536 - qe2) | ((unsigned)qs2 << 16));
+}
+
+// one query against the unit's slots: cnt[r] += hit   (no branches, no exec masking, no LDS)
+template <bool USE_V, bool PACKED>
+__device__ __forceinline__ void match_raw(const Raw &R, int (&cnt)[IGD_SLOTS], int p0, int p1, int p2, int v)
+{
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+#if IGD_EXP_NOMATCH
+        asm volatile("" ::"v"(R.a[r]), "v"(R.x[r]));
+        continue;
+#endif
+        if (PACKED) {
+            igd_u16x2 rec, qw;
+            __builtin_memcpy(&rec, &R.a[r], 4);
+            __builtin_memcpy(&qw, &p0, 4);
+            const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);   // v_pk_max_u16
+            uint32_t mxw;
+            __builtin_memcpy(&mxw, &mx, 4);
+            cnt[r] += mxw == R.a[r] ? 1 : 0;             // both halves already >= the query's
+        } else {
+            const uint32_t d = R.a[r] - (uint32_t)p0;
+            int t = d < (uint32_t)p1 ? R.b[r] : INT_MIN;
+            if (USE_V) t = R.w[r] >= v ? t : INT_MIN;
+            cnt[r] += t > p2 ? 1 : 0;
+        }
+    }
+}
+
+template <bool SORTED, bool USE_V, bool PACKED>
+__device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a, const UnitRegs &L, int Lr0,
+                                             int Lr1, int kk, int lane, Raw &R, u64 *hits)
+{
+    const int r0 = __builtin_amdgcn_readlane(Lr0, kk), r1 = __builtin_amdgcn_readlane(Lr1, kk);
+    const bool active = SORTED ? (r1 > r0) : (r0 > 0);
+    if (!active) return;
+    const int un = __builtin_amdgcn_readlane(L.n, kk);
+    if (un == 0) return;                                 // placeholder of an empty tile
+    const int bd = __builtin_amdgcn_readlane(L.bd, kk);
+    const int jf = __builtin_amdgcn_readlane(L.jf, kk);
+    const int uj = jf >> 4;
+    const int T = (int)((unsigned)uj * (unsigned)db.nbp);
+    int cnt[IGD_SLOTS];
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        cnt[r] = 0;
+        // lanes past the unit's last record hold someone else's data: make them unmatchable;
+        // (compact image) so are records that fail the value filter -- v is fixed for the batch
+        bool drop = r * IGD_WAVE + lane >= un;
+        if (PACKED && USE_V) drop = drop || R.w[r] < a.v;
+        if (drop) R.a[r] = PACKED ? 0u : (uint32_t)INT_MAX;
+    }
+    int nLater = 0;                                      // covering queries for which this is NOT the first tile
+    if (SORTED) {
+        const int ctg = __builtin_amdgcn_readlane(L.ctg, kk);
+        // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); which of the
+        // previous tiles are empty is a property of the database (flag bits 1..3 of the unit)
+        const int deadk = a.rule == IGD_HIP_RULE_NEST ? (jf & 15) : 0;
+        for (int p = r0; p < r1; p += IGD_WAVE) {
+            int qc = (p + lane < r1) ? R.q0 : -1, qs_ = R.q1, qe_ = R.q2;
+            if (p != r0) {
+                const int i = p + lane;
+                const bool in = i < r1;
+                qc = in ? a.q_ichr[i] : -1;
+                qs_ = in ? a.q_qs[i] : 0;
+                qe_ = in ? a.q_qe[i] : 0;
+            }
+            const int n1 = tile_of(db, qs_);
+            const int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
+            const int k = uj - n1;                       // 0: this is the query's first tile
+            // k == 0 with qe <= T is left to k_exact_walk when the compact image is read;
+            // tiles further than IGD_SHORT_TILES-1 behind are too (long queries)
+            const bool later = k > 0 && k < IGD_SHORT_TILES && n2 >= uj && !((deadk >> k) & 1);
+            const bool covers = qc == ctg && n1 >= 0 && ((k == 0 && !(PACKED && qe_ <= T)) || later);
+            int P0, P1 = 0, P2 = 0;
+            if (PACKED) P0 = query_word(qs_, qe_, k == 0, T, db.nbp);
+            else {
+                P0 = k == 0 ? INT_MIN : bd;
+                P1 = (int)((unsigned)qe_ - (unsigned)P0);
+                P2 = qs_;
+            }
+            unsigned long long m = __ballot(covers);
+            if (PACKED) nLater += __popcll(__ballot(covers && later));
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                if (PACKED) match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, src), 0, 0, a.v);
+                else match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, src),
+                                              __builtin_amdgcn_readlane(P1, src), __builtin_amdgcn_readlane(P2, src), a.v);
+            }
+        }
+    } else {
+        const int np = r0, pend = r1;
+        for (int p = pend - np; p < pend; p += IGD_WAVE) {
+            int m = pend - p;
+            if (m > IGD_WAVE) m = IGD_WAVE;
+            int px_ = R.q0, py_ = R.q1;
+            if (p != pend - np) {
+                const int2 pr = (lane < m) ? a.pairs[p + lane] : make_int2(0, INT_MIN);
+                px_ = pr.x; py_ = pr.y;
+            }
+            const bool first = px_ >= bd;                // tile 0: bd = INT_MIN, always first
+            int P0, P1 = 0, P2 = 0;
+            if (PACKED) {
+                P0 = query_word(px_, py_, first, T, db.nbp);
+                nLater += __popcll(__ballot(lane < m && !first));
+            } else {
+                P0 = first ? INT_MIN : bd;
+                P1 = (int)((unsigned)py_ - (unsigned)P0);
+                P2 = px_;
+            }
+            for (int k = 0; k < m; k++) {
+                if (PACKED) match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, k), 0, 0, a.v);
+                else match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, k), __builtin_amdgcn_readlane(P1, k),
+                                              __builtin_amdgcn_readlane(P2, k), a.v);
+            }
+        }
+    }
+    // one LDS atomic per record that was hit, with the number of queries that hit it
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        int c = cnt[r];
+        // records that start before the tile (s' = 0, low half 65535) were matched by every
+        // "later tile" query, none of which may count them (the reference's tS skip, :510-511)
+        if (PACKED) c -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+        if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
+    }
+}
 
 // SORTED = true : merge join over the caller's ordered arrays (firstQ[])
 // SORTED = false: bucketed pairs
 // In the device-decides mode both are enqueued and the one that does not apply returns at once.
-template <bool SORTED, bool USE_V, bool LDS_HITS>
+template <bool SORTED, bool USE_V, bool LDS_HITS, bool PACKED>
 __global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs a)
 {
     {
@@ -502,112 +762,46 @@ __global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs 
     }
     const int lane = threadIdx.x & 63;
     const int wavesPerWG = IGD_WG / IGD_WAVE;
-    // readfirstlane: tell the compiler the wave index is uniform, so that everything derived from
-    // it (unit descriptors, query ranges) lives in SGPRs and is fetched with scalar loads
+    // readfirstlane: the wave index is uniform; everything derived from it stays in SGPRs
     const int gwave = blockIdx.x * wavesPerWG + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * wavesPerWG;
-    Chunk c;
+    Raw A, B;
 
-    if (SORTED) {
-        // ---- merge join over the caller's (contig,start)-ordered arrays --------------------
-        for (int ui = gwave; ui < db.nUnits; ui += nwaves) {
-            const Unit u = db.units[ui];                 // uniform address: one s_load_dwordx8
-            const int uj = UNIT_J(u), uf = UNIT_FLAGS(u);
-            const int lb = uj < IGD_SHORT_TILES - 1 ? uj : IGD_SHORT_TILES - 1;
-            // an empty tile's placeholder only matters for the long queries that start in it
-            const int qa = a.firstQ[u.tile - (u.n > 0 ? lb : 0)];
-            const int qb = a.firstQ[u.tile + 1];
-            if (qb <= qa) continue;                      // no query reaches this tile
-            if (u.n == 0 && a.rule != IGD_HIP_RULE_FLAT) continue;
-            if (u.n > 0) {
-                load_chunk<USE_V>(db, u.off, u.n, lane, c);
-                chunk_mins(c);
-            }
-            // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); which
-            // of the previous tiles are empty is a property of the database (flag bits 1..3)
-            const int deadk = a.rule == IGD_HIP_RULE_NEST ? uf : 0;
-            unsigned long long anyLong = 0;
-            for (int p = qa; p < qb; p += IGD_WAVE) {
-                const int i = p + lane;
-                const bool in = i < qb;
-                const int qc = in ? a.q_ichr[i] : -1;
-                const int qs_ = in ? a.q_qs[i] : 0;
-                const int qe_ = in ? a.q_qe[i] : 0;
-                const int n1 = tile_of(db, qs_);
-                const int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
-                const int k = uj - n1;                   // 0: this is the query's first tile
-                const bool mine = qc == u.ctg && n1 >= 0;
-                // queries that START here and span more than IGD_SHORT_TILES tiles: the tiles beyond
-                // the look-back window are walked below by the first unit of this tile
-                anyLong |= __ballot(mine && k == 0 && (uf & 1) && (n2 < u.mT ? n2 : u.mT) - n1 >= IGD_SHORT_TILES);
-                if (u.n == 0) continue;
-                const bool covers = mine && (k == 0 || (k > 0 && k < IGD_SHORT_TILES && n2 >= uj && !((deadk >> k) & 1)));
-                unsigned long long m = __ballot(covers);
-                while (m) {
-                    const int src = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int qs = __builtin_amdgcn_readlane(qs_, src);
-                    const int qe = __builtin_amdgcn_readlane(qe_, src);
-                    const int lob = (qs >= u.bd) ? INT_MIN : u.bd;
-                    match_chunk<USE_V>(c, qs, qe, lob, a.v, hits);
-                }
-            }
-            if (anyLong) {                               // rare: the chunk registers are free again
-                for (int p = a.firstQ[u.tile]; p < qb; p += IGD_WAVE) {
-                    const int i = p + lane;
-                    const bool in = i < qb;
-                    const int qc = in ? a.q_ichr[i] : -1;
-                    const int qs_ = in ? a.q_qs[i] : 0;
-                    const int qe_ = in ? a.q_qe[i] : 0;
-                    const int n1 = tile_of(db, qs_);
-                    int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
-                    if (n2 > u.mT) n2 = u.mT;
-                    unsigned long long m = __ballot(qc == u.ctg && n1 == uj && n2 - n1 >= IGD_SHORT_TILES);
-                    while (m) {
-                        const int src = __builtin_ctzll(m);
-                        m &= m - 1;
-                        walk_tiles<USE_V>(db, u.tile - uj, uj + IGD_SHORT_TILES, __builtin_amdgcn_readlane(n2, src),
-                                          uj, __builtin_amdgcn_readlane(qs_, src),
-                                          __builtin_amdgcn_readlane(qe_, src), a.v, lane, c, hits);
+    for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
+        UnitRegs L;
+        int Lr0 = 0, Lr1 = 0;
+        {
+            const long long mi = (long long)ub + (long long)lane * nwaves;
+            if (mi < db.nUnits) {
+                L = load_unit_regs(db.units + mi);
+                if (SORTED) {
+                    const int lj = L.jf >> 4;
+                    const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+                    if (L.n > 0) {
+                        Lr0 = a.firstQ[L.tile - lb];
+                        Lr1 = a.firstQ[L.tile + 1];
                     }
+                } else if (L.n > 0) {
+                    Lr0 = a.pairN[L.tile];
+                    Lr1 = a.pairPos[L.tile];
                 }
             }
         }
-    } else {
-        // ---- bucketed pairs: one chunk of one tile per wave iteration ----------------------
-        for (int ui = gwave; ui < db.nUnits; ui += nwaves) {
-            const Unit u = db.units[ui];
-            if (u.n == 0) continue;
-            const int np = a.pairN[u.tile];
-            if (np == 0) continue;                       // tile not visited by this batch
-            const int pend = a.pairPos[u.tile];
-            load_chunk<USE_V>(db, u.off, u.n, lane, c);
-            chunk_mins(c);
-            for (int p = pend - np; p < pend; p += IGD_WAVE) {
-                int m = pend - p;
-                if (m > IGD_WAVE) m = IGD_WAVE;
-                const int2 mine = (lane < m) ? a.pairs[p + lane] : make_int2(0, INT_MIN);
-                for (int k = 0; k < m; k++) {
-                    const int qs = __builtin_amdgcn_readlane(mine.x, k);
-                    const int qe = __builtin_amdgcn_readlane(mine.y, k);
-                    // first tile of this query <=> qs lies at/after the tile start (tile 0: always)
-                    const int lob = (qs >= u.bd) ? INT_MIN : u.bd;
-                    match_chunk<USE_V>(c, qs, qe, lob, a.v, hits);
-                }
+        int cntU = (int)(((long long)db.nUnits - ub + nwaves - 1) / nwaves);
+        if (cntU > IGD_WAVE) cntU = IGD_WAVE;
+        if (PACKED) {
+            issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, 0, lane, A);
+            for (int kk = 0; kk < cntU; kk += 2) {
+                if (kk + 1 < cntU) issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 1, lane, B);
+                compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
+                if (kk + 2 < cntU) issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 2, lane, A);
+                if (kk + 1 < cntU) compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 1, lane, B, hits);
             }
-        }
-        // long queries (listed by k_count_pairs): one wave walks all tiles of one query
-        const int nLong = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NLONG + (a.epoch & 1)]);
-        for (int li = gwave; li < nLong; li += nwaves) {
-            const int q = __builtin_amdgcn_readfirstlane(a.longList[li]);
-            const int qs = __builtin_amdgcn_readfirstlane(a.q_qs[q]);
-            const int qe = __builtin_amdgcn_readfirstlane(a.q_qe[q]);
-            const int cc = __builtin_amdgcn_readfirstlane(a.q_ichr[q]);
-            const int n1 = tile_of(db, qs);
-            int n2 = tile_of(db, (int)((unsigned)qe - 1u));
-            const int mT = db.ctgNTile[cc] - 1;
-            if (n2 > mT) n2 = mT;
-            walk_tiles<USE_V>(db, db.ctgBase[cc], n1, n2, n1, qs, qe, a.v, lane, c, hits);
+        } else {
+            for (int kk = 0; kk < cntU; kk++) {
+                issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A);
+                compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
+            }
         }
     }
 
@@ -616,6 +810,67 @@ __global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs 
         u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
         for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_exact_walk: what the scan kernel leaves out (the exact-walk list of the batch's path): one
+// wave per listed query walks its tiles on the EXACT arrays, 6 slots at a time, and adds
+// straight into the caller's global hits[] (and the batch total).  Rare by construction.
+template <bool USE_V>
+__global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const int2 *__restrict__ fixList,
+                                                    const int2 *__restrict__ longList)
+{
+    const bool uns = __builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch;
+    if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
+    const bool sortedPath = a.mode == 1 || (a.mode == 0 && !uns);
+    const int2 *list = sortedPath ? fixList : longList;
+    const int nList = __builtin_amdgcn_readfirstlane(a.ctl[(sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1)]);
+    const int lane = threadIdx.x & 63;
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    u64 found = 0;
+    for (int li = gwave; li < nList; li += nwaves) {
+        const int2 ent = list[li];
+        const int q = ent.x, kind = ent.y;
+        const int qs = a.q_qs[q], qe = a.q_qe[q], cc = a.q_ichr[q];
+        const int n1 = tile_of(db, qs);
+        int n2 = tile_of(db, (int)((unsigned)qe - 1u));
+        const int mT = db.ctgNTile[cc] - 1;
+        if (n2 > mT) n2 = mT;
+        const int base = db.ctgBase[cc];
+        if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[base + n1] == 0) continue;   // :468
+        int j0 = n1, j1 = n2 > n1 ? n2 : n1;
+        if (kind == WALK_BEYOND) j0 = n1 + IGD_SHORT_TILES;
+        if (kind == WALK_FIRST) j1 = n1;
+        for (int j = j0; j <= j1; j++) {
+            const int t = base + j;
+            const int tcnt = db.tileCnt[t];
+            if (tcnt == 0) continue;
+            const int lob = (j == n1) ? INT_MIN : db.tileBd[t];
+            const int64_t toff = db.tileOff[t];
+            for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
+                int st[IGD_SLOTS], en[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int i = rec0 + r * IGD_WAVE + lane;
+                    const bool ok = i < tcnt;
+                    st[r] = ok ? db.start[toff + i] : INT_MAX;
+                    en[r] = ok ? db.end[toff + i] : INT_MIN;
+                    ix[r] = ok ? db.idx[toff + i] : 0;
+                    if (USE_V) va[r] = ok ? db.value[toff + i] : INT_MIN;
+                }
+                if (__builtin_amdgcn_readfirstlane(st[0]) >= qe) break;    // sorted: nothing further
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
+                    if (USE_V) hit = hit & (va[r] >= a.v);
+                    found += __popcll(__ballot(hit));
+                    if (hit) atomicAdd(&a.out[ix[r]], 1ull);
+                }
+            }
+        }
+    }
+    if (a.total && lane == 0 && found) atomicAdd(a.total, found);
 }
 
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
@@ -671,7 +926,7 @@ __global__ __launch_bounds__(256) void k_sum_hits(const u64 *__restrict__ hits, 
 template <bool FILL>
 __global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
     DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
-    const int4 *__restrict__ pairs, const int32_t *__restrict__ longList,
+    const int4 *__restrict__ pairs, const int2 *__restrict__ longList,
     const int32_t *__restrict__ ctl, int epoch, const int32_t *__restrict__ q_ichr,
     const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe,
     int32_t *__restrict__ pcount /* [nq*K] */, int64_t *__restrict__ qlong /* [nq] long totals */,
@@ -724,7 +979,7 @@ __global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
 
     const int nLong = __builtin_amdgcn_readfirstlane(ctl[CTL_NLONG + (epoch & 1)]);
     for (int li = gwave; li < nLong; li += nwaves) {
-        const int q = __builtin_amdgcn_readfirstlane(longList[li]);
+        const int q = __builtin_amdgcn_readfirstlane(longList[li].x);
         const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
         const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
         const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
@@ -880,8 +1135,8 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     (void)hipSetDevice(db->device);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_chunkTile, db->d_chunkRec0,
-                    db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_ctl,
-                    db->d_units, db->d_firstQ, db->d_pairN,
+                    db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
+                    db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1079,14 +1334,12 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     if (db->ldsHits) {
         TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1), acct));
         if (db->ldsBytes > 64 * 1024) {
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, false, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<true, true, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, false, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_tiles<false, true, true>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            const void *fns[] = {(const void *)igd_scan_tiles<true, false, true, false>, (const void *)igd_scan_tiles<true, true, true, false>,
+                                 (const void *)igd_scan_tiles<false, false, true, false>, (const void *)igd_scan_tiles<false, true, true, false>,
+                                 (const void *)igd_scan_tiles<true, false, true, true>, (const void *)igd_scan_tiles<true, true, true, true>,
+                                 (const void *)igd_scan_tiles<false, false, true, true>, (const void *)igd_scan_tiles<false, true, true, true>};
+            for (const void *fn : fns)
+                TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
         }
     }
 #undef TRY
@@ -1097,10 +1350,40 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     for (int b = 0; b < 31; b++)
         if (db->nbp == (1 << b)) v.shift = b;
     v.units = db->d_units; v.nUnits = db->nUnits;
+
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
     v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
     v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile;
     v.chunkTile = db->d_chunkTile; v.chunkRec0 = db->d_chunkRec0;
+    // compact image (see k_pack_units): needs tile-relative offsets and idx to fit 16 bits
+    db->packed = db->nbp <= 32768 && db->nFiles <= 65536 && db->nRec > 0 && !getenv("IGD_HIP_NO_PACK");
+    if (db->packed) {
+        const size_t n = (size_t)db->nRec;
+        int rc2;
+        // + one chunk of padding: the scan kernel's loads run up to a chunk past a unit's end
+        if ((rc2 = dalloc(&db->d_pse, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK ||
+            (rc2 = dalloc(&db->d_px, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK ||
+            (db->gType == 1 && (rc2 = dalloc(&db->d_pv, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK)) {
+            igd_hip_close(db);
+            return rc2;
+        }
+        hipError_t e = hipMemset(db->d_ctl, 0, 16 * 4);
+        if (e == hipSuccess) {
+            k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_pse, db->d_px, db->d_pv, db->d_ctl);
+            e = hipStreamSynchronize(db->stream);
+        }
+        int32_t fl = 0;
+        if (e == hipSuccess) e = hipMemcpy(&fl, db->d_ctl, 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(db->d_ctl, 0, 16 * 4);
+        if (e != hipSuccess) {
+            set_err("pack", e, __FILE__, __LINE__);
+            igd_hip_close(db);
+            return IGD_HIP_ERR_DEVICE;
+        }
+        db->packedV = db->gType == 1 && !(fl & 1);
+        if (fl & 2) db->packed = false;          // a record outside its tile: exact arrays only
+        v.pse = db->d_pse; v.px = db->d_px; v.pv = db->d_pv;
+    }
     *out = db;
     return IGD_HIP_OK;
 }
@@ -1114,11 +1397,14 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
     if (db->d_pairs) (void)hipFree(db->d_pairs);
     if (db->d_long) (void)hipFree(db->d_long);
-    db->d_pairs = nullptr; db->d_long = nullptr;
+    if (db->d_fix) (void)hipFree(db->d_fix);
+    db->d_pairs = nullptr; db->d_long = nullptr; db->d_fix = nullptr;
     db->wsQueries = 0;
     int rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr);
     if (rc != IGD_HIP_OK) return rc;
     rc = dalloc(&db->d_long, (size_t)cap, nullptr);
+    if (rc != IGD_HIP_OK) return rc;
+    rc = dalloc(&db->d_fix, (size_t)cap * 2, nullptr);     // a query can be both long and WALK_FIRST
     if (rc != IGD_HIP_OK) return rc;
     db->wsQueries = cap;
     db->pairBytes = pb;
@@ -1130,28 +1416,37 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
 // counts in d_pairN, the range ends in d_pairPos, and d_pairCnt zeroed again.
 template <bool WITH_Q>
 static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
-                         int nq, int rule, int gate, hipStream_t st)
+                         int nq, int rule, int gate, int packed, hipStream_t st)
 {
     const int nT = db->nT;
     const int qb = (nq + 255) / 256;
-    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairCnt, db->d_long, db->d_ctl,
+    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairCnt, db->d_long, db->d_ctl,
                                       gate, db->epoch);
     const int sb = (nT + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE;
     k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_ctl, gate);
     k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos, db->d_pairN,
                                                 db->d_ctl, gate);
-    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, db->d_pairPos, db->d_pairs,
+    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairPos, db->d_pairs,
                                                 db->d_ctl, gate);
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
 
-template <bool USE_V, bool LDS_HITS>
+template <bool USE_V, bool LDS_HITS, bool PACKED>
 static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
 {
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
-    if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
-    if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+}
+template <bool LDS_HITS>
+static void launch_scan_any(igd_hip_db *db, const ScanArgs &a, bool useV, bool packed, hipStream_t st)
+{
+    if (packed) {
+        if (useV) launch_scan<true, LDS_HITS, true>(db, a, st); else launch_scan<false, LDS_HITS, true>(db, a, st);
+    } else {
+        if (useV) launch_scan<true, LDS_HITS, false>(db, a, st); else launch_scan<false, LDS_HITS, false>(db, a, st);
+    }
 }
 
 extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
@@ -1170,34 +1465,48 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     if (rc != IGD_HIP_OK) return rc;
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
     const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
+    const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
     db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
     int slot = -1;
     if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
     if (mode != 2)
-        k_query_bounds<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, (int)nq, db->d_firstQ,
-                                                              db->d_ctl, db->epoch);
+        k_query_bounds<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
+                                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch);
     if (mode != 1) {
-        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, st);
+        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st);
         if (rc != IGD_HIP_OK) return rc;
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
     ScanArgs a;
     a.firstQ = db->d_firstQ; a.pairN = db->d_pairN; a.pairPos = db->d_pairPos; a.pairs = (const int2 *)db->d_pairs;
-    a.longList = db->d_long; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe;
+    a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe;
+    a.total = (u64 *)d_total;
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     if (db->ldsHits) {
         a.out = db->d_slab;
-        if (useV) launch_scan<true, true>(db, a, st); else launch_scan<false, true>(db, a, st);
+        launch_scan_any<true>(db, a, useV, packed, st);
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+        {   // the listed exact walks add straight into the caller's hits[] and total
+            ScanArgs w = a;
+            w.out = (u64 *)d_hits;
+            if (useV) k_exact_walk<true><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+            else k_exact_walk<false><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+        }
         dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
         k_reduce_slabs<<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
                                            db->d_ctl, mode == 1 ? db->epoch : 0);
     } else {
         a.out = (u64 *)d_hits;
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
-        if (useV) launch_scan<true, false>(db, a, st); else launch_scan<false, false>(db, a, st);
+        launch_scan_any<false>(db, a, useV, packed, st);
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+        {   // total is taken from the growth of sum(hits) here (k_sum_hits), not by the walk
+            ScanArgs w = a;
+            w.total = nullptr;
+            if (useV) k_exact_walk<true><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+            else k_exact_walk<false><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+        }
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
@@ -1322,7 +1631,7 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     EH(hipMemsetAsync(d_pcount, 0, (size_t)nq * IGD_SHORT_TILES * 4, st));
     EH(hipMemsetAsync(d_qlong, 0, (size_t)nq * 8, st));
     db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
-    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, 0, st);
+    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, 0, 0, st);
     if (rc != IGD_HIP_OK) { cleanup(); return rc; }
     igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
         db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);

@@ -94,13 +94,17 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  *   IGD_HIP_FLAG_BUCKET   always counting-sort (tests / measurements). */
 #define IGD_HIP_FLAG_SORTED 1
 #define IGD_HIP_FLAG_BUCKET 2
+/* Besides the exact start/end/idx/value arrays the engine keeps a compact tile-relative image
+ * (6 bytes per record) that the counting kernels read when the tile width is <= 32768 and
+ * nFiles <= 65536.  IGD_HIP_FLAG_EXACT makes a call read the exact arrays instead (tests). */
+#define IGD_HIP_FLAG_EXACT 4
 
 /* Host-buffer search.  ichr[i] = contig index (as get_id returns; <0 or >=nCtg: skipped).
  * hits[0..nFiles) is caller-allocated and is ADDED to (reference semantics :491).
  * *total (may be NULL) receives the number of overlaps of this batch.  Blocking. */
 int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                    int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total);
-/* same with `flags` (IGD_HIP_FLAG_BUCKET only; the blocking call never trusts a promise) */
+/* same with `flags` (IGD_HIP_FLAG_BUCKET / _EXACT; the blocking call never trusts a promise) */
 int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                       int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
 

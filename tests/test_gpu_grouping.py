@@ -13,7 +13,7 @@ from test_gpu_parity import CASES, _random_db, _random_queries
 
 pytestmark = pytest.mark.gpu
 
-FLAG_SORTED, FLAG_BUCKET = 1, 2
+FLAG_SORTED, FLAG_BUCKET, FLAG_EXACT = 1, 2, 4
 
 
 @pytest.fixture(scope="module")
@@ -47,7 +47,7 @@ def test_sorted_batches_all_modes(case, workdir):
         ichr, qs, qe = _sorted(ichr, qs, qe)
         for v in (0, 1, 500):
             want, wtot = orc.search(ichr, qs, qe, v)
-            for flags in (0, FLAG_BUCKET):
+            for flags in (0, FLAG_BUCKET, FLAG_EXACT, FLAG_BUCKET | FLAG_EXACT):
                 got, gtot = db.search(ichr, qs, qe, v, flags=flags)
                 assert gtot == wtot, (case, v, flags)
                 np.testing.assert_array_equal(got, want, err_msg="case %d v %d flags %d" % (case, v, flags))
@@ -128,6 +128,64 @@ def test_alternating_batches_keep_workspace_clean(workdir):
                 gq, gr = db.enumerate(ichr[:300], qs[:300], qe[:300])
                 np.testing.assert_array_equal(gq, wq)
                 np.testing.assert_array_equal(gr[:, 1:], wr)
+    finally:
+        db.close()
+        orc.close()
+
+
+@pytest.mark.parametrize("nbp_log,wide_values", [(11, False), (12, True), (15, False), (16, False)])
+def test_compact_image_edges(nbp_log, wide_values, workdir):
+    """The 6-byte tile-relative image must agree with the exact arrays everywhere, including
+    the one case it cannot express (first-tile query with qe <= tile start: inverted queries that
+    reach back over a tile boundary), values outside int16 (falls back to exact arrays for -v)
+    and tile widths at / beyond its 16-bit limit (2^15 packs, 2^16 does not)."""
+    import os
+    from helpers import write_igd_numpy
+    from igd_amd import Database
+    rng = random.Random(900 + nbp_log)
+    nbp = 1 << nbp_log
+    span = 12 * nbp
+    files = []
+    for f in range(7):
+        rows = []
+        for _ in range(150):
+            s = rng.randrange(0, span)
+            L = rng.choice([1, 2, nbp - 1, nbp, nbp + 1, 3 * nbp + 5, rng.randint(1, 2 * nbp)])
+            if rng.random() < 0.3:
+                s = (s // nbp) * nbp - rng.choice([0, 1])          # starts at / just before a tile start
+                s = max(s, 0)
+            val = rng.choice([0, 1, 500, 32767, 40000, -5, -40000]) if wide_values else rng.randint(0, 1000)
+            rows.append(("chr1", s, s + L, val))
+        files.append(rows)
+    path = os.path.join(workdir, "cmp%d%d.igd" % (nbp_log, wide_values))
+    write_igd_numpy(path, files, nbp=nbp, gtype=1)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        qs, qe = [], []
+        for t in range(0, 13):
+            T = t * nbp
+            for dq in (-3, -1, 0, 1, 5, nbp - 1):
+                for de in (-nbp - 2, -7, -1, 0, 1, 2, nbp, 2 * nbp + 1):
+                    qs.append(T + dq)
+                    qe.append(T + dq + de)
+        for _ in range(1500):
+            a = rng.randrange(-nbp + 1, span + nbp)
+            qs.append(a)
+            qe.append(a + rng.choice([-rng.randint(1, 3 * nbp), 0, 1, rng.randint(1, 2 * nbp)]))
+        qs = np.array(qs, np.int32); qe = np.array(qe, np.int32)
+        keep = qs > -nbp                                           # qs <= -nbp is reference UB
+        qs, qe = qs[keep], qe[keep]
+        ichr = np.zeros(len(qs), np.int32)
+        for order in ("as-is", "sorted"):
+            if order == "sorted":
+                ichr, qs, qe = _sorted(ichr, qs, qe)
+            for v in (0, 1, 501, 33000):
+                want, wtot = orc.search(ichr, qs, qe, v)
+                for flags in (0, FLAG_BUCKET, FLAG_EXACT):
+                    got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                    assert gtot == wtot, (order, v, flags)
+                    np.testing.assert_array_equal(got, want, err_msg="%s v=%d flags=%d" % (order, v, flags))
     finally:
         db.close()
         orc.close()
