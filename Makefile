@@ -16,7 +16,7 @@ HIPFLAGS?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-functio
 INC     := -Iinclude -Iigd_amd/csrc
 SRC     := igd_amd/csrc
 LIB     ?= igd_amd/lib
-RPATH   := -Wl,-rpath,'$$ORIGIN' -Wl,-Bsymbolic
+RPATH   := -Wl,-rpath,'$$ORIGIN' -Wl,-Bsymbolic-functions
 
 all: $(LIB)/libigd_hip.so $(LIB)/libigd.so $(LIB)/libigd_py.so $(LIB)/libigdr.so \
      $(LIB)/libigd_synth.so bin/igd bin/igd_synth

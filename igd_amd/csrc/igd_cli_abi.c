@@ -28,6 +28,16 @@ static igdc_db *g_core = NULL;       /* header tables + dictionary + device hand
 static iGD_t   *g_core_of = NULL;    /* the iGD_t that g_core mirrors                      */
 static char    *g_core_path = NULL;
 
+/* The database the search functions work on.  In the reference everything is one program and
+ * `IGD` is THE global (src/igd.c:15).  When this library is a shared object and the calling
+ * program defines its own `IGD` (as src/igd.c does) without exporting it, the program's variable
+ * and ours are different objects and ours stays NULL: then the handle last returned by
+ * get_igdinfo() is the database -- which is what the program stored in its `IGD` anyway. */
+static iGD_t *cur_igd(void)
+{
+    return (IGD && IGD == g_core_of) ? IGD : g_core_of;
+}
+
 static int device_from_env(void)
 {
     const char *e = getenv("IGD_DEVICE");
@@ -45,12 +55,13 @@ static void die_no_gpu(const char *where, int rc)
  * reference would do its first fseek/fread on fP (src/igd_search.c:469-476). */
 static igd_hip_db *engine(void)
 {
-    if (!IGD || !g_core || g_core_of != IGD) {
+    iGD_t *G = cur_igd();
+    if (!G || !g_core) {
         fprintf(stderr, "igd: search called before get_igdinfo()\n");
         exit(EX_SOFTWARE);
     }
-    if (g_core->dev && igd_hip_nfiles(g_core->dev) == IGD->nFiles) return g_core->dev;
-    g_core->nFiles = IGD->nFiles;        /* hits[] is sized from the TSV (:923-925) */
+    if (g_core->dev && igd_hip_nfiles(g_core->dev) == G->nFiles) return g_core->dev;
+    g_core->nFiles = G->nFiles;          /* hits[] is sized from the TSV (:923-925) */
     int rc = fP ? igdc_attach_fp(g_core, fP, device_from_env())
                 : igdc_attach_path(g_core, g_core_path, device_from_env());
     if (rc != IGD_HIP_OK) die_no_gpu("open", rc);
@@ -77,7 +88,7 @@ int32_t bSearch(gdata_t *g, int32_t t0, int32_t tc, int32_t qe)    /* src/igd_ba
 
 int32_t get_id(const char *chrm)                                   /* src/igd_base.c:325-331 */
 {
-    return igdc_get_id((const igdc_db *)hc, chrm);
+    return igdc_get_id(hc ? (const igdc_db *)hc : g_core, chrm);
 }
 
 info_t *get_fileinfo(char *ifName, int32_t *nFiles)                /* src/igd_base.c:235-267 */
@@ -168,7 +179,7 @@ int32_t get_overlaps_v(char *chrm, int32_t qs, int32_t qe, int32_t v, int64_t *h
 /* ------------------------------- query files ------------------------------------------ */
 static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
 {
-    if (!g_core || g_core_of != IGD) { engine(); }
+    if (!g_core || !cur_igd()) { engine(); }
     igdc_queries q;
     if (igdc_read_queries(g_core, qFile, 1, &q) != 0) return 0;      /* :701-702 */
     int64_t total = 0;
@@ -219,6 +230,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 {
     if (q->n == 0) return 0;
     igd_hip_db *dev = engine();
+    iGD_t *G = cur_igd();
     int64_t *qoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->n + 1));
     igd_hip_hit *hit = NULL;
     int64_t total = 0, grand = 0;
@@ -231,8 +243,8 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
         if (rc != IGD_HIP_OK) die_no_gpu("enumerate", rc);
         for (int64_t i = 0; i < m; i++) {
             const int32_t c = q->ichr[q0 + i], qs = q->qs[q0 + i], qe = q->qe[q0 + i];
-            const int32_t n1 = qs / IGD->nbp;
-            if (n1 > IGD->nTile[c] - 1 || n1 < 0) continue;           /* :544-545 */
+            const int32_t n1 = qs / G->nbp;
+            if (n1 > G->nTile[c] - 1 || n1 < 0) continue;           /* :544-545 */
             ob_room(&o, 128);
             ob_str(&o, "Query ", 6);
             ob_str(&o, names[q0 + i], strlen(names[q0 + i]));
@@ -240,7 +252,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
             ob_str(&o, ": \n", 3);
             int32_t k = 0;
             for (int64_t h = qoff[i]; h < qoff[i + 1]; h++, k++) {
-                const char *fn = IGD->finfo[hit[h].idx].fileName;
+                const char *fn = G->finfo[hit[h].idx].fileName;
                 size_t L = strlen(fn);
                 ob_room(&o, 64 + L);
                 if (L + 64 > o.cap) { ob_flush(&o); printf("%i\t %i\t %i\t %s\n", k, hit[h].start, hit[h].end, fn); continue; }
@@ -260,7 +272,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 
 static int64_t file_enumerate(const char *qFile)
 {
-    if (!g_core || g_core_of != IGD) engine();
+    if (!g_core || !cur_igd()) engine();
     igdc_lines *r = igdc_lines_open(qFile);
     if (!r) return 0;
     igdc_queries q;

@@ -78,6 +78,8 @@ def orc():
         lib.orc_ctg_name.argtypes = [C.c_void_p, C.c_int32]
         lib.orc_file_name.restype = C.c_char_p
         lib.orc_file_name.argtypes = [C.c_void_p, C.c_int32]
+        lib.orc_file_nr.restype = C.c_int32
+        lib.orc_file_nr.argtypes = [C.c_void_p, C.c_int32]
         lib.orc_get_id.restype = C.c_int32
         lib.orc_get_id.argtypes = [C.c_void_p, C.c_char_p]
         lib.orc_get_stats.restype = C.POINTER(OrcStats)

@@ -1,0 +1,102 @@
+"""GPU, BASELINE.json's full sizes (roadmap-scale synthetic .igd: 1900 files x 26316 intervals,
+53 M tile records; 10^6 queries): size-independent properties, plus the REAL reference's totals
+when the prebuilt oracle/_ref/igd travelled with the repo.
+
+  * every grouping / image choice of the engine gives the identical per-file vector
+  * any permutation and any sharding of the queries gives the identical vector (hits[] is a sum)
+  * sum(hits) == returned total; the -v path equals the reference at v=500
+  * histogram of the enumerated (-f) records' dataset index == the counted hits vector
+  * the engine's exact work statistics (algorithmic-byte model) equal the oracle's
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import REF_BIN, Oracle, have_ref, parse_hits_table
+
+pytestmark = pytest.mark.gpu
+DIR = "/tmp/igdb"
+FILES, PER_FILE, Q = 1900, 26316, 1000000
+
+
+@pytest.fixture(scope="module")
+def big():
+    from igd_amd import Database, synth
+    path = os.path.join(DIR, "rm%dx%d.igd" % (FILES, PER_FILE))
+    if not (os.path.exists(path) and os.path.exists(path + ".done")):
+        os.makedirs(DIR, exist_ok=True)
+        synth.make_db(path, files=FILES, per_file=PER_FILE, seed=1000, nbp_log=14, genome=synth.HG38)
+        open(path + ".done", "w").write("ok")
+    db = Database(path)
+    q = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=True)
+    yield db, path, q
+    db.close()
+
+
+def test_all_engine_paths_agree_and_match_reference(big):
+    from igd_amd import synth
+    db, path, (ichr, qs, qe) = big
+    base, tot = db.search(ichr, qs, qe)
+    assert base.sum() == tot and tot > 3e7
+    for flags in (2, 4, 6):                       # bucket, exact arrays, both
+        h, t = db.search(ichr, qs, qe, flags=flags)
+        assert t == tot
+        np.testing.assert_array_equal(h, base)
+    perm = np.random.default_rng(1).permutation(Q)
+    h, t = db.search(ichr[perm], qs[perm], qe[perm])
+    np.testing.assert_array_equal(h, base)
+    acc = np.zeros_like(base)
+    for k in range(8):                            # 8 contiguous shards, as 8 GPUs would take them
+        lo, hi = k * Q // 8, (k + 1) * Q // 8
+        acc += db.search(ichr[lo:hi], qs[lo:hi], qe[lo:hi])[0]
+    np.testing.assert_array_equal(acc, base)
+    hv, tv = db.search(ichr, qs, qe, v=500)
+    assert hv.sum() == tv and 0.3 * tot < tv < 0.7 * tot
+    np.testing.assert_array_equal(db.search(ichr, qs, qe, v=500, flags=6)[0], hv)
+    if have_ref():
+        bed = os.path.join(DIR, "t_q.bed")
+        synth.write_bed(bed, synth.HG38, ichr, qs, qe)
+        for extra, want in (([], base), (["-v", "500"], hv)):
+            out = subprocess.run([REF_BIN, "search", path, "-q", bed] + extra, stdout=subprocess.PIPE, check=True).stdout.decode()
+            rh, rt = parse_hits_table(out, db.nfiles)
+            np.testing.assert_array_equal(rh, want)
+            assert rt == want.sum()
+
+
+def test_enumeration_histogram_equals_counts(big):
+    db, path, (ichr, qs, qe) = big
+    n = 200000
+    sl = slice(300000, 300000 + n)
+    hits, tot = db.search(ichr[sl], qs[sl], qe[sl])
+    qoff, rec = db.enumerate(ichr[sl], qs[sl], qe[sl])
+    assert qoff[-1] == tot == len(rec)
+    np.testing.assert_array_equal(np.bincount(rec[:, 1], minlength=db.nfiles), hits)
+    assert (np.diff(qoff) >= 0).all()
+    np.testing.assert_array_equal(rec[:, 0], np.repeat(np.arange(n), np.diff(qoff)))
+    # every emitted record really overlaps its query (half-open on both sides)
+    q = rec[:, 0]
+    assert (rec[:, 2] < qe[sl][q]).all() and (rec[:, 3] > qs[sl][q]).all()
+    # spot-check the order against the oracle on the first 2000 queries
+    o = Oracle(path)
+    wq, wr = o.enumerate(ichr[sl][:2000], qs[sl][:2000], qe[sl][:2000])
+    np.testing.assert_array_equal(qoff[:2001], wq)
+    np.testing.assert_array_equal(rec[: wq[-1], 1:], wr)
+    o.close()
+
+
+def test_work_statistics_equal_oracle(big):
+    import torch
+    db, path, (ichr, qs, qe) = big
+    n = 20000
+    idx = np.arange(0, Q, Q // n)[:n]
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(np.ascontiguousarray(x[idx])).to(dev) for x in (ichr, qs, qe)]
+    o = Oracle(path)
+    for v in (0, 500):
+        st = db.batch_stats(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n, v=v)
+        o.search(ichr[idx], qs[idx], qe[idx], v)
+        w = o.stats()
+        assert (st["pairs"], st["S"], st["B"], st["H"]) == (w["pairs"], w["S"], w["B"], w["H"]), (v, st, w)
+    o.close()

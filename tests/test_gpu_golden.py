@@ -1,0 +1,147 @@
+"""GPU: the product's front-ends against the golden fixtures (the REAL reference's stdout and the
+reference's own Python wrapper's return values) and the oracle.
+
+  - bin/igd search ... prints, byte for byte, what the reference printed (tests/golden/*/outNN.txt)
+  - a C program written against include/igd_search.h the way the reference's igd.c is (it defines
+    the process-wide globals itself) compiles, links with -ligd and gets the oracle's numbers
+  - igd_py (the Cython wrapper's class, bound with ctypes to libigd_py.so) returns what the
+    reference's wrapper returned (tests/golden/pywrap.json)
+  - the R flavour's plain-C / .C entry points (libigdr.so) agree with the oracle
+"""
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, Oracle, short_tmpdir
+from test_golden_oracle import CASES, materialize
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "bin", "igd")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_cli_prints_what_the_reference_printed(case):
+    d, dst, man = materialize(case)
+    try:
+        for run in man["runs"]:
+            args = [os.path.join(dst, a) if a in ("db.igd", "q.bed", "q.bed.gz", "q100.bed") else a for a in run["args"]]
+            p = subprocess.run([EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()[-300:]
+            want = open(os.path.join(dst, run["stdout"])).read()
+            assert p.stdout.decode() == want, "%s %s" % (case, run["args"])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("case,chrom,s,e,v", [("smallrand", "chr2", 100000, 260000, 500), ("quirk", "chr1", 100, 30000, 1),
+                                             ("gtype0", "chr1", 5000, 30000, 0), ("edge", "chr1", 20000, 40000, 500)])
+def test_c_caller_written_like_the_reference_main(case, chrom, s, e, v):
+    d = short_tmpdir("igm")
+    try:
+        exe = os.path.join(d, "m")
+        lib = os.path.join(ROOT, "igd_amd", "lib")
+        subprocess.check_call(["gcc", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                               os.path.join(ROOT, "tests", "c", "cli_flavour_main.c"), "-L" + lib, "-ligd", "-ligd_hip",
+                               "-Wl,-rpath," + lib])
+        db = os.path.join(GOLDEN, case, "db.igd")
+        q = os.path.join(GOLDEN, case, "q.bed")
+        out = subprocess.run([exe, db, q, chrom, str(s), str(e), str(v)], stdout=subprocess.PIPE, check=True).stdout.decode()
+        o = Oracle(db)
+        lines = {l.split(" ret=")[0]: l for l in out.splitlines() if " ret=" in l}
+
+        def parse(tag):
+            l = lines[tag]
+            ret = int(l.split("ret=")[1].split()[0])
+            h = l.split("hits=")[1] if "hits=" in l else ""
+            return ret, np.array([int(x) for x in h.split(",") if x], np.int64)
+
+        want, _ = o.file_search(q, 0)
+        ret, h = parse("getOverlaps")
+        assert ret == 0                                     # the reference's counter is never incremented there
+        np.testing.assert_array_equal(h, want)
+        np.testing.assert_array_equal(parse("getOverlaps(again,accumulates)")[1], 2 * want)
+        ci = o.get_id(chrom)
+        one = lambda vv: o.search(np.array([ci], np.int32), np.array([s], np.int32), np.array([e], np.int32), vv)
+        if o.gtype == 1:
+            wv, wtot = o.file_search(q, v)
+            ret, h = parse("getOverlaps_v")
+            assert ret == wtot == wv.sum()
+            np.testing.assert_array_equal(h, wv)
+            w1, t1 = one(v)
+            ret, h = parse("get_overlaps_v")
+            assert ret == t1
+            np.testing.assert_array_equal(h, w1)
+            ret, h = parse("get_overlaps")
+            assert ret == 0
+            np.testing.assert_array_equal(h, one(0)[0])
+            # -f prints "Query ..." + one line per overlap, returns their number (rule NEST)
+            qoff, rec = o.enumerate(np.array([ci], np.int32), np.array([s], np.int32), np.array([e], np.int32))
+            assert "get_overlaps_f1 ret=%d" % len(rec) in out
+        else:
+            np.testing.assert_array_equal(parse("getOverlaps0")[1], want)
+            np.testing.assert_array_equal(parse("get_overlaps0")[1], one(0)[0])
+        assert "id(%s)=%d id(nope)=-1" % (chrom, ci) in out
+        assert "getOverlaps(missing file)=0" in out
+        assert "parse_bed -> chr1 12 34" in out
+        o.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_python_wrapper_class_returns_what_the_reference_wrapper_returned():
+    from igd_amd import igd_py as iGD          # the reference's test does `import igd_py as iGD`
+    pins = json.load(open(os.path.join(GOLDEN, "pywrap.json")))
+    g = iGD.igd_py()
+    g.open(os.path.join(GOLDEN, "smallrand", "db.igd"))
+    n = g.get_nFiles()
+    assert n == pins["nFiles"]
+    h = np.zeros(n, dtype="int64")
+    tot = g.search_n(os.path.join(GOLDEN, "smallrand", "q.bed"), h)
+    assert tot == pins["search_n_return"]
+    assert h.tolist() == pins["search_n_hits"]
+    for key, want in pins["search_1"].items():
+        c, rng = key.split(":")
+        s, e = rng.split("-")
+        v = np.zeros(n, dtype="int64")
+        g.search_1(c, int(s), int(e), v)
+        assert v.tolist() == want, key
+    # a handle that was never opened can be dropped (the reference frees garbage there)
+    iGD.igd_py().__del__()
+
+
+def test_r_flavour_c_entry_points():
+    from igd_amd import _native as N
+    L = N.rabi()
+    db = os.path.join(GOLDEN, "smallrand", "db.igd")
+    q = os.path.join(GOLDEN, "smallrand", "q.bed")
+    o = Oracle(db)
+    n = o.nfiles
+    # .C getOverlaps(char **igdFile, char **qFile, int64 *hits): any contig name, >= 3 fields
+    h = np.zeros(n, np.int64)
+    a, b = (C.c_char_p * 1)(db.encode()), (C.c_char_p * 1)(q.encode())
+    L.getOverlaps(a, b, h.ctypes.data_as(N.i64p))
+    np.testing.assert_array_equal(h, o.file_search(q, 0)[0])
+    # .C search_1
+    h1 = np.zeros(n, np.int64)
+    cs, ce = C.c_int32(1000000), C.c_int32(1100000)
+    L.search_1(a, (C.c_char_p * 1)(b"chr1"), C.byref(cs), C.byref(ce), h1.ctypes.data_as(N.i64p))
+    want = o.search(np.array([o.get_id("chr1")], np.int32), np.array([1000000], np.int32), np.array([1100000], np.int32))[0]
+    np.testing.assert_array_equal(h1, want)
+    # handle + 32-bit counters (what search_1r / search_nr use)
+    hnd = L.open_iGD(db.encode())
+    h32 = np.zeros(n, np.int32)
+    L.get_overlaps32(hnd, b"chr1", 1000000, 1100000, h32.ctypes.data_as(N.i32p))
+    np.testing.assert_array_equal(h32, want)
+    ichr, qs, qe = o.read_queries(q)
+    names = o.ctg_names()
+    arr = (C.c_char_p * len(qs))(*[names[c].encode() for c in ichr])
+    h32[:] = 0
+    L.igdr_search_n32(hnd, len(qs), arr, qs.ctypes.data_as(N.i32p), qe.ctypes.data_as(N.i32p), h32.ctypes.data_as(N.i32p))
+    np.testing.assert_array_equal(h32, o.search(ichr, qs, qe)[0])
+    L.close_iGD(hnd)
+    o.close()

@@ -1,0 +1,239 @@
+"""Host side of the product (C, no GPU needed): .igd / _index.tsv loaders, contig lookup, BED
+reader, bSearch, the minimal writer, the generator -- each against the CPU oracle or the golden
+fixtures -- and the C-ABI surface: every function declared in include/*.h is exported by the
+library that implements it.  No search is executed here."""
+import ctypes as C
+import json
+import os
+import random
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, ROOT, Oracle, orc, parse_hits_table, run_oracle_cli, short_tmpdir, write_bed
+from test_golden_oracle import materialize
+
+
+@pytest.fixture(scope="module")
+def N():
+    from igd_amd import _native
+    if not os.path.exists(os.path.join(_native.LIBDIR, "libigd.so")):
+        _native.build()
+    return _native
+
+
+@pytest.mark.parametrize("case", ["edge", "quirk", "branch", "gtype0", "smallrand"])
+def test_header_loader_matches_oracle(case, N):
+    L = N.cli()
+    path = os.path.join(GOLDEN, case, "db.igd")
+    core = L.igdc_open(path.encode())
+    assert core
+    tsv = L.igdc_index_path(path.encode())
+    assert C.cast(tsv, C.c_char_p).value.decode() == os.path.join(GOLDEN, case, "db_index.tsv")
+    assert L.igdc_load_index(core, C.cast(tsv, C.c_char_p)) == 0
+    N.free(tsv)
+    o = Oracle(path, preload=False)
+    c = core.contents
+    assert (c.nbp, c.gType, c.nCtg, c.nFiles) == (o.nbp, o.gtype, o.nctg, o.nfiles)
+    lib = orc()
+    nrec = 0
+    for i in range(c.nCtg):
+        assert c.cName[i].decode() == lib.orc_ctg_name(o.h, i).decode()
+        assert c.nTile[i] == lib.orc_ntile(o.h, i)
+        for j in range(c.nTile[i]):
+            assert c.nCnt[i][j] == lib.orc_ncnt(o.h, i, j)
+            nrec += c.nCnt[i][j]
+        assert L.igdc_get_id(core, c.cName[i]) == i
+    assert c.nRecords == nrec
+    rec = 12 if c.gType == 0 else 16
+    assert c.dataOff + rec * nrec == os.path.getsize(path)
+    for i in range(c.nFiles):
+        assert c.fileName[i].decode() == lib.orc_file_name(o.h, i).decode()
+        assert c.fileNr[i] == lib.orc_file_nr(o.h, i)
+    for bad in (b"chr", b"Chr1", b"chr1 ", b"", b"chr99"):
+        assert L.igdc_get_id(core, bad) == o.get_id(bad.decode())
+    L.igdc_close(core)
+    o.close()
+
+
+def test_query_reader_matches_oracle_and_reference_rules(N):
+    """parse fixture: headers, short lines, end<=0, non-chr names, 39/40-char names, CRLF,
+    junk suffixes, no final newline, gz -- same accepted (contig,start,end) list as the oracle."""
+    L = N.cli()
+    case = os.path.join(GOLDEN, "parse")
+    core = L.igdc_open(os.path.join(case, "db.igd").encode())
+    o = Oracle(os.path.join(case, "db.igd"), preload=False)
+    for q in ("q.bed", "q.bed.gz"):
+        want = o.read_queries(os.path.join(case, q))
+        qq = N.CoreQueries()
+        assert L.igdc_read_queries(core, os.path.join(case, q).encode(), 1, C.byref(qq)) == 0
+        got = [np.ctypeslib.as_array(p, shape=(qq.n,)).copy() for p in (qq.ichr, qq.qs, qq.qe)]
+        L.igdc_queries_free(C.byref(qq))
+        assert qq.n == 0 or len(got[0]) == len(want[0])
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(g, w)
+        assert len(want[0]) == 7        # the 7 lines the reference accepts for known contigs
+    # the Python/R rule (any contig name, end may be <= 0): strictly more lines
+    qq = N.CoreQueries()
+    assert L.igdc_read_queries(core, os.path.join(case, "q.bed").encode(), 0, C.byref(qq)) == 0
+    assert qq.n == 10
+    L.igdc_queries_free(C.byref(qq))
+    L.igdc_close(core)
+    o.close()
+
+
+def test_parse_bed_line_fuzz(N):
+    L = N.cli()
+    lib = orc()
+    rng = random.Random(3)
+    pieces = ["chr1", "chrX", "1", "chr", "Chr2", "chr" + "a" * 36, "chr" + "a" * 37, "", " chr1", "100", "-5", "0",
+              "12abc", " 77", "+9", "2147483648", "99999999999", "1e5", "x", "\r"]
+    for _ in range(3000):
+        n = rng.randint(0, 6)
+        line = "\t".join(rng.choice(pieces) for _ in range(n)).encode()
+        a, b = C.create_string_buffer(line, len(line) + 2), C.create_string_buffer(line, len(line) + 2)
+        s1, e1, s2, e2 = C.c_int32(7), C.c_int32(7), C.c_int32(7), C.c_int32(7)
+        r1 = L.parse_bed(a, C.byref(s1), C.byref(e1))
+        r2 = lib.orc_parse_bed(b, C.byref(s2), C.byref(e2))
+        assert bool(r1) == bool(r2), line
+        assert (s1.value, e1.value) == (s2.value, e2.value), line
+        if r1:
+            assert C.cast(r1, C.c_char_p).value == C.cast(r2, C.c_char_p).value
+
+
+def test_bsearch_is_last_start_below_qe(N):
+    L = N.cli()
+    rng = random.Random(9)
+    for _ in range(300):
+        n = rng.randint(1, 40)
+        starts = sorted(rng.randint(0, 30) for _ in range(n))
+        g = np.zeros((n, 4), np.int32)
+        g[:, 1] = starts
+        for qe in range(-1, 33):
+            want = max([i for i in range(n) if starts[i] < qe], default=-1)
+            assert L.bSearch(g.ctypes.data, 0, n - 1, qe) == want
+
+
+def test_product_writer_equals_reference_create_on_counts(N):
+    """smallrand: the same BED files through the product's minimal `create`; the oracle's counts
+    on that .igd must equal the reference's stdout on ITS .igd (tie order inside a tile may differ
+    -- the reference's radix sort is not stable -- so counts, not -f text)."""
+    d, dst, man = materialize("smallrand")
+    try:
+        out = os.path.join(d, "w")
+        os.makedirs(out)
+        L = N.cli()
+        assert L.igdc_create_from_beds((os.path.join(dst, "beds") + "/*").encode(), out.encode(), b"db", 16384, 1) == 0
+        mine = os.path.join(out, "db.igd")
+        ref_tsv = open(os.path.join(dst, "db_index.tsv")).read().splitlines()
+        my_tsv = open(os.path.join(out, "db_index.tsv")).read().splitlines()
+        assert [l.split("\t")[:3] for l in my_tsv] == [l.split("\t")[:3] for l in ref_tsv]
+        # same header tables as the reference's file
+        a, b = Oracle(mine, preload=False), Oracle(os.path.join(dst, "db.igd"), preload=False)
+        assert (a.nbp, a.gtype, a.nctg, a.nfiles, a.ctg_names()) == (b.nbp, b.gtype, b.nctg, b.nfiles, b.ctg_names())
+        lib = orc()
+        for i in range(a.nctg):
+            assert lib.orc_ntile(a.h, i) == lib.orc_ntile(b.h, i)
+            for j in range(lib.orc_ntile(a.h, i)):
+                assert lib.orc_ncnt(a.h, i, j) == lib.orc_ncnt(b.h, i, j)
+        a.close(); b.close()
+        for run in man["runs"][:2]:
+            args = [mine if x == "db.igd" else os.path.join(dst, x) if x == "q.bed" else x for x in run["args"]]
+            got = parse_hits_table(run_oracle_cli(args), 12)
+            want = parse_hits_table(open(os.path.join(dst, run["stdout"])).read(), 12)
+            np.testing.assert_array_equal(got[0], want[0])
+            assert got[1] == want[1]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_writer_handles_fewer_than_ten_files_and_gtype0(N):
+    """the reference's create divides by n_files/10 (SIGFPE below 10 files): ours must not."""
+    d = short_tmpdir("igw")
+    try:
+        beds = os.path.join(d, "b")
+        os.makedirs(beds)
+        write_bed(os.path.join(beds, "a.bed"), [("chr1", 5, 50, "n", 3), ("chr2", 70000, 70001, "n", 9), ("chr1", 9, 9, "n", 1)])
+        write_bed(os.path.join(beds, "b.bed"), [("chr2", 16384, 40000, "n", 7)])
+        L = N.cli()
+        for gt in (1, 0):
+            out = os.path.join(d, "o%d" % gt)
+            assert L.igdc_create_from_beds((beds + "/*").encode(), out.encode(), b"x", 16384, gt) == 0
+            o = Oracle(os.path.join(out, "x.igd"))
+            assert (o.nfiles, o.gtype, o.ctg_names()) == (2, gt, ["chr1", "chr2"])
+            h, _ = o.search(np.array([0, 1, 1], np.int32), np.array([0, 16000, 69999], np.int32), np.array([100, 17000, 70001], np.int32))
+            # query 2 starts in chr2's EMPTY tile 0: rule NEST drops it although tile 1 overlaps
+            np.testing.assert_array_equal(h, [2, 0])
+            if gt == 1:
+                np.testing.assert_array_equal(o.search(np.array([1], np.int32), np.array([16000], np.int32), np.array([17000], np.int32), 1)[0], [0, 1])
+            o.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_generator_queries_sorted_and_reproducible(N):
+    from igd_amd import synth
+    a = synth.make_queries(5000, seed=7, genome=synth.HG38)
+    b = synth.make_queries(5000, seed=7, genome=synth.HG38)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    key = a[0].astype(np.int64) * (1 << 32) + a[1]
+    assert (np.diff(key) >= 0).all()
+    c = synth.make_queries(5000, seed=7, genome=synth.HG38, sorted_=False)
+    assert sorted(zip(*[v.tolist() for v in c])) == sorted(zip(*[v.tolist() for v in a]))
+    assert (a[2] - a[1] >= 100).all() and (a[2] - a[1] <= 1999).all()
+
+
+# --------------------------------------------------------------------------------------------
+# C ABI surface
+HEADER_LIBS = {"igd_hip.h": "libigd_hip.so", "igd_search.h": "libigd.so", "igd_base.h": "libigd.so",
+               "igd_py_abi.h": "libigd_py.so", "igdr_abi.h": "libigdr.so"}
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef IGDR_HAVE_R.*?#endif", "", txt, flags=re.S)   # .Call group needs R headers
+    names = re.findall(r"^\s*(?:[A-Za-z_][\w\s\*]*?[\s\*])([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", txt, flags=re.M)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+@pytest.mark.parametrize("header", sorted(HEADER_LIBS))
+def test_every_declared_function_is_exported(header, N):
+    lib = os.path.join(N.LIBDIR, HEADER_LIBS[header])
+    assert os.path.exists(lib), "run make"
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = set(l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TBDW")
+    names = _declared_functions(header)
+    assert len(names) >= 5, (header, names)
+    missing = [n for n in names if n not in exported]
+    assert not missing, "%s declares but %s does not export: %s" % (header, HEADER_LIBS[header], missing)
+    C.CDLL(lib)      # and it loads (HIP runtime resolves) without a GPU
+
+
+def test_cli_globals_are_exported(N):
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(N.LIBDIR, "libigd.so")],
+                         stdout=subprocess.PIPE, check=True).stdout.decode()
+    syms = set(l.split()[-1] for l in out.splitlines())
+    for g in ("hc", "IGD", "gData", "gData0", "preIdx", "preChr", "tile_size", "fP"):
+        assert g in syms
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback(N):
+    """product path must fail loudly without a usable HIP device (this test is for GPU-less hosts)."""
+    if N.hip().igd_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from igd_amd import Database
+    from igd_amd.database import IgdError
+    with pytest.raises(IgdError, match="no CPU search path"):
+        Database(os.path.join(GOLDEN, "edge", "db.igd"))
+    exe = os.path.join(ROOT, "bin", "igd")
+    p = subprocess.run([exe, "search", os.path.join(GOLDEN, "edge", "db.igd"), "-q", os.path.join(GOLDEN, "edge", "q.bed")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 69 and b"no CPU search path" in p.stderr and b"Total" not in p.stdout
+    # ... and the package never imports the oracle
+    src = "".join(open(os.path.join(ROOT, "igd_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "igd_amd")) if f.endswith(".py"))
+    assert "oracle" not in src.lower().replace("no cpu", "")
