@@ -75,6 +75,21 @@ def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5):
             "seconds": best, "totals_match_gpu": ok}
 
 
+def measured_traffic(mode, args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile.sh
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of THIS command; FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950 streaming reads).  Counters cannot be collected
+    from inside the benchmark process, so the committed summary is reported when it was taken with
+    the same workload; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        key = "%s/%s/q%d" % (mode, "shuffled" if args.shuffled else "sorted", args.queries)
+        return t.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,9 +103,12 @@ def main():
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
-    ap.add_argument("--grouping", choices=["auto", "sorted", "bucket"], default="auto",
-                    help="auto: the device checks the query order and picks merge-join or bucketing (default); "
-                         "sorted: promise (contig,start) order, verified on the device; bucket: always counting-sort")
+    ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
+                    help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
+                         "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
+                         "promises (contig,start) order -- what a position-sorted BED is -- and the device VERIFIES it "
+                         "in the timed region (a broken promise is an error, never a wrong count); bucket: always "
+                         "counting-sort.  default = sorted for the position-sorted workload, auto with --shuffled")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,7 +141,6 @@ def main():
     d_qs = torch.from_numpy(qs).to(dev)
     d_qe = torch.from_numpy(qe).to(dev)
     d_hits = torch.zeros(max(db.nfiles, 1), dtype=torch.int64, device=dev)
-    d_acc = torch.zeros_like(d_hits)
     # One explicit (non-default) stream carries everything: torch's memsets/adds, the engine's
     # kernels (it enqueues on the hipStream_t it is given) and the RCCL all-reduce.
     tstream = torch.cuda.Stream(device=dev)
@@ -132,6 +149,8 @@ def main():
     stream = tstream.cuda_stream
     assert stream != 0
 
+    if args.grouping == "default":
+        args.grouping = "auto" if args.shuffled else "sorted"
     gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
 
     def step():
@@ -139,12 +158,10 @@ def main():
         db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
                       v=args.v, stream=stream, flags=gflags)
         allreduce_hits(d_hits)              # the one collective of the path (no-op at N=1)
-        d_acc.add_(d_hits)
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
-    d_acc.zero_()
     barrier()
     torch.cuda.synchronize(dev)
     db.profile_begin(args.steps)
@@ -165,7 +182,7 @@ def main():
     st = db.batch_stats(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, v=args.v)
     mode = "v" if (args.v > 0 and db.gtype == 1) else "hits"
     algo_bytes = db.algorithmic_bytes(st, Q, mode)
-    hits_one = (d_acc // max(args.steps, 1)).cpu().numpy()
+    hits_one = d_hits.cpu().numpy()       # the last step's (all-reduced) vector
 
     if rank == 0:
         value = world * Q * args.steps / elapsed
@@ -185,12 +202,12 @@ def main():
                        "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
                        "collective": "all-reduce int64[%d] per step" % db.nfiles if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(mode, args),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_query": algo_bytes / Q, "kernel_ms": prof["scan_ms"],
                          "pipeline_ms": prof["pipeline_ms"], "launches_timed": prof["launches"],
                          "work": st},
-            "hits_per_step_total": int(hits_one.sum()) if world == 1 else None,
+            "hits_per_step_total": int(hits_one.sum()),
             "db_open_s": open_s,
         }
         if world == 1 and not args.no_cpu:

@@ -185,7 +185,8 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
     int64_t total = 0;
     if (q.n > 0) {
         igd_hip_db *dev = engine();
-        int rc = igd_hip_search(dev, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total);
+        /* position-sorted BED (the common case): tell the engine, it verifies on the device */
+        int rc = igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
         if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
     }
     igdc_queries_free(&q);

@@ -310,6 +310,7 @@ int igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe)
         if (!a || !b || !c) return -1;
         q->cap = cap;
     }
+    if (q->n > 0 && (ichr < q->ichr[q->n - 1] || (ichr == q->ichr[q->n - 1] && qs < q->qs[q->n - 1]))) q->unsorted = 1;
     q->ichr[q->n] = ichr; q->qs[q->n] = qs; q->qe[q->n] = qe;
     q->n++;
     return 0;

@@ -71,6 +71,7 @@ void        igdc_lines_close(igdc_lines *r);
 typedef struct {
     int64_t n, cap;
     int32_t *ichr, *qs, *qe;
+    int32_t unsorted;        /* 0 while every pushed query was >= the previous by (contig, start) */
 } igdc_queries;
 /* returns 0, or -1 when the file cannot be opened.  Lines whose contig is not in the
  * database are dropped here (the reference drops them in get_overlaps, :456-457). */

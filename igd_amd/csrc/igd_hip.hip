@@ -122,7 +122,7 @@ struct DbView {
     // compact tile-relative image of the same records (6 bytes each), see k_pack_units:
     const uint32_t *pse;                        // s' | e' << 16
     const uint16_t *px;                         // idx
-    const int16_t *pv;                          // value (only when every value fits 16 bits)
+    const uint32_t *pxv;                        // idx | value << 16 (only when every value fits 16 bits)
     const int64_t *tileOff;                     // [nT+1] record offset of each tile
     const int32_t *tileCnt;                     // [nT]
     const int32_t *tileBd;                      // [nT] tile start coordinate j*nbp (INT_MIN for j==0)
@@ -141,7 +141,7 @@ struct igd_hip_db {
     int32_t *d_start, *d_end, *d_idx, *d_value;
     uint32_t *d_pse;
     uint16_t *d_px;
-    int16_t *d_pv;
+    uint32_t *d_pxv;
     bool packed, packedV;         // compact image usable (nbp<=32768, nFiles<=65536) / values fit int16
     int64_t *d_tileOff;
     int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_chunkTile, *d_chunkRec0;
@@ -242,10 +242,12 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 //   ctl[2] = epoch of the last batch that broke a caller's IGD_HIP_FLAG_SORTED promise
 //   ctl[4 + (epoch & 1)] = entries of the bucket path's exact-walk list (k_count_pairs)
 //   ctl[6 + (epoch & 1)] = entries of the merge-join path's exact-walk list (k_query_bounds)
+//   ctl[8 + (epoch & 1)] = gap-fill budget spent by k_query_bounds (units of 256 tiles)
 #define CTL_UNSORTED 1
 #define CTL_BROKEN 2
 #define CTL_NLONG 4
 #define CTL_NFIX 6
+#define CTL_BUDGET 8
 // Exact-walk list entries (int2: query index, kind).  The scan kernels handle the common case
 // only; what they leave out is listed by the grouping kernels and done by k_exact_walk:
 #define WALK_BEYOND 0   // merge join: tiles n1+IGD_SHORT_TILES .. n2 of a long query
@@ -276,6 +278,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     if (i == 0) {                                           // next batch's list counters
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
     }
     const int lane = threadIdx.x & 63;
     int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
@@ -300,15 +303,31 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
             }
         }
     }
-    // short gaps by the owner, long gaps by the whole wave
+    // short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
+    // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
+    // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
+    // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
+    // A wave that sees disorder among its own queries, or finds the batch already marked, fills
+    // nothing: firstQ[] is not going to be used.
+    const bool disorder = __ballot(lo > hi + 1) != 0 ||
+                          __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
     const bool big = hi - lo >= 8;
-    if (!big) for (int t = lo; t <= hi; t++) firstQ[t] = val;
-    unsigned long long m = __ballot(big);
+    if (!big && !disorder) for (int t = lo; t <= hi; t++) firstQ[t] = val;
+    unsigned long long m = disorder ? 0ull : __ballot(big);
     while (m) {
         const int src = __builtin_ctzll(m);
         m &= m - 1;
         const int l2 = __builtin_amdgcn_readlane(lo, src), h2 = __builtin_amdgcn_readlane(hi, src);
         const int v2 = __builtin_amdgcn_readlane(val, src);
+        if (h2 - l2 >= 256) {
+            int spent = 0;
+            if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
+            spent = __builtin_amdgcn_readfirstlane(spent);
+            if (spent > (db.nT >> 8) + 16) {
+                if (lane == 0) ctl[CTL_UNSORTED] = epoch;
+                continue;
+            }
+        }
         for (int t = l2 + lane; t <= h2; t += IGD_WAVE) firstQ[t] = v2;
     }
     // the tail: tiles after the last query's key (done by the last wave)
@@ -340,6 +359,7 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
     if (gate == 0 && i == 0) {
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
     }
     if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     if (i >= nq) return;
@@ -467,7 +487,7 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 // case that needs the exact starts: the grouping kernels list it for k_exact_walk (WALK_FIRST).
 // 6 bytes per record (4 + 2; 8 with the 16-bit value) instead of 12 (16).
 __global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restrict__ pse,
-                                                    uint16_t *__restrict__ px, int16_t *__restrict__ pv,
+                                                    uint16_t *__restrict__ px, uint32_t *__restrict__ pv,
                                                     int32_t *__restrict__ flag /* bit 0: a value needs > 16 bits; bit 1: malformed tile */)
 {
     const int lane = threadIdx.x & 63;
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restr
             if (pv) {
                 const int v = db.value[r];
                 wide |= (v < -32768) | (v > 32767);
-                pv[r] = (int16_t)v;
+                pv[r] = (uint32_t)(uint16_t)db.idx[r] | ((uint32_t)(uint16_t)(int16_t)v << 16);
             }
             // a record that does not belong to its tile (malformed file): keep the exact path
             if (!(st < T + db.nbp && en > T)) wide |= 2;
@@ -569,15 +589,15 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
     // one chunk); compute_unit discards them.
     const uint32_t *pa = db.pse + base;
     const uint16_t *pxx = db.px + base;
-    const int16_t *pvv = USE_V ? db.pv + base : nullptr;
+    const uint32_t *pvv = USE_V ? db.pxv + base : nullptr;
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
         const int i = r * IGD_WAVE + lane;
         const int64_t at = base + (i < n ? i : 0);
         if (PACKED) {
             R.a[r] = pa[i];
-            R.x[r] = (int)pxx[i];
-            if (USE_V) R.w[r] = (int)pvv[i];
+            if (USE_V) R.x[r] = (int)pvv[i];             // idx | value << 16: one word, one register
+            else R.x[r] = (int)pxx[i];
         } else {
             R.a[r] = (uint32_t)db.start[at];
             R.b[r] = db.end[at];
@@ -664,7 +684,10 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
         // lanes past the unit's last record hold someone else's data: make them unmatchable;
         // (compact image) so are records that fail the value filter -- v is fixed for the batch
         bool drop = r * IGD_WAVE + lane >= un;
-        if (PACKED && USE_V) drop = drop || R.w[r] < a.v;
+        if (PACKED && USE_V) {
+            drop = drop || (R.x[r] >> 16) < a.v;         // arithmetic shift: the signed 16-bit value
+            R.x[r] &= 0xFFFF;
+        }
         if (drop) R.a[r] = PACKED ? 0u : (uint32_t)INT_MAX;
     }
     int nLater = 0;                                      // covering queries for which this is NOT the first tile
@@ -1136,7 +1159,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_chunkTile, db->d_chunkRec0,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
-                    db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pv,
+                    db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1363,13 +1386,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         // + one chunk of padding: the scan kernel's loads run up to a chunk past a unit's end
         if ((rc2 = dalloc(&db->d_pse, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK ||
             (rc2 = dalloc(&db->d_px, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK ||
-            (db->gType == 1 && (rc2 = dalloc(&db->d_pv, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK)) {
+            (db->gType == 1 && (rc2 = dalloc(&db->d_pxv, n + IGD_CHUNK, &db->resident)) != IGD_HIP_OK)) {
             igd_hip_close(db);
             return rc2;
         }
         hipError_t e = hipMemset(db->d_ctl, 0, 16 * 4);
         if (e == hipSuccess) {
-            k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_pse, db->d_px, db->d_pv, db->d_ctl);
+            k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_pse, db->d_px, db->d_pxv, db->d_ctl);
             e = hipStreamSynchronize(db->stream);
         }
         int32_t fl = 0;
@@ -1382,7 +1405,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         db->packedV = db->gType == 1 && !(fl & 1);
         if (fl & 2) db->packed = false;          // a record outside its tile: exact arrays only
-        v.pse = db->d_pse; v.px = db->d_px; v.pv = db->d_pv;
+        v.pse = db->d_pse; v.px = db->d_px; v.pxv = db->d_pxv;
     }
     *out = db;
     return IGD_HIP_OK;
@@ -1562,7 +1585,6 @@ extern "C" int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t
 extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                                  int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total)
 {
-    flags &= ~IGD_HIP_FLAG_SORTED;    // the blocking call always lets the device decide
     if (!db || !hits || nq < 0 || (nq > 0 && (!ichr || !qs || !qe))) {
         snprintf(g_err, sizeof g_err, "igd_hip_search: bad argument");
         return IGD_HIP_ERR_ARG;
@@ -1582,7 +1604,15 @@ extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int3
         HIPCHK(hipMemcpyAsync(db->d_qe, qe + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
         rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, flags, db->d_hits, db->d_total, st);
         if (rc != IGD_HIP_OK) return rc;
-        HIPCHK(hipStreamSynchronize(st));                 // staging buffers are reused
+        rc = igd_hip_sync(db, st);                       // staging buffers are reused; promise checked
+        if (rc == IGD_HIP_ERR_UNSORTED) {
+            // the caller's order promise did not hold for this slice (it added nothing): redo it
+            // with the device choosing the grouping
+            flags &= ~IGD_HIP_FLAG_SORTED;
+            rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, flags, db->d_hits, db->d_total, st);
+            if (rc == IGD_HIP_OK) rc = igd_hip_sync(db, st);
+        }
+        if (rc != IGD_HIP_OK) return rc;
     }
     std::vector<int64_t> h((size_t)db->nFiles);
     int64_t tot = 0;

@@ -98,8 +98,8 @@ int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
     igdc_queries q;
     if (igdc_read_queries(iGD->core, qFile, 0, &q) != 0) return 0;
     if (q.n > 0) {
-        int rc = igd_hip_search(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                IGD_HIP_RULE_NEST, hits, NULL);
+        int rc = igd_hip_search_ex(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                   IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
         if (rc != IGD_HIP_OK) die_no_gpu("getOverlaps", rc);
     }
     igdc_queries_free(&q);

@@ -111,8 +111,8 @@ void getOverlaps(char **igdFile, char **qFile, int64_t *hits)
     igdc_queries q;
     if (igdc_read_queries(h->core, *qFile, 0, &q) == 0) {
         if (q.n > 0) {
-            int rc = igd_hip_search(h->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                    IGD_HIP_RULE_NEST, hits, NULL);
+            int rc = igd_hip_search_ex(h->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                       IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
             if (rc != IGD_HIP_OK) die_no_gpu("getOverlaps", rc);
         }
         igdc_queries_free(&q);

@@ -104,7 +104,8 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  * *total (may be NULL) receives the number of overlaps of this batch.  Blocking. */
 int igd_hip_search(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                    int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total);
-/* same with `flags` (IGD_HIP_FLAG_BUCKET / _EXACT; the blocking call never trusts a promise) */
+/* same with `flags`.  An IGD_HIP_FLAG_SORTED promise that the device finds broken is not an
+ * error here: the call repeats that slice with the device choosing the grouping. */
 int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                       int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
 

@@ -189,3 +189,28 @@ def test_compact_image_edges(nbp_log, wide_values, workdir):
     finally:
         db.close()
         orc.close()
+
+
+def test_blocking_api_repairs_a_wrong_order_promise(workdir):
+    """igd_hip_search_ex(..., IGD_HIP_FLAG_SORTED) on UNSORTED host arrays: the device reports the
+    broken promise, the call repeats the slice in auto mode -- counts are right, never doubled."""
+    from igd_amd import Database
+    rng = random.Random(404)
+    nbp = 1 << 12
+    path, ctgs, span = _random_db(rng, workdir, "fix", nbp, 1, 7, 2, 25, 70, 0)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, [0, 1], nbp, span, 2500)
+        for v in (0, 400):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            got, gtot = db.search(ichr, qs, qe, v, flags=FLAG_SORTED)
+            assert gtot == wtot
+            np.testing.assert_array_equal(got, want)
+            si, ss, se = _sorted(ichr, qs, qe)
+            got, gtot = db.search(si, ss, se, v, flags=FLAG_SORTED)
+            assert gtot == wtot
+            np.testing.assert_array_equal(got, want)
+    finally:
+        db.close()
+        orc.close()
