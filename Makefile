@@ -25,7 +25,7 @@ $(LIB) bin:
 	mkdir -p $@
 
 $(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip include/igd_hip.h | $(LIB)
-	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $<
+	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $< -lpthread
 
 CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_create_min.c
 CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create_min.h include/igd_hip.h

@@ -122,6 +122,8 @@ def main():
         log("[bench] note: WORLD_SIZE=%d, --gpus=%d (using WORLD_SIZE)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: igd_amd has no CPU search path")
+    if os.environ.get("IGD_BENCH_ONE_GPU"):      # N>1 control-flow test on a 1-GPU box (with IGD_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

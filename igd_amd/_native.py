@@ -55,7 +55,8 @@ def _load(name):
 
 class HipDesc(C.Structure):
     _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("nFiles", C.c_int32),
-                ("nTile", i32p), ("nCnt", i32p), ("records", C.c_void_p), ("nRecords", C.c_int64)]
+                ("nTile", i32p), ("nCnt", i32p), ("records", C.c_void_p), ("nRecords", C.c_int64),
+                ("fd", C.c_int), ("fd_offset", C.c_int64)]
 
 
 class HipHit(C.Structure):

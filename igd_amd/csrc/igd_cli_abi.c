@@ -12,8 +12,26 @@
 #include <string.h>
 #include <sysexits.h>
 
+#include <time.h>
+
 #include "igd_search.h"
 #include "igd_core.h"
+
+/* IGD_TIMING=1: wall-clock phases of `igd search` on stderr (stdout stays the reference's) */
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static int timing_on(void) { const char *e = getenv("IGD_TIMING"); return e && *e && *e != '0'; }
+static void phase(const char *name, double *t0)
+{
+    if (!timing_on()) return;
+    double t = now_s();
+    fprintf(stderr, "[igd timing] %-28s %8.1f ms\n", name, 1e3 * (t - *t0));
+    *t0 = t;
+}
 
 /* process-wide state of this flavour (reference: src/igd.c:14-19) */
 void     *hc = NULL;
@@ -62,9 +80,13 @@ static igd_hip_db *engine(void)
     }
     if (g_core->dev && igd_hip_nfiles(g_core->dev) == G->nFiles) return g_core->dev;
     g_core->nFiles = G->nFiles;          /* hits[] is sized from the TSV (:923-925) */
-    int rc = fP ? igdc_attach_fp(g_core, fP, device_from_env())
-                : igdc_attach_path(g_core, g_core_path, device_from_env());
+    double t0 = now_s();
+    /* the path is preferred when known (pipelined pread + upload); fP serves callers that only
+     * opened the stream themselves */
+    int rc = g_core_path ? igdc_attach_path(g_core, g_core_path, device_from_env())
+                         : igdc_attach_fp(g_core, fP, device_from_env());
     if (rc != IGD_HIP_OK) die_no_gpu("open", rc);
+    phase("database -> GPU", &t0);
     return g_core->dev;
 }
 
@@ -181,13 +203,17 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
 {
     if (!g_core || !cur_igd()) { engine(); }
     igdc_queries q;
+    double t0 = now_s();
     if (igdc_read_queries(g_core, qFile, 1, &q) != 0) return 0;      /* :701-702 */
+    phase("read + parse queries", &t0);
     int64_t total = 0;
     if (q.n > 0) {
         igd_hip_db *dev = engine();
+        t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
         int rc = igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
         if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+        phase("search (H2D + kernels + D2H)", &t0);
     }
     igdc_queries_free(&q);
     return total;
@@ -352,8 +378,10 @@ int igd_search(int argc, char **argv)                                        /* 
     }
     fclose(probe);
 
+    double t0 = now_s();
     IGD = get_igdinfo(igdName);
     if (!IGD) return EX_OK;
+    phase("header", &t0);
     char *tsv = igdc_index_path(igdName);
     {   /* fname = path without extension; the reference strcpy's into 64 bytes (:916-922) */
         size_t stem = strlen(tsv) - strlen("_index.tsv");

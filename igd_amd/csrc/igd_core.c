@@ -171,16 +171,18 @@ void igdc_close(igdc_db *db)
 }
 
 /* --------------------------------------------------------------------------------------- */
-static int attach_records(igdc_db *db, const void *records, int device)
+static int attach_records(igdc_db *db, const void *records, int fd, int device)
 {
     igd_hip_desc d;
     memset(&d, 0, sizeof d);
     d.nbp = db->nbp; d.gType = db->gType; d.nCtg = db->nCtg; d.nFiles = db->nFiles;
     d.nTile = db->nTile; d.nCnt = db->nCntFlat; d.records = records; d.nRecords = db->nRecords;
+    d.fd = fd; d.fd_offset = db->dataOff;
     if (db->dev) { igd_hip_close(db->dev); db->dev = NULL; }
     return igd_hip_open(&d, device, &db->dev);
 }
 
+/* the engine preads the tile region itself, staged through pinned buffers (no mmap faults) */
 int igdc_attach_path(igdc_db *db, const char *igd_path, int device)
 {
     const int64_t recBytes = db->gType == 0 ? 12 : 16;
@@ -189,13 +191,9 @@ int igdc_attach_path(igdc_db *db, const char *igd_path, int device)
     if (fd < 0) return IGD_HIP_ERR_ARG;
     struct stat st;
     if (fstat(fd, &st) != 0 || (int64_t)st.st_size < need) { close(fd); return IGD_HIP_ERR_ARG; }
-    if (db->nRecords == 0) { close(fd); return attach_records(db, NULL, device); }
-    void *map = mmap(NULL, (size_t)need, PROT_READ, MAP_PRIVATE, fd, 0);
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    int rc = attach_records(db, NULL, fd, device);
     close(fd);
-    if (map == MAP_FAILED) return IGD_HIP_ERR_NOMEM;
-    (void)madvise(map, (size_t)need, MADV_SEQUENTIAL);
-    int rc = attach_records(db, (const char *)map + db->dataOff, device);
-    munmap(map, (size_t)need);
     return rc;
 }
 
@@ -208,7 +206,7 @@ int igdc_attach_fp(igdc_db *db, FILE *fp, int device)
     long keep = ftell(fp);
     int ok = fseeko(fp, (off_t)db->dataOff, SEEK_SET) == 0 && read_exact(fp, buf, bytes) == 0;
     if (keep >= 0) fseek(fp, keep, SEEK_SET);
-    int rc = ok ? attach_records(db, buf, device) : IGD_HIP_ERR_ARG;
+    int rc = ok ? attach_records(db, buf, -1, device) : IGD_HIP_ERR_ARG;
     free(buf);
     return rc;
 }

@@ -41,6 +41,8 @@
 #include <string.h>
 #include <limits.h>
 #include <vector>
+#include <thread>
+#include <unistd.h>
 
 #include "igd_hip.h"
 
@@ -1171,14 +1173,42 @@ extern "C" void igd_hip_close(igd_hip_db *db)
 extern "C" int igd_hip_device(const igd_hip_db *db) { return db ? db->device : -1; }
 extern "C" int32_t igd_hip_nfiles(const igd_hip_db *db) { return db ? db->nFiles : 0; }
 extern "C" int64_t igd_hip_resident_bytes(const igd_hip_db *db) { return db ? db->resident : 0; }
-extern "C" void igd_hip_free(void *p) { free(p); }
+// Enumeration results are returned in PINNED host memory (the D2H copy of ~16 bytes per overlap is
+// the slowest step of `-f`; pageable memory runs it at a fifth of the PCIe rate).  Pinning is
+// expensive, so one released buffer is kept for the next call.
+static void *g_pinCache = nullptr;
+static size_t g_pinCacheBytes = 0;
+static void *pinned_take(size_t bytes, size_t *got)
+{
+    if (g_pinCache && g_pinCacheBytes >= bytes) {
+        void *p = g_pinCache;
+        *got = g_pinCacheBytes;
+        g_pinCache = nullptr; g_pinCacheBytes = 0;
+        return p;
+    }
+    void *p = nullptr;
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipHostMalloc(&p, want + 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *got = want;
+    return p;
+}
+extern "C" void igd_hip_free(void *p)
+{
+    if (!p) return;
+    size_t *hdr = (size_t *)((char *)p - 64);            // size header in front of the payload
+    if (g_pinCache) {
+        if (g_pinCacheBytes >= hdr[0]) { (void)hipHostFree(hdr); return; }
+        (void)hipHostFree((char *)g_pinCache);
+    }
+    g_pinCache = hdr; g_pinCacheBytes = hdr[0];
+}
 extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_tiles"; }
 
 extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 {
     if (!d || !out || d->nbp <= 0 || d->nCtg < 0 || d->nFiles < 0 || d->nRecords < 0 ||
         (d->gType != 0 && d->gType != 1) || (d->nCtg > 0 && (!d->nTile || !d->nCnt)) ||
-        (d->nRecords > 0 && !d->records)) {
+        (d->nRecords > 0 && !d->records && d->fd < 0)) {
         snprintf(g_err, sizeof g_err, "igd_hip_open: bad descriptor");
         return IGD_HIP_ERR_ARG;
     }
@@ -1296,36 +1326,78 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         TRYHIP(hipMemcpy(db->d_chunkTile, chunkTile.data(), chunkTile.size() * 4, hipMemcpyHostToDevice));
         TRYHIP(hipMemcpy(db->d_chunkRec0, chunkRec0.data(), chunkRec0.size() * 4, hipMemcpyHostToDevice));
     }
-    // records: upload the AoS region in slices and transpose on the GPU
+    // records: the AoS region goes through two pinned staging buffers -- the CPU fills one
+    // (memcpy from the caller's memory, or pread from the .igd when desc->fd is used) while the
+    // previous one is copied to the GPU and transposed there (SoA) on the engine's stream.
     if (n > 0) {
         const size_t recBytes = d->gType == 1 ? 16 : 12;
-        const size_t slice = (size_t)1 << 24;            // records per slice (256 MiB of gdata_t)
-        void *d_aos = nullptr;
-        size_t sl = n < slice ? n : slice;
-        TRYHIP(hipMalloc(&d_aos, sl * recBytes));
-        for (size_t r0 = 0; r0 < n; r0 += slice) {
-            size_t m = n - r0 < slice ? n - r0 : slice;
-            hipError_t e = hipMemcpy(d_aos, (const char *)d->records + r0 * recBytes, m * recBytes,
-                                     hipMemcpyHostToDevice);
-            if (e == hipSuccess) {
-                int blocks = (int)((m + 255) / 256);
-                if (blocks > 256 * 32) blocks = 256 * 32;
-                if (d->gType == 1)
-                    k_aos_to_soa16<<<blocks, 256, 0, db->stream>>>((const int4 *)d_aos, (int64_t)m,
-                        db->d_start + r0, db->d_end + r0, db->d_idx + r0, db->d_value + r0);
-                else
-                    k_aos_to_soa12<<<blocks, 256, 0, db->stream>>>((const int32_t *)d_aos, (int64_t)m,
-                        db->d_start + r0, db->d_end + r0, db->d_idx + r0);
-                e = hipStreamSynchronize(db->stream);
-            }
-            if (e != hipSuccess) {
-                set_err("upload/transpose", e, __FILE__, __LINE__);
-                (void)hipFree(d_aos);
-                igd_hip_close(db);
-                return IGD_HIP_ERR_DEVICE;
-            }
+        const size_t slice = (size_t)1 << 22;            // records per stage (64 MiB of gdata_t)
+        int nthr = (int)std::thread::hardware_concurrency();
+        nthr = nthr < 1 ? 1 : (nthr > 8 ? 8 : nthr);
+        const size_t sl = n < slice ? n : slice;
+        void *d_aos[2] = {nullptr, nullptr}, *h_pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipMalloc(&d_aos[k], sl * recBytes);
+            if (e == hipSuccess) e = hipHostMalloc(&h_pin[k], sl * recBytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
         }
-        (void)hipFree(d_aos);
+        bool ioerr = false;
+        int k = 0;
+        for (size_t r0 = 0; r0 < n && e == hipSuccess && !ioerr; r0 += slice, k ^= 1) {
+            const size_t m = n - r0 < slice ? n - r0 : slice;
+            if (r0 >= 2 * slice) e = hipEventSynchronize(ev[k]);    // this stage's previous copy is done
+            if (e != hipSuccess) break;
+            {   // fill the stage with a few threads: one core copies page cache at only ~4 GB/s
+                const size_t bytes = m * recBytes;
+                const size_t part = ((bytes / nthr) + 4095) & ~(size_t)4095;
+                std::vector<std::thread> th;
+                std::vector<int> bad((size_t)nthr, 0);
+                for (int t = 0; t < nthr; t++) {
+                    const size_t b0 = (size_t)t * part;
+                    if (b0 >= bytes) break;
+                    const size_t b1 = b0 + part < bytes ? b0 + part : bytes;
+                    char *dst = (char *)h_pin[k];
+                    auto job = [=, &bad]() {
+                        if (d->records) { memcpy(dst + b0, (const char *)d->records + r0 * recBytes + b0, b1 - b0); return; }
+                        size_t done = b0;
+                        while (done < b1) {
+                            ssize_t got = pread(d->fd, dst + done, b1 - done, (off_t)(d->fd_offset + (int64_t)(r0 * recBytes + done)));
+                            if (got <= 0) { bad[(size_t)t] = 1; return; }
+                            done += (size_t)got;
+                        }
+                    };
+                    if (t + 1 < nthr && b1 < bytes) th.emplace_back(job); else job();
+                }
+                for (auto &x : th) x.join();
+                for (int b : bad) ioerr = ioerr || b;
+                if (ioerr) break;
+            }
+            e = hipMemcpyAsync(d_aos[k], h_pin[k], m * recBytes, hipMemcpyHostToDevice, db->stream);
+            if (e != hipSuccess) break;
+            int blocks = (int)((m + 255) / 256);
+            if (blocks > 256 * 32) blocks = 256 * 32;
+            if (d->gType == 1)
+                k_aos_to_soa16<<<blocks, 256, 0, db->stream>>>((const int4 *)d_aos[k], (int64_t)m,
+                    db->d_start + r0, db->d_end + r0, db->d_idx + r0, db->d_value + r0);
+            else
+                k_aos_to_soa12<<<blocks, 256, 0, db->stream>>>((const int32_t *)d_aos[k], (int64_t)m,
+                    db->d_start + r0, db->d_end + r0, db->d_idx + r0);
+            e = hipEventRecord(ev[k], db->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+        for (int q = 0; q < 2; q++) {
+            if (d_aos[q]) (void)hipFree(d_aos[q]);
+            if (h_pin[q]) (void)hipHostFree(h_pin[q]);
+            if (ev[q]) (void)hipEventDestroy(ev[q]);
+        }
+        if (e != hipSuccess || ioerr) {
+            if (ioerr) snprintf(g_err, sizeof g_err, "igd_hip_open: short read of the tile region");
+            else set_err("upload/transpose", e, __FILE__, __LINE__);
+            igd_hip_close(db);
+            return ioerr ? IGD_HIP_ERR_ARG : IGD_HIP_ERR_DEVICE;
+        }
         TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
         k_idx_range<<<256 * 8, 256, 0, db->stream>>>(db->d_idx, (int64_t)n, d->nFiles, db->d_ctl);
         int32_t bad = 0;
@@ -1675,11 +1747,14 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
         if ((rc = dalloc(&d_out, (size_t)tot, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
         igd_enum_tiles<true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
             db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_out);
-        igd_hip_hit *h = (igd_hip_hit *)malloc((size_t)tot * sizeof(igd_hip_hit));
-        if (!h) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_enumerate: host malloc"); return IGD_HIP_ERR_NOMEM; }
+        size_t got = 0;
+        size_t *hdr = (size_t *)pinned_take((size_t)tot * sizeof(igd_hip_hit), &got);
+        if (!hdr) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_enumerate: pinned host allocation failed"); return IGD_HIP_ERR_NOMEM; }
+        hdr[0] = got;
+        igd_hip_hit *h = (igd_hip_hit *)((char *)hdr + 64);
         hipError_t e = hipMemcpyAsync(h, d_out, (size_t)tot * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { free(h); set_err("enumerate fill", e, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; }
+        if (e != hipSuccess) { igd_hip_free(h); set_err("enumerate fill", e, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; }
         *out = h;
     }
 #undef EH

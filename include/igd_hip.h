@@ -50,8 +50,10 @@ typedef struct {
     int32_t nFiles;           /* length of hits[] (from _index.tsv)                          */
     const int32_t *nTile;     /* [nCtg]                                                     */
     const int32_t *nCnt;      /* contig-major, sum(nTile) entries (file order)               */
-    const void *records;      /* host pointer: all tile records in file order (AoS)          */
+    const void *records;      /* host pointer: all tile records in file order (AoS), or NULL: */
     int64_t nRecords;         /* = sum(nCnt)                                                */
+    int     fd;               /* records == NULL: read them from this descriptor ...         */
+    int64_t fd_offset;        /* ... starting at this byte offset (header size of the .igd)  */
 } igd_hip_desc;
 
 /* One emitted overlap of the `-f` path: query number (position in the batch), then the
