@@ -55,7 +55,9 @@
 #define IGD_SCAN_ITEMS 16                    // elements per thread in the tile scan
 #define IGD_SCAN_BLOCK 256
 #define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
-#define IGD_REDUCE_GROUPS 32
+#ifndef IGD_REDUCE_GROUPS
+#define IGD_REDUCE_GROUPS 128
+#endif
 #define IGD_LDS_HITS_MAX_BYTES (128 * 1024)
 
 typedef unsigned long long u64;
@@ -842,8 +844,8 @@ __global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs 
 // wave per listed query walks its tiles on the EXACT arrays, 6 slots at a time, and adds
 // straight into the caller's global hits[] (and the batch total).  Rare by construction.
 template <bool USE_V>
-__global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const int2 *__restrict__ fixList,
-                                                    const int2 *__restrict__ longList)
+__device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
+                                                const int2 *__restrict__ longList, int gwave, int nwaves)
 {
     const bool uns = __builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch;
     if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
@@ -851,8 +853,6 @@ __global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const
     const int2 *list = sortedPath ? fixList : longList;
     const int nList = __builtin_amdgcn_readfirstlane(a.ctl[(sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1)]);
     const int lane = threadIdx.x & 63;
-    const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * (blockDim.x >> 6);
     u64 found = 0;
     for (int li = gwave; li < nList; li += nwaves) {
         const int2 ent = list[li];
@@ -898,10 +898,21 @@ __global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const
     if (a.total && lane == 0 && found) atomicAdd(a.total, found);
 }
 
+template <bool USE_V>
+__global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const int2 *__restrict__ fixList,
+                                                    const int2 *__restrict__ longList)
+{
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    exact_walk_body<USE_V>(db, a, fixList, longList, gwave, gridDim.x * (blockDim.x >> 6));
+}
+
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
+template <bool USE_V>
 __global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ slab, int rows, int nFiles,
                                                       u64 *__restrict__ hits, u64 *__restrict__ total,
-                                                      const int32_t *__restrict__ ctl, int brokenIf)
+                                                      const int32_t *__restrict__ ctl, int brokenIf, DbView db,
+                                                      ScanArgs wa, const int2 *__restrict__ fixList,
+                                                      const int2 *__restrict__ longList)
 {
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
@@ -921,6 +932,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ sl
             if (t) atomicAdd(total, t);
         }
     }
+    // ... and the batch's exact-walk list (normally empty) rides in the same launch
+    const int nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int gwave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    exact_walk_body<USE_V>(db, wa, fixList, longList, gwave, nb * 4);
 }
 
 // without LDS counters the batch total is the growth of sum(hits): measured around the launch
@@ -1582,15 +1598,17 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         a.out = db->d_slab;
         launch_scan_any<true>(db, a, useV, packed, st);
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
-        {   // the listed exact walks add straight into the caller's hits[] and total
+        {   // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
-            if (useV) k_exact_walk<true><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
-            else k_exact_walk<false><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+            dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
+            if (useV)
+                k_reduce_slabs<true><<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                                                         db->d_ctl, mode == 1 ? db->epoch : 0, db->v, w, db->d_fix, db->d_long);
+            else
+                k_reduce_slabs<false><<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                                                          db->d_ctl, mode == 1 ? db->epoch : 0, db->v, w, db->d_fix, db->d_long);
         }
-        dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
-        k_reduce_slabs<<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                           db->d_ctl, mode == 1 ? db->epoch : 0);
     } else {
         a.out = (u64 *)d_hits;
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
