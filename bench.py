@@ -155,8 +155,9 @@ def main():
         args.grouping = "auto" if args.shuffled else "sorted"
     gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
 
+    gflags |= 8          # IGD_HIP_FLAG_ZERO_FIRST: each step's hits[] starts from zero (the API adds)
+
     def step():
-        d_hits.zero_()
         db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
                       v=args.v, stream=stream, flags=gflags)
         allreduce_hits(d_hits)              # the one collective of the path (no-op at N=1)

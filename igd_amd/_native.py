@@ -90,6 +90,7 @@ IGD_HIP_NO_VALUE_FILTER = -(2 ** 31)
 IGD_HIP_FLAG_SORTED = 1
 IGD_HIP_FLAG_BUCKET = 2
 IGD_HIP_FLAG_EXACT = 4
+IGD_HIP_FLAG_ZERO_FIRST = 8
 IGD_HIP_ERR_UNSORTED = -4
 
 _hip = None

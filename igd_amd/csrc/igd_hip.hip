@@ -276,9 +276,12 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
                                                       int packed, int32_t *__restrict__ firstQ,
-                                                      int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch)
+                                                      int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
+                                                      u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST
+    if (zeroTotal && i == 0) *zeroTotal = 0;
     if (i == 0) {                                           // next batch's list counters
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
@@ -357,9 +360,11 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
                               const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                               int nq, int rule, int packed, int32_t *__restrict__ pairCnt,
                               int2 *__restrict__ longList, int32_t *__restrict__ ctl,
-                              int gate, int epoch)
+                              int gate, int epoch, u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST (bucket-only mode)
+    if (zeroTotal && i == 0) *zeroTotal = 0;
     if (gate == 0 && i == 0) {
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
@@ -1527,12 +1532,14 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
 // counts in d_pairN, the range ends in d_pairPos, and d_pairCnt zeroed again.
 template <bool WITH_Q>
 static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
-                         int nq, int rule, int gate, int packed, hipStream_t st)
+                         int nq, int rule, int gate, int packed, hipStream_t st, u64 *zeroHits = nullptr,
+                         u64 *zeroTotal = nullptr)
 {
     const int nT = db->nT;
     const int qb = (nq + 255) / 256;
-    k_count_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairCnt, db->d_long, db->d_ctl,
-                                      gate, db->epoch);
+    const int qbz = zeroHits ? ((nq > db->nFiles ? nq : db->nFiles) + 255) / 256 : qb;
+    k_count_pairs<<<qbz, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairCnt, db->d_long, db->d_ctl,
+                                      gate, db->epoch, zeroHits, zeroTotal);
     const int sb = (nT + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE;
     k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_ctl, gate);
     k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos, db->d_pairN,
@@ -1569,9 +1576,16 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         snprintf(g_err, sizeof g_err, "igd_hip_search_dev: bad argument");
         return IGD_HIP_ERR_ARG;
     }
-    if (nq == 0 || db->nT == 0 || db->nFiles == 0) return IGD_HIP_OK;
+    if (db->nFiles == 0) return IGD_HIP_OK;
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = stream ? (hipStream_t)stream : db->stream;
+    if (nq == 0 || db->nT == 0) {
+        if (flags & IGD_HIP_FLAG_ZERO_FIRST) {
+            HIPCHK(hipMemsetAsync(d_hits, 0, (size_t)db->nFiles * 8, st));
+            if (d_total) HIPCHK(hipMemsetAsync(d_total, 0, 8, st));
+        }
+        return IGD_HIP_OK;
+    }
     int rc = ensure_workspace(db, nq, 8);
     if (rc != IGD_HIP_OK) return rc;
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
@@ -1581,11 +1595,16 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     int slot = -1;
     if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
+    // IGD_HIP_FLAG_ZERO_FIRST: the first kernel of the batch clears hits[] (and total)
+    u64 *zh = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_hits : nullptr;
+    u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
+    const int gridQ = (int)(((nq > db->nFiles ? nq : db->nFiles) + 255) / 256);
     if (mode != 2)
-        k_query_bounds<<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch);
+        k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
+                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt);
     if (mode != 1) {
-        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st);
+        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+                                  mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         if (rc != IGD_HIP_OK) return rc;
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));

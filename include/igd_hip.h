@@ -100,6 +100,9 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  * (6 bytes per record) that the counting kernels read when the tile width is <= 32768 and
  * nFiles <= 65536.  IGD_HIP_FLAG_EXACT makes a call read the exact arrays instead (tests). */
 #define IGD_HIP_FLAG_EXACT 4
+/* igd_hip_search_dev only: d_hits[] (and d_total) are cleared by the batch's first kernel before the
+ * counts are added -- saves the caller a separate memset when it does not accumulate. */
+#define IGD_HIP_FLAG_ZERO_FIRST 8
 
 /* Host-buffer search.  ichr[i] = contig index (as get_id returns; <0 or >=nCtg: skipped).
  * hits[0..nFiles) is caller-allocated and is ADDED to (reference semantics :491).

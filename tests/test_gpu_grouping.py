@@ -98,6 +98,18 @@ def test_device_api_sorted_promise(workdir):
                               tot.data_ptr(), v=0, stream=stream.cuda_stream, flags=0)
                 db.sync(stream.cuda_stream)
                 np.testing.assert_array_equal(hits.cpu().numpy(), orc.search(a, b, c, 0)[0])
+                # the API adds ... unless IGD_HIP_FLAG_ZERO_FIRST (8) asks the batch to clear first
+                for fl in (0, 2):
+                    db.search_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(a), hits.data_ptr(),
+                                  tot.data_ptr(), v=0, stream=stream.cuda_stream, flags=fl)
+                db.sync(stream.cuda_stream)
+                np.testing.assert_array_equal(hits.cpu().numpy(), 3 * orc.search(a, b, c, 0)[0])
+                for fl in (8, 8 | 2):
+                    db.search_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(a), hits.data_ptr(),
+                                  tot.data_ptr(), v=0, stream=stream.cuda_stream, flags=fl)
+                    db.sync(stream.cuda_stream)
+                    np.testing.assert_array_equal(hits.cpu().numpy(), orc.search(a, b, c, 0)[0])
+                    assert int(tot.item()) == orc.search(a, b, c, 0)[1]
     finally:
         db.close()
         orc.close()
