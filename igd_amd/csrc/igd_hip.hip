@@ -47,10 +47,14 @@
 #include "igd_hip.h"
 
 #define IGD_WAVE 64
+#ifndef IGD_SLOTS
 #define IGD_SLOTS 5                          // register slots per array per lane
+#endif
 #define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (320)
 #define IGD_SHORT_TILES 4                    // queries spanning more tiles take the long path
-#define IGD_WG 512                           // threads per scan workgroup (8 waves)
+#ifndef IGD_WG
+#define IGD_WG 1024                          // threads per scan workgroup (16 waves; 2 workgroups per CU)
+#endif
 #define IGD_MAX_BATCH (1ll << 24)            // queries per device batch
 #define IGD_SCAN_ITEMS 16                    // elements per thread in the tile scan
 #define IGD_SCAN_BLOCK 256
@@ -1440,7 +1444,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     db->ldsBytes = (int)((size_t)d->nFiles * 8);
     db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
-    int perCU = 4;                                       // 4 x 512 threads = 32 waves/CU
+    int perCU = 2048 / IGD_WG;                           // 32 waves per CU
+    if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
     if (db->ldsHits && db->ldsBytes > 0) {
         int fit = (160 * 1024) / (db->ldsBytes + 256);
         if (fit < 1) fit = 1;

@@ -18,3 +18,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "ref" in item.keywords and not have_ref():
             item.add_marker(skip_ref)
+
+
+def pytest_sessionstart(session):
+    """Build the native libraries / oracle when the tree was copied without them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    need = [os.path.join(root, "igd_amd", "lib", n) for n in
+            ("libigd_hip.so", "libigd.so", "libigd_py.so", "libigdr.so", "libigd_synth.so")]
+    need += [os.path.join(root, "bin", "igd"), os.path.join(root, "bin", "igd_synth"),
+             os.path.join(root, "oracle", "_build", "liboracle.so"), os.path.join(root, "oracle", "_build", "igd_oracle")]
+    if not all(os.path.exists(p) for p in need):
+        subprocess.check_call(["make", "-s", "-C", root, "all"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
