@@ -31,24 +31,24 @@ CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_create_min.c
 CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create_min.h include/igd_hip.h
 
 $(LIB)/libigd.so: $(SRC)/igd_cli_abi.c $(CORE_SRC) $(CORE_HDR) include/igd_search.h include/igd_base.h $(LIB)/libigd_hip.so
-	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_cli_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz $(RPATH)
+	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_cli_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
 $(LIB)/libigd_py.so: $(SRC)/igd_py_abi.c $(CORE_SRC) $(CORE_HDR) include/igd_py_abi.h $(LIB)/libigd_hip.so
-	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_py_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz $(RPATH)
+	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_py_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
 # R flavour: the .C / plain-C entry points always build; the .Call (SEXP) ones need R's headers
 R_INC := $(shell R RHOME >/dev/null 2>&1 && echo "-DIGDR_HAVE_R -I`R RHOME`/include")
 $(LIB)/libigdr.so: $(SRC)/igdr_abi.c $(CORE_SRC) $(CORE_HDR) include/igdr_abi.h $(LIB)/libigd_hip.so
-	$(CC) $(CFLAGS) $(INC) $(R_INC) -shared -o $@ $(SRC)/igdr_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz $(RPATH)
+	$(CC) $(CFLAGS) $(INC) $(R_INC) -shared -o $@ $(SRC)/igdr_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
 $(LIB)/libigd_synth.so: tools/igd_synth.c $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so
-	$(CC) $(CFLAGS) $(INC) -shared -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz $(RPATH)
+	$(CC) $(CFLAGS) $(INC) -shared -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
 bin/igd: $(SRC)/igd_main.c $(LIB)/libigd.so | bin
 	$(CC) $(CFLAGS) $(INC) -o $@ $(SRC)/igd_main.c -L$(LIB) -ligd -ligd_hip -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
 
 bin/igd_synth: tools/igd_synth.c $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so | bin
-	$(CC) $(CFLAGS) $(INC) -DIGD_SYNTH_MAIN -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
+	$(CC) $(CFLAGS) $(INC) -DIGD_SYNTH_MAIN -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
 
 oracle:
 	$(MAKE) -C oracle

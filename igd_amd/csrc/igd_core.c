@@ -320,9 +320,173 @@ void igdc_queries_free(igdc_queries *q)
     memset(q, 0, sizeof *q);
 }
 
+/* ---------------------------------------------------------------------------------------
+ * Query ingest.  Plain-text BED files are mapped and parsed by several
+ * threads, each on a newline-aligned slice, without modifying the text; the slices' results
+ * are concatenated in file order, so the accepted (contig,start,end) list is exactly what the
+ * sequential reader (and the reference's ks_getuntil + parse_bed loop) produces.  gzip input
+ * keeps the sequential path (inflate is serial). */
+#include <pthread.h>
+#include <ctype.h>
+
+/* atol() of the field [p,end): optional leading white space, optional sign, digits; saturates
+ * like strtol; then narrowed to int32 the way `int32_t st = atol(..)` narrows. */
+static int32_t field_atol32(const char *p, const char *end)
+{
+    while (p < end && isspace((unsigned char)*p)) p++;
+    int neg = 0;
+    if (p < end && (*p == '+' || *p == '-')) { neg = (*p == '-'); p++; }
+    unsigned long long v = 0;
+    int sat = 0;
+    for (; p < end && *p >= '0' && *p <= '9'; p++) {
+        if (v > (0x7fffffffffffffffULL - (unsigned)(*p - '0')) / 10) sat = 1;
+        if (!sat) v = v * 10 + (unsigned)(*p - '0');
+    }
+    long long r;
+    if (sat) r = neg ? (long long)(-0x7fffffffffffffffLL - 1) : 0x7fffffffffffffffLL;
+    else r = neg ? -(long long)v : (long long)v;
+    return (int32_t)r;
+}
+
+static int32_t get_id_n(const igdc_db *db, const char *s, size_t len)
+{
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < len; i++) h = (h ^ (unsigned char)s[i]) * 16777619u;
+    uint32_t p = h & (uint32_t)(db->dictCap - 1);
+    for (;;) {
+        int32_t c = db->dict[p];
+        if (c < 0) return -1;
+        if (strlen(db->cName[c]) == len && memcmp(db->cName[c], s, len) == 0) return c;
+        p = (p + 1) & (uint32_t)(db->dictCap - 1);
+    }
+}
+
+/* one line [s,e) (no '\n'); same accept rule as igdc_parse_bed + dictionary lookup */
+static void ingest_line(const igdc_db *db, const char *s, const char *e, int require_chr, igdc_queries *q)
+{
+    if (e - s > 1 && e[-1] == '\r') e--;                    /* src/kseq.h:127 */
+    const char *nul = (const char *)memchr(s, '\0', (size_t)(e - s));
+    if (nul) e = nul;                                        /* C-string semantics of the reference */
+    const char *f1 = (const char *)memchr(s, '\t', (size_t)(e - s));
+    if (!f1) return;
+    const char *f2 = (const char *)memchr(f1 + 1, '\t', (size_t)(e - f1 - 1));
+    if (!f2) return;
+    const char *f3 = (const char *)memchr(f2 + 1, '\t', (size_t)(e - f2 - 1));
+    if (!f3) f3 = e;
+    const int32_t st = field_atol32(f1 + 1, f2), en = field_atol32(f2 + 1, f3);
+    const size_t nl = (size_t)(f1 - s);
+    if (require_chr) {
+        if (!(nl >= 3 && s[0] == 'c' && s[1] == 'h' && s[2] == 'r' && nl < 40 && en > 0)) {
+            /* a name shorter than 3 chars: the reference reads ctg[1], ctg[2] past a NUL only when
+             * the earlier ones matched; "c", "ch" fail the prefix test like here */
+            return;
+        }
+    }
+    const int32_t id = get_id_n(db, s, nl);
+    if (id >= 0) igdc_queries_push(q, id, st, en);
+}
+
+typedef struct {
+    const igdc_db *db;
+    const char *beg, *end;
+    int require_chr;
+    igdc_queries q;
+} ingest_job;
+
+static void *ingest_run(void *arg)
+{
+    ingest_job *j = (ingest_job *)arg;
+    const char *p = j->beg;
+    while (p < j->end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(j->end - p));
+        const char *le = nl ? nl : j->end;
+        ingest_line(j->db, p, le, j->require_chr, &j->q);
+        p = le + 1;
+    }
+    return NULL;
+}
+
+static int read_queries_text_parallel(const igdc_db *db, const char *map, size_t size, int require_chr,
+                                      igdc_queries *out)
+{
+    int nthr = (int)sysconf(_SC_NPROCESSORS_ONLN);
+    const char *env = getenv("IGD_PARSE_THREADS");
+    if (env && *env) nthr = atoi(env);
+    if (nthr < 1) nthr = 1;
+    if (nthr > 16) nthr = 16;
+    if (size < ((size_t)1 << 20)) nthr = 1;
+    ingest_job job[16];
+    pthread_t th[16];
+    const char *end = map + size;
+    const char *cut = map;
+    int n = 0;
+    for (int t = 0; t < nthr && cut < end; t++) {
+        const char *b = cut;
+        const char *e = end;
+        if (t + 1 < nthr) {
+            const char *guess = map + (size / (size_t)nthr) * (size_t)(t + 1);
+            if (guess < b) guess = b;
+            const char *nl = guess < end ? (const char *)memchr(guess, '\n', (size_t)(end - guess)) : NULL;
+            e = nl ? nl + 1 : end;
+        }
+        memset(&job[n], 0, sizeof job[n]);
+        job[n].db = db; job[n].beg = b; job[n].end = e; job[n].require_chr = require_chr;
+        cut = e;
+        n++;
+    }
+    for (int t = 1; t < n; t++)
+        if (pthread_create(&th[t], NULL, ingest_run, &job[t]) != 0) { th[t] = 0; ingest_run(&job[t]); }
+    if (n > 0) ingest_run(&job[0]);
+    for (int t = 1; t < n; t++)
+        if (th[t]) pthread_join(th[t], NULL);
+    int64_t total = 0;
+    for (int t = 0; t < n; t++) total += job[t].q.n;
+    memset(out, 0, sizeof *out);
+    if (n == 1) { *out = job[0].q; return 0; }
+    out->cap = total > 0 ? total : 1;
+    out->ichr = (int32_t *)malloc(sizeof(int32_t) * (size_t)out->cap);
+    out->qs = (int32_t *)malloc(sizeof(int32_t) * (size_t)out->cap);
+    out->qe = (int32_t *)malloc(sizeof(int32_t) * (size_t)out->cap);
+    if (!out->ichr || !out->qs || !out->qe) return -1;
+    for (int t = 0; t < n; t++) {
+        igdc_queries *q = &job[t].q;
+        if (q->n) {
+            /* order across the seam, then inside the slice */
+            if (out->n > 0 && (q->ichr[0] < out->ichr[out->n - 1] ||
+                               (q->ichr[0] == out->ichr[out->n - 1] && q->qs[0] < out->qs[out->n - 1])))
+                out->unsorted = 1;
+            memcpy(out->ichr + out->n, q->ichr, sizeof(int32_t) * (size_t)q->n);
+            memcpy(out->qs + out->n, q->qs, sizeof(int32_t) * (size_t)q->n);
+            memcpy(out->qe + out->n, q->qe, sizeof(int32_t) * (size_t)q->n);
+            out->n += q->n;
+        }
+        out->unsorted |= q->unsorted;
+        igdc_queries_free(q);
+    }
+    return 0;
+}
+
 int igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out)
 {
     memset(out, 0, sizeof *out);
+    /* plain text -> parallel path; gzip (magic 1f 8b) or anything unmappable -> sequential */
+    int fd = open(qfile, O_RDONLY);
+    if (fd >= 0) {
+        struct stat st;
+        unsigned char magic[2] = {0, 0};
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0 && pread(fd, magic, 2, 0) == 2 &&
+            !(magic[0] == 0x1f && magic[1] == 0x8b) && !getenv("IGD_PARSE_SEQUENTIAL")) {
+            void *map = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map != MAP_FAILED) {
+                (void)madvise(map, (size_t)st.st_size, MADV_SEQUENTIAL);
+                int rc = read_queries_text_parallel(db, (const char *)map, (size_t)st.st_size, require_chr, out);
+                munmap(map, (size_t)st.st_size);
+                close(fd);
+                return rc;
+            }
+        }
+        close(fd);
+    }
     igdc_lines *r = igdc_lines_open(qfile);
     if (!r) return -1;
     char *line;

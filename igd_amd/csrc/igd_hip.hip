@@ -42,6 +42,7 @@
 #include <limits.h>
 #include <vector>
 #include <thread>
+#include <time.h>
 #include <unistd.h>
 
 #include "igd_hip.h"
@@ -136,8 +137,6 @@ struct DbView {
     const int32_t *tileBd;                      // [nT] tile start coordinate j*nbp (INT_MIN for j==0)
     const int32_t *ctgBase;                     // [nCtg] global tile id of the contig's tile 0
     const int32_t *ctgNTile;                    // [nCtg]
-    const int32_t *chunkTile;                   // [nChunks] tile of each chunk
-    const int32_t *chunkRec0;                   // [nChunks] first record (within the tile)
 };
 
 struct igd_hip_db {
@@ -152,11 +151,13 @@ struct igd_hip_db {
     uint32_t *d_pxv;
     bool packed, packedV;         // compact image usable (nbp<=32768, nFiles<=65536) / values fit int16
     int64_t *d_tileOff;
-    int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_chunkTile, *d_chunkRec0;
+    int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile;
     Unit *d_units;
     int32_t nUnits;
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
+    char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
+    size_t arenaSize, arenaUsed;
     int32_t epoch;                // batch counter: device-side flags are compared against it
     int32_t promised;             // epoch of the last batch launched under IGD_HIP_FLAG_SORTED (0: none)
     // per-batch workspace
@@ -1165,11 +1166,23 @@ __global__ void k_batch_stats(DbView db, const int32_t *__restrict__ ichr,
 
 // ==========================================================================================
 // host side
+static thread_local igd_hip_db *t_arenaOwner = nullptr;   // set while igd_hip_open builds the image
+
 template <typename T>
 static int dalloc(T **p, size_t n, int64_t *acct)
 {
     *p = nullptr;
     if (n == 0) n = 1;
+    if (t_arenaOwner && t_arenaOwner->arena) {
+        igd_hip_db *o = t_arenaOwner;
+        const size_t at = (o->arenaUsed + 255) & ~(size_t)255, bytes = n * sizeof(T);
+        if (at + bytes <= o->arenaSize) {
+            *p = (T *)(o->arena + at);
+            o->arenaUsed = at + bytes;
+            if (acct) *acct += (int64_t)bytes;
+            return IGD_HIP_OK;
+        }
+    }
     hipError_t e = hipMalloc((void **)p, n * sizeof(T));
     if (e != hipSuccess) {
         set_err("hipMalloc", e, __FILE__, __LINE__);
@@ -1182,14 +1195,16 @@ static int dalloc(T **p, size_t n, int64_t *acct)
 extern "C" void igd_hip_close(igd_hip_db *db)
 {
     if (!db) return;
+    if (t_arenaOwner == db) t_arenaOwner = nullptr;
     (void)hipSetDevice(db->device);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
-                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_chunkTile, db->d_chunkRec0,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
+    if (db->arena) (void)hipFree(db->arena);
     for (hipEvent_t e : db->ev) (void)hipEventDestroy(e);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
@@ -1229,8 +1244,19 @@ extern "C" void igd_hip_free(void *p)
 }
 extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_tiles"; }
 
+static double wall_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+#define OPEN_PHASE(name) do { if (tim) { double t_ = wall_s(); fprintf(stderr, "[igd timing]   open: %-22s %8.1f ms\n", name, 1e3 * (t_ - t0)); t0 = t_; } } while (0)
+
 extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 {
+    const char *tenv = getenv("IGD_TIMING");
+    const bool tim = tenv && *tenv && *tenv != '0';
+    double t0 = wall_s();
     if (!d || !out || d->nbp <= 0 || d->nCtg < 0 || d->nFiles < 0 || d->nRecords < 0 ||
         (d->gType != 0 && d->gType != 1) || (d->nCtg > 0 && (!d->nTile || !d->nCnt)) ||
         (d->nRecords > 0 && !d->records && d->fd < 0)) {
@@ -1247,6 +1273,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         return IGD_HIP_ERR_ARG;
     }
     HIPCHK(hipSetDevice(device));
+    OPEN_PHASE("HIP runtime init");
     igd_hip_db *db = new igd_hip_db();   // value-initialised: every field zero
     db->device = device;
     db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
@@ -1265,7 +1292,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     db->nT = (int32_t)nT;
     std::vector<int64_t> tileOff((size_t)nT + 1);
     std::vector<int32_t> tileCnt((size_t)nT + 1), tileBd((size_t)nT + 1), ctgBase((size_t)d->nCtg + 1),
-        ctgNTile((size_t)d->nCtg + 1), chunkTile, chunkRec0;
+        ctgNTile((size_t)d->nCtg + 1);
     std::vector<Unit> units;
     int64_t off = 0;
     int32_t maxIdxCheck = 0;
@@ -1282,10 +1309,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                 tileCnt[t] = cnt;
                 // tile start coordinate; computed with wrap like `bd` at src/igd_search.c:496,529
                 tileBd[t] = (j == 0) ? INT_MIN : (int32_t)((uint32_t)d->nbp * (uint32_t)j);
-                for (int32_t r0 = 0; r0 < cnt; r0 += IGD_CHUNK) {
-                    chunkTile.push_back((int32_t)t);
-                    chunkRec0.push_back(r0);
-                }
                 for (int32_t r0 = 0; r0 < cnt || r0 == 0; r0 += IGD_CHUNK) {
                     Unit u;
                     u.off = off + r0;
@@ -1311,7 +1334,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         delete db;
         return IGD_HIP_ERR_ARG;
     }
-    db->nChunks = (int32_t)chunkTile.size();
+    db->nChunks = 0;
     db->nUnits = (int32_t)units.size();
 
     int rc;
@@ -1320,6 +1343,30 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); igd_hip_close(db); return IGD_HIP_ERR_DEVICE; } } while (0)
     TRYHIP(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
     size_t n = (size_t)d->nRecords;
+    {   // launch geometry first: the slab is part of the arena
+        hipDeviceProp_t prop0;
+        TRYHIP(hipGetDeviceProperties(&prop0, device));
+        int cus = prop0.multiProcessorCount > 0 ? prop0.multiProcessorCount : 256;
+        db->ldsBytes = (int)((size_t)d->nFiles * 8);
+        db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
+        int perCU = 2048 / IGD_WG;                       // 32 waves per CU
+        if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
+        if (db->ldsHits && db->ldsBytes > 0) {
+            int fit = (160 * 1024) / (db->ldsBytes + 256);
+            if (fit < 1) fit = 1;
+            if (fit < perCU) perCU = fit;
+        }
+        if (perCU < 1) perCU = 1;
+        db->grid = cus * perCU;
+        const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
+        const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 64 * ((size_t)nT + 2) + sizeof(Unit) * units.size() +
+                       slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
+        db->arena = nullptr;
+        if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
+        else db->arena = nullptr;                        // fall back to individual allocations
+        t_arenaOwner = db;
+    }
     TRY(dalloc(&db->d_start, n, acct));
     TRY(dalloc(&db->d_end, n, acct));
     TRY(dalloc(&db->d_idx, n, acct));
@@ -1329,8 +1376,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_tileBd, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_ctgBase, (size_t)d->nCtg + 1, acct));
     TRY(dalloc(&db->d_ctgNTile, (size_t)d->nCtg + 1, acct));
-    TRY(dalloc(&db->d_chunkTile, chunkTile.size(), acct));
-    TRY(dalloc(&db->d_chunkRec0, chunkRec0.size(), acct));
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -1347,16 +1392,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     if (!units.empty())
         TRYHIP(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(Unit), hipMemcpyHostToDevice));
-    if (!chunkTile.empty()) {
-        TRYHIP(hipMemcpy(db->d_chunkTile, chunkTile.data(), chunkTile.size() * 4, hipMemcpyHostToDevice));
-        TRYHIP(hipMemcpy(db->d_chunkRec0, chunkRec0.data(), chunkRec0.size() * 4, hipMemcpyHostToDevice));
-    }
+    OPEN_PHASE("tables + hipMalloc");
     // records: the AoS region goes through two pinned staging buffers -- the CPU fills one
     // (memcpy from the caller's memory, or pread from the .igd when desc->fd is used) while the
     // previous one is copied to the GPU and transposed there (SoA) on the engine's stream.
     if (n > 0) {
         const size_t recBytes = d->gType == 1 ? 16 : 12;
-        const size_t slice = (size_t)1 << 22;            // records per stage (64 MiB of gdata_t)
+        const size_t slice = (size_t)1 << 20;            // records per stage (16 MiB of gdata_t)
         int nthr = (int)std::thread::hardware_concurrency();
         nthr = nthr < 1 ? 1 : (nthr > 8 ? 8 : nthr);
         const size_t sl = n < slice ? n : slice;
@@ -1370,6 +1412,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         bool ioerr = false;
         int k = 0;
+        OPEN_PHASE("staging buffers");
         for (size_t r0 = 0; r0 < n && e == hipSuccess && !ioerr; r0 += slice, k ^= 1) {
             const size_t m = n - r0 < slice ? n - r0 : slice;
             if (r0 >= 2 * slice) e = hipEventSynchronize(ev[k]);    // this stage's previous copy is done
@@ -1412,6 +1455,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             e = hipEventRecord(ev[k], db->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(db->stream);
+        OPEN_PHASE("read + upload + SoA");
         for (int q = 0; q < 2; q++) {
             if (d_aos[q]) (void)hipFree(d_aos[q]);
             if (h_pin[q]) (void)hipHostFree(h_pin[q]);
@@ -1438,20 +1482,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
     TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
 
-    // launch geometry of the scan kernel
-    hipDeviceProp_t prop;
-    TRYHIP(hipGetDeviceProperties(&prop, device));
-    int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    db->ldsBytes = (int)((size_t)d->nFiles * 8);
-    db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
-    int perCU = 2048 / IGD_WG;                           // 32 waves per CU
-    if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
-    if (db->ldsHits && db->ldsBytes > 0) {
-        int fit = (160 * 1024) / (db->ldsBytes + 256);
-        if (fit < 1) fit = 1;
-        if (fit < perCU) perCU = fit;
-    }
-    db->grid = cus * perCU;
+    // launch geometry of the scan kernel: computed above (db->grid, db->ldsBytes, db->ldsHits)
     if (db->ldsHits) {
         TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1), acct));
         if (db->ldsBytes > 64 * 1024) {
@@ -1475,7 +1506,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
     v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
     v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile;
-    v.chunkTile = db->d_chunkTile; v.chunkRec0 = db->d_chunkRec0;
+    OPEN_PHASE("idx check, slab");
     // compact image (see k_pack_units): needs tile-relative offsets and idx to fit 16 bits
     db->packed = db->nbp <= 32768 && db->nFiles <= 65536 && db->nRec > 0 && !getenv("IGD_HIP_NO_PACK");
     if (db->packed) {
@@ -1505,6 +1536,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         if (fl & 2) db->packed = false;          // a record outside its tile: exact arrays only
         v.pse = db->d_pse; v.px = db->d_px; v.pxv = db->d_pxv;
     }
+    OPEN_PHASE("compact image");
+    t_arenaOwner = nullptr;
     *out = db;
     return IGD_HIP_OK;
 }

@@ -85,6 +85,61 @@ def test_query_reader_matches_oracle_and_reference_rules(N):
     o.close()
 
 
+def test_parallel_ingest_equals_sequential_and_oracle(N):
+    """>1 MiB plain BED goes through the multi-threaded, non-mutating reader: it must accept
+    exactly the lines, in order, that the sequential reader / the oracle accept (incl. junk)."""
+    L = N.cli()
+    rng = random.Random(17)
+    d = short_tmpdir("igq")
+    try:
+        case = os.path.join(GOLDEN, "smallrand")
+        core = L.igdc_open(os.path.join(case, "db.igd").encode())
+        o = Oracle(os.path.join(case, "db.igd"), preload=False)
+        junk = ["track x", "#c", "chr1\t5", "1\t2\t3", "chr1\t7\t0", "chr2\t 12\t 99 \textra", "chrX\t+3\t9z", "",
+                "chr3\t99999999999\t5", "chr1\t-4\t88\r", "chr9\t1\t2", "chr1 1 2", "chr2\t1e3\t2000\t\t",
+                "chr1\t9223372036854775807\t9223372036854775808", "chr" + "a" * 37 + "\t1\t2", "c\t1\t2", "ch\t1\t2"]
+        for srt in (True, False):
+            rows = []
+            for _ in range(120000):
+                if rng.random() < 0.03:
+                    rows.append(rng.choice(junk))
+                else:
+                    c = rng.choice(["chr1", "chr2", "chr3", "chrX"])
+                    s0 = rng.randrange(0, 4000000)
+                    rows.append("%s\t%d\t%d" % (c, s0, s0 + rng.randint(1, 50000)))
+            if srt:
+                key = lambda r: (r.split("\t")[0], int(r.split("\t")[1])) if r.count("\t") == 2 and r.split("\t")[1].isdigit() else ("", 0)
+                rows.sort(key=key)
+            path = os.path.join(d, "q_%d.bed" % srt)
+            with open(path, "w") as f:
+                f.write("\n".join(rows))                 # no trailing newline
+            assert os.path.getsize(path) > (1 << 20)
+            want = o.read_queries(path)
+            res = {}
+            for mode in ("par", "seq", "par3"):
+                os.environ.pop("IGD_PARSE_SEQUENTIAL", None); os.environ.pop("IGD_PARSE_THREADS", None)
+                if mode == "seq": os.environ["IGD_PARSE_SEQUENTIAL"] = "1"
+                if mode == "par3": os.environ["IGD_PARSE_THREADS"] = "3"
+                for rule in (1, 0):
+                    qq = N.CoreQueries()
+                    assert L.igdc_read_queries(core, path.encode(), rule, C.byref(qq)) == 0
+                    res[(mode, rule)] = ([np.ctypeslib.as_array(p, shape=(qq.n,)).copy() for p in (qq.ichr, qq.qs, qq.qe)], qq.unsorted)
+                    L.igdc_queries_free(C.byref(qq))
+            os.environ.pop("IGD_PARSE_SEQUENTIAL", None); os.environ.pop("IGD_PARSE_THREADS", None)
+            for rule in (1, 0):
+                for mode in ("par", "par3"):
+                    for g, w in zip(res[(mode, rule)][0], res[("seq", rule)][0]):
+                        np.testing.assert_array_equal(g, w)
+                    assert bool(res[(mode, rule)][1]) == bool(res[("seq", rule)][1])
+            for g, w in zip(res[("par", 1)][0], want):
+                np.testing.assert_array_equal(g, w)
+            assert len(want[0]) > 100000
+        L.igdc_close(core)
+        o.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def test_parse_bed_line_fuzz(N):
     L = N.cli()
     lib = orc()
