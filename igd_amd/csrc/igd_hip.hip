@@ -1079,34 +1079,61 @@ __global__ void k_enum_qcount(const int32_t *__restrict__ pcount, const int64_t 
     qcount[i] = s;
 }
 
-// single-workgroup exclusive scan of int64 (nq <= 2^24: at most a few ms; the -f path is
-// bound by its output, not by this)
-__global__ __launch_bounds__(1024) void k_scan64(const int64_t *__restrict__ in, int n,
-                                                 int64_t *__restrict__ out /* n+1 */)
+// exclusive scan of int64 per-query counts -> qoff[0..n] (two kernels, like the tile scan)
+__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan64_sums(const int64_t *__restrict__ in, int n,
+                                                                int64_t *__restrict__ blockSums)
 {
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ int64_t red[IGD_SCAN_BLOCK / IGD_WAVE];
+    const int base = blockIdx.x * IGD_SCAN_TILE + threadIdx.x * IGD_SCAN_ITEMS;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++)
+        if (base + k < n) s += in[base + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + threadIdx.x;
-        int64_t v = i < n ? in[i] : 0;
-        int64_t inc = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            int64_t t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        int64_t pre = carry;
-        for (int k = 0; k < w; k++) pre += wsum[k];
-        if (i < n) out[i] = pre + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = pre + inc;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < IGD_SCAN_BLOCK / IGD_WAVE; w++) t += red[w];
+        blockSums[blockIdx.x] = t;
     }
-    if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan64_apply(const int64_t *__restrict__ in, int n,
+                                                                 const int64_t *__restrict__ blockSums,
+                                                                 int64_t *__restrict__ out /* n+1 */)
+{
+    __shared__ int64_t red[IGD_SCAN_BLOCK / IGD_WAVE];
+    __shared__ int64_t wsum[IGD_SCAN_BLOCK / IGD_WAVE];
+    int64_t pre = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += IGD_SCAN_BLOCK) pre += blockSums[b];
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_down(pre, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pre;
+    const int base = blockIdx.x * IGD_SCAN_TILE + threadIdx.x * IGD_SCAN_ITEMS;
+    int64_t v[IGD_SCAN_ITEMS];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int64_t inc = s;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        int64_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int64_t run = inc - s;
+    for (int w = 0; w < IGD_SCAN_BLOCK / IGD_WAVE; w++) run += red[w];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < IGD_SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+        if (base + k == n - 1) out[n] = run;             // the grand total closes the offsets
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1788,13 +1815,14 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     rc = ensure_workspace(db, nq, 16);
     if (rc != IGD_HIP_OK) return rc;
     int32_t *d_pcount = nullptr;
-    int64_t *d_qlong = nullptr, *d_qcount = nullptr, *d_qoff = nullptr;
+    int64_t *d_qlong = nullptr, *d_qcount = nullptr, *d_qoff = nullptr, *d_bsum = nullptr;
     igd_hip_hit *d_out = nullptr;
     auto cleanup = [&]() {
         if (d_pcount) (void)hipFree(d_pcount);
         if (d_qlong) (void)hipFree(d_qlong);
         if (d_qcount) (void)hipFree(d_qcount);
         if (d_qoff) (void)hipFree(d_qoff);
+        if (d_bsum) (void)hipFree(d_bsum);
         if (d_out) (void)hipFree(d_out);
     };
 #define EH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; } } while (0)
@@ -1802,6 +1830,7 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     if ((rc = dalloc(&d_qlong, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
     if ((rc = dalloc(&d_qcount, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
     if ((rc = dalloc(&d_qoff, (size_t)nq + 1, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
+    if ((rc = dalloc(&d_bsum, (size_t)(nq / IGD_SCAN_TILE + 2), nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
     EH(hipMemcpyAsync(db->d_qc, ichr, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemcpyAsync(db->d_qs, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
@@ -1813,7 +1842,11 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
         db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
     k_enum_qcount<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_pcount, d_qlong, (int)nq, d_qcount);
-    k_scan64<<<1, 1024, 0, st>>>(d_qcount, (int)nq, d_qoff);
+    {
+        const int sb = (int)((nq + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE);
+        k_scan64_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(d_qcount, (int)nq, d_bsum);
+        k_scan64_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(d_qcount, (int)nq, d_bsum, d_qoff);
+    }
     EH(hipMemcpyAsync(qoff, d_qoff, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, st));
     EH(hipStreamSynchronize(st));
     int64_t tot = qoff[nq];
