@@ -127,6 +127,7 @@ def hip():
         L.igd_hip_free.argtypes = [C.c_void_p]
         L.igd_hip_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_int32, C.c_int, C.POINTER(HipStats)]
+        L.igd_hip_hitmap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, i64p]
         L.igd_hip_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.igd_hip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]

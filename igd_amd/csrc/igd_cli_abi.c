@@ -346,6 +346,27 @@ static int32_t one_enumerate(char *chrm, int32_t qs, int32_t qe)
 int32_t get_overlaps_f1(char *chrm, int32_t qs, int32_t qe) { return one_enumerate(chrm, qs, qe); } /* :537-620 */
 int32_t get_overlaps_f0(char *chrm, int32_t qs, int32_t qe) { return one_enumerate(chrm, qs, qe); } /* :114-200 */
 
+/* ------------------------------- hit map (-m) ----------------------------------------- */
+static int64_t hit_map(uint32_t **hitmap, int use_v, int32_t v)
+{
+    igd_hip_db *dev = engine();
+    const int32_t n = cur_igd()->nFiles;
+    uint32_t *flat = (uint32_t *)calloc((size_t)n * (size_t)n + 1, sizeof(uint32_t));
+    int64_t total = 0;
+    int rc = igd_hip_hitmap(dev, use_v, v, flat, &total);
+    if (rc != IGD_HIP_OK) die_no_gpu("hitmap", rc);
+    for (int32_t a = 0; a < n; a++)
+        for (int32_t b = 0; b < n; b++) hitmap[a][b] += flat[(size_t)a * (size_t)n + (size_t)b];
+    free(flat);
+    /* the reference prints a progress counter every 1000 tiles while it works (:783-784) */
+    int64_t tiles = 0;
+    for (int32_t c = 0; c < cur_igd()->nCtg; c++) tiles += cur_igd()->nTile[c];
+    for (int64_t m = 1000; m <= tiles; m += 1000) printf("%i\n", (int)m);
+    return total;
+}
+int64_t getMap(uint32_t **hitmap) { return hit_map(hitmap, 0, 0); }                  /* :772-826 */
+int64_t getMap_v(uint32_t **hitmap, int32_t v) { return hit_map(hitmap, 1, v); }      /* :829-886 */
+
 /* ------------------------------- `igd search` ----------------------------------------- */
 static int usage_search(void)
 {
@@ -356,8 +377,9 @@ static int usage_search(void)
             "    -r <chrN start end>        a single region\n"
             "    -v <signal value 0-1000>   keep records with value >= v\n"
             "    -f                         print every overlap (with -q or -r)\n"
-            "    -o <name>, -c              accepted, no effect on this path\n"
-            "    -s, -m                     Seqpare / hit map: not part of this build\n"
+            "    -m                         dataset x dataset hit map, written to -o <name> (default Hitsmap)\n"
+            "    -c                         accepted, no effect\n"
+            "    -s                         Seqpare: not part of this build\n"
             "  environment: IGD_DEVICE=<n> selects the GPU (default 0)\n");
     return EX_OK;
 }
@@ -398,6 +420,7 @@ int igd_search(int argc, char **argv)                                        /* 
     int32_t v = 0, qs = 1, qe = 2;
     int mode = -1, full = 0;
     char *chrm = NULL, *qfName = (char *)"";
+    char out[64] = "";
     for (int i = 3; i < argc; i++) {                                          /* :931-971 */
         const char *a = argv[i];
         if (strcmp(a, "-q") == 0) {
@@ -419,6 +442,8 @@ int igd_search(int argc, char **argv)                                        /* 
             mode = 3;
         } else if (strcmp(a, "-f") == 0) {
             full = 1;
+        } else if (strcmp(a, "-o") == 0) {
+            if (i + 1 < argc) { strncpy(out, argv[i + 1], sizeof out - 1); out[sizeof out - 1] = '\0'; }
         }
     }
 
@@ -453,8 +478,31 @@ int igd_search(int argc, char **argv)                                        /* 
         printf("index\t number of regions\t number of hits\t File_name\n");
         for (int32_t i = 0; i < nfiles; i++)
             printf("%i\t%i\t%lld\t%s\n", i, IGD->finfo[i].nr, (long long)hits[i], IGD->finfo[i].fileName);
-    } else if (mode == 0 || mode == 3) {
-        printf("igd: -m (hit map) and -s (Seqpare) are not part of the MI355X search build\n");
+    } else if (mode == 0) {                                                   /* :996-1022 */
+        if (IGD->gType != 1) {
+            printf("igd: -m needs a database created with 16-byte records (gType 1)\n");
+        } else {
+            uint32_t **hitmap = (uint32_t **)malloc(sizeof(uint32_t *) * (size_t)(nfiles + 1));
+            for (int32_t i = 0; i < nfiles; i++) hitmap[i] = (uint32_t *)calloc((size_t)nfiles + 1, sizeof(uint32_t));
+            if (v > 0) getMap_v(hitmap, v); else getMap(hitmap);
+            if (strlen(out) < 2) strcpy(out, "Hitsmap");
+            FILE *fo = fopen(out, "w");
+            if (!fo) printf("Can't open file %s\n", out);
+            else {
+                static char obuf[1 << 20];
+                setvbuf(fo, obuf, _IOFBF, sizeof obuf);
+                fprintf(fo, "%u\t%u\t%u\n", (unsigned)nfiles, (unsigned)nfiles, (unsigned)v);
+                for (int32_t i = 0; i < nfiles; i++) {
+                    for (int32_t j = 0; j < nfiles; j++) fprintf(fo, "%u\t", hitmap[i][j]);
+                    fprintf(fo, "\n");
+                }
+                fclose(fo);
+            }
+            for (int32_t i = 0; i < nfiles; i++) free(hitmap[i]);
+            free(hitmap);
+        }
+    } else if (mode == 3) {
+        printf("igd: -s (Seqpare) is not part of the MI355X search build\n");
     } else {
         free(hits);
         return usage_search();

@@ -1137,6 +1137,74 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan64_apply(const int64_t *
 }
 
 // ------------------------------------------------------------------------------------------
+// `-m`: dataset x dataset hit map (getMap src/igd_search.c:772-826, getMap_v :829-886;
+// SURVEY 8f row f3).  Tile by tile, every record j is a query against its own tile:
+//     hitmap[idx_j][idx_i]++   for every i with  start_i < end_j && end_i > start_j
+//                                                && (start_j >= bd || start_i >= bd)   [&& value_j,value_i > v]
+// (the last clause is the reference's tS skip, :803-804: two records that both begin before the
+// tile were already paired in an earlier tile; its maxE early exit, :791-796/:811, only shortens
+// the scan).  One workgroup per tile; each thread owns a record j of a 256-record slice and walks
+// the tile's records, staged 256 at a time in LDS (broadcast reads), leaving as soon as the sorted
+// starts pass every end of the slice.  Counters are the reference's uint32.
+#define IGD_MAP_WG 256
+template <bool USE_V>
+__global__ __launch_bounds__(IGD_MAP_WG) void igd_hitmap_tiles(DbView db, int v, uint32_t *__restrict__ hitmap,
+                                                               u64 *__restrict__ total)
+{
+    __shared__ int32_t sS[IGD_MAP_WG], sE[IGD_MAP_WG], sX[IGD_MAP_WG], sV[IGD_MAP_WG];
+    __shared__ u64 red[IGD_MAP_WG / IGD_WAVE];
+    u64 found = 0;
+    for (int t = blockIdx.x; t < db.nT; t += gridDim.x) {
+        const int cnt = db.tileCnt[t];
+        if (cnt == 0) continue;
+        const int64_t off = db.tileOff[t];
+        const int tb = db.tileBd[t];
+        const int bd = tb == INT_MIN ? 0 : tb;                       // getMap uses nbp*n1, also for tile 0
+        for (int jb = 0; jb < cnt; jb += IGD_MAP_WG) {
+            const int j = jb + (int)threadIdx.x;
+            bool act = j < cnt;
+            const int qs = act ? db.start[off + j] : 0;
+            const int qe = act ? db.end[off + j] : INT_MIN;
+            const int jj = act ? db.idx[off + j] : 0;
+            if (USE_V && act) act = db.value[off + j] > v;
+            const bool prefix = qs < bd;
+            uint32_t *row = hitmap + (size_t)jj * (size_t)db.nFiles;
+            for (int ib = 0; ib < cnt; ib += IGD_MAP_WG) {
+                const int i = ib + (int)threadIdx.x;
+                __syncthreads();
+                if (i < cnt) {
+                    sS[threadIdx.x] = db.start[off + i];
+                    sE[threadIdx.x] = db.end[off + i];
+                    sX[threadIdx.x] = db.idx[off + i];
+                    if (USE_V) sV[threadIdx.x] = db.value[off + i];
+                }
+                __syncthreads();
+                // sorted by start: once the first start of this stage is >= every end of the slice, done
+                if (!__syncthreads_or(act && qe > sS[0])) break;
+                const int nB = cnt - ib < IGD_MAP_WG ? cnt - ib : IGD_MAP_WG;
+                if (act) {
+                    for (int k = 0; k < nB; k++) {
+                        const int s = sS[k];
+                        if (s >= qe) break;                          // this thread's partners end here
+                        bool hit = sE[k] > qs && (!prefix || s >= bd);
+                        if (USE_V) hit = hit && sV[k] > v;
+                        if (hit) { atomicAdd(&row[sX[k]], 1u); found++; }
+                    }
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) found += __shfl_down(found, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = found;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 s = 0;
+        for (int w = 0; w < IGD_MAP_WG / IGD_WAVE; w++) s += red[w];
+        if (s) atomicAdd(total, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // instrumentation: exact terms of the algorithmic byte model, thread per query.
 __device__ __forceinline__ int lower_bound_start(const int32_t *s, int n, int key)
 {
@@ -1867,6 +1935,50 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     }
 #undef EH
     cleanup();
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total)
+{
+    if (!db || !hitmap) {
+        snprintf(g_err, sizeof g_err, "igd_hip_hitmap: bad argument");
+        return IGD_HIP_ERR_ARG;
+    }
+    if (total) *total = 0;
+    if (db->gType != 1) {
+        snprintf(g_err, sizeof g_err, "igd_hip_hitmap: needs a gType-1 database (the reference's getMap reads 16-byte records)");
+        return IGD_HIP_ERR_ARG;
+    }
+    const size_t cells = (size_t)db->nFiles * (size_t)db->nFiles;
+    if (cells == 0 || db->nT == 0) return IGD_HIP_OK;
+    if (cells * 4 > ((size_t)64 << 30)) {
+        snprintf(g_err, sizeof g_err, "igd_hip_hitmap: %d x %d matrix does not fit", db->nFiles, db->nFiles);
+        return IGD_HIP_ERR_NOMEM;
+    }
+    HIPCHK(hipSetDevice(db->device));
+    uint32_t *d_map = nullptr;
+    u64 *d_tot = nullptr;
+    int rc;
+    if ((rc = dalloc(&d_map, cells, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&d_tot, 1, nullptr)) != IGD_HIP_OK) { (void)hipFree(d_map); return rc; }
+    hipStream_t st = db->stream;
+    hipError_t e = hipMemsetAsync(d_map, 0, cells * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_tot, 0, 8, st);
+    if (e == hipSuccess) {
+        int grid = db->nT < 256 * 16 ? db->nT : 256 * 16;
+        if (use_v) igd_hitmap_tiles<true><<<grid, IGD_MAP_WG, 0, st>>>(db->v, v, d_map, d_tot);
+        else igd_hitmap_tiles<false><<<grid, IGD_MAP_WG, 0, st>>>(db->v, v, d_map, d_tot);
+        e = hipGetLastError();
+    }
+    std::vector<uint32_t> h;
+    u64 tot = 0;
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) { h.resize(cells); e = hipMemcpy(h.data(), d_map, cells * 4, hipMemcpyDeviceToHost); }
+    if (e == hipSuccess) e = hipMemcpy(&tot, d_tot, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_map); (void)hipFree(d_tot);
+    if (e != hipSuccess) { set_err("hitmap", e, __FILE__, __LINE__); return IGD_HIP_ERR_DEVICE; }
+    for (size_t c = 0; c < cells; c++) hitmap[c] += h[c];            // hitmap[][]++ semantics: added to
+    if (total) *total = (int64_t)tot;
     return IGD_HIP_OK;
 }
 

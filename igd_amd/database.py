@@ -149,6 +149,13 @@ class Database:
             rec = np.zeros((0, 4), np.int32)
         return qoff, rec
 
+    def hitmap(self, v=0):
+        """`-m`: (uint32[nfiles,nfiles], pairs); v>0 keeps records with value > v (getMap_v)."""
+        m = np.zeros((self.nfiles, self.nfiles), np.uint32)
+        total = C.c_int64(0)
+        _chk(self._H.igd_hip_hitmap(self.dev, 1 if v > 0 else 0, int(v), m.ctypes.data, C.byref(total)), "igd_hip_hitmap")
+        return m, total.value
+
     def batch_stats(self, d_ichr, d_qs, d_qe, nq, v=0):
         rule, vf = self.cli_dispatch(self.gtype, v)
         st = N.HipStats()

@@ -133,6 +133,12 @@ int  igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs,
                        int64_t *total);
 void igd_hip_free(void *p);
 
+/* `-m`: dataset x dataset hit map, getMap src/igd_search.c:772-826 (use_v = 0) and getMap_v
+ * :829-886 (use_v = 1: both records need value > v, strictly).  hitmap is nFiles x nFiles uint32,
+ * row-major, caller-allocated, ADDED to; *total (may be NULL) receives the number of pairs.
+ * gType-1 databases only.  Blocking. */
+int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total);
+
 /* Instrumentation ------------------------------------------------------------------- */
 /* Exact algorithmic-work terms for a device-resident batch (blocking). */
 int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,

@@ -16,7 +16,7 @@
  * GPU selection: environment variable IGD_DEVICE (default 0).
  *
  * Out of scope (declared by the reference, not provided here):
- * seq_overlaps/seqOverlaps (Seqpare), getMap/getMap_v (hit map).
+ * seq_overlaps/seqOverlaps (Seqpare).
  */
 #ifndef __IGD_SEARCH_H__
 #define __IGD_SEARCH_H__
@@ -40,7 +40,12 @@ int64_t getOverlaps0 (char *qFile, int64_t *hits);                              
 int64_t getOverlaps_f1(char *qFile);                                                   /* :721-744 */
 int64_t getOverlaps_f0(char *qFile);                                                   /* :227-250 */
 
-/* `igd search <db.igd> [-q file | -r chr s e] [-v N] [-f] [-o name] [-c]`             :889-1079 */
+/* dataset x dataset hit map (`-m`): hitmap[nFiles][nFiles], caller-zeroed, incremented; returns
+ * the number of pairs counted */
+int64_t getMap(uint32_t **hitmap);                                                     /* :772-826 */
+int64_t getMap_v(uint32_t **hitmap, int32_t v);                                        /* :829-886 */
+
+/* `igd search <db.igd> [-q file | -r chr s e | -m] [-v N] [-f] [-o name] [-c]`        :889-1079 */
 int igd_search(int argc, char **argv);
 
 #ifdef __cplusplus

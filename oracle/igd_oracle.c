@@ -571,6 +571,60 @@ int64_t orc_enumerate_batch(orc_db *db, const int32_t *ichr, const int32_t *qs, 
     return n;
 }
 
+/* ------------------------------ hit map (-m) ----------------------------------------- */
+/* getMap :772-826 / getMap_v :829-886.  Tile by tile, every record j of the tile is a query
+ * against the tile itself: partners i with start_i < end_j (index from the <16 back-walk or
+ * bSearch over [tS, cnt-1], :806-810), scanned downwards while the running maximum of ends
+ * maxE[i] > start_j (:811), counted when end_i > start_j [and both values > v].  A record that
+ * starts before the tile (qs < bd) only pairs with records that start inside it (:803-804). */
+int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *progress)
+{
+    const int rs = db->rs;
+    int64_t nols = 0;
+    int m = 0;
+    for (int32_t ichr = 0; ichr < db->nCtg; ichr++) {
+        for (int32_t n1 = 0; n1 < db->nTile[ichr]; n1++) {
+            const int32_t bd = (int32_t)((uint32_t)db->nbp * (uint32_t)n1);
+            const int32_t cnt = db->nCnt[ichr][n1];
+            m++;
+            if (progress && m % 1000 == 0) fprintf(progress, "%i\n", m);
+            if (cnt <= 0) continue;
+            db->preIdx = -8; db->preChr = -6;                    /* the reference re-reads every tile */
+            const int32_t *g = fetch_tile(db, ichr, n1, cnt);
+            int32_t *maxE = (int32_t *)malloc(sizeof(int32_t) * (size_t)cnt);
+            int32_t tmax = R_END(g, rs, 0);
+            for (int32_t i = 0; i < cnt; i++) {
+                if (R_END(g, rs, i) > tmax) tmax = R_END(g, rs, i);
+                maxE[i] = tmax;
+            }
+            for (int32_t j = 0; j < cnt; j++) {
+                if (use_v && !(R_VALUE(g, rs, j) > v)) continue;
+                const int32_t qe = R_END(g, rs, j), qs = R_START(g, rs, j);
+                if (!(qe > R_START(g, rs, 0))) continue;
+                const int32_t jj = R_IDX(g, rs, j);
+                int32_t tS = 0;
+                if (qs < bd)
+                    while (tS < cnt && R_START(g, rs, tS) < bd) tS++;
+                int32_t i;
+                if (cnt < 16) {
+                    i = cnt - 1;
+                    while (R_START(g, rs, i) >= qe) i--;
+                } else
+                    i = tS <= cnt - 1 ? bsearch_last(g, rs, tS, cnt - 1, qe) : -1;
+                while (i >= tS && maxE[i] > qs) {
+                    if (R_END(g, rs, i) > qs && (!use_v || R_VALUE(g, rs, i) > v)) {
+                        nols++;
+                        hitmap[(size_t)jj * (size_t)db->nFiles + (size_t)R_IDX(g, rs, i)]++;
+                    }
+                    i--;
+                }
+            }
+            free(maxE);
+        }
+    }
+    return nols;
+}
+
 /* ------------------------------ `igd search` driver -------------------------------- */
 /* src/igd_search.c:889-1079.  Same flag loop (:931-971), same dispatch (:975-1053), same
  * text.  `-m` and `-s` are outside the hot path and are not restated. */
@@ -591,6 +645,7 @@ int orc_igd_search(int argc, char **argv, FILE *out)
     int32_t v = 0, qs = 1, qe = 2;
     int mode = -1, p_mode = 0;
     const char *chrm = NULL, *qfName = "";
+    char outName[64] = "";
     for (int i = 3; i < argc; i++) {
         if (strcmp(argv[i], "-q") == 0) {
             if (i + 1 < argc) { qfName = argv[i + 1]; mode = 1; }
@@ -600,6 +655,9 @@ int orc_igd_search(int argc, char **argv, FILE *out)
         } else if (strcmp(argv[i], "-v") == 0) {
             if (i + 1 < argc) v = atoi(argv[i + 1]);
         } else if (strcmp(argv[i], "-m") == 0) mode = 0;
+        else if (strcmp(argv[i], "-o") == 0) {
+            if (i + 1 < argc) { strncpy(outName, argv[i + 1], 63); outName[63] = '\0'; }
+        }
         else if (strcmp(argv[i], "-s") == 0 && mode != 2) mode = 3;
         else if (strcmp(argv[i], "-f") == 0) p_mode = 1;
     }
@@ -611,6 +669,22 @@ int orc_igd_search(int argc, char **argv, FILE *out)
             fprintf(out, "Total overlaps: %lld\n", (long long)orc_get_overlaps_f(db, chrm, qs, qe, out));
         else
             fprintf(out, "Not supported -f option\n");
+    } else if (mode == 0) {                                      /* :996-1022           */
+        const size_t nf = (size_t)db->nFiles;
+        uint32_t *hm = (uint32_t *)calloc(nf * nf + 1, sizeof(uint32_t));
+        orc_getMap(db, v > 0, v, hm, out);
+        if (strlen(outName) < 2) strcpy(outName, "Hitsmap");
+        FILE *fo = fopen(outName, "w");
+        if (!fo) fprintf(out, "Can't open file %s\n", outName);
+        else {
+            fprintf(fo, "%u\t%u\t%u\n", (unsigned)nf, (unsigned)nf, (unsigned)v);
+            for (size_t a = 0; a < nf; a++) {
+                for (size_t b = 0; b < nf; b++) fprintf(fo, "%u\t", hm[a * nf + b]);
+                fprintf(fo, "\n");
+            }
+            fclose(fo);
+        }
+        free(hm);
     } else if (mode == 1) {                                      /* :1023-1040          */
         if (db->gType == 0 || v <= 0) orc_getOverlaps(db, qfName, hits);
         else orc_getOverlaps_v(db, qfName, hits, v);

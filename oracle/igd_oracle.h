@@ -100,6 +100,12 @@ int64_t orc_search_batch(orc_db *db, const int32_t *ichr, const int32_t *qs, con
 int64_t orc_enumerate_batch(orc_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                             int64_t nq, int64_t *qoff, orc_hit *out, int64_t cap);
 
+/* ---- dataset x dataset hit map (`-m`), SURVEY 8f row f3 ------------------------------ */
+/* getMap src/igd_search.c:772-826 (use_v=0) / getMap_v :829-886 (value > v, strict):
+ * hitmap is nFiles x nFiles, row-major, ADDED to.  Returns the number of pairs counted.
+ * progress!=NULL receives the reference's progress lines ("%i\n" every 1000 tiles, :783-784). */
+int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *progress);
+
 /* ---- `igd search` driver (stdout text identical to src/igd_search.c:889-1079) ----- */
 int orc_igd_search(int argc, char **argv, FILE *out);
 

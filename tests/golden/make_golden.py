@@ -65,6 +65,15 @@ class Case:
         open(os.path.join(self.tmp, key), "w").write(out)
         self.runs.append({"args": args, "stdout": key})
 
+    def hitmap(self, v):
+        """`igd search db.igd -m [-v v] -o <name>`: keeps the written matrix file and the stdout."""
+        name = "hm%d.txt" % v
+        args = ["search", "db.igd", "-m", "-o", name] + (["-v", str(v)] if v else [])
+        out = run_ref(args, cwd=self.tmp)
+        key = "hm%d.stdout" % v
+        open(os.path.join(self.tmp, key), "w").write(out)
+        self.meta.setdefault("hitmaps", []).append({"args": args, "file": name, "stdout": key})
+
     def finish(self, keep_beds=True):
         json.dump({"runs": self.runs, "meta": self.meta}, open(os.path.join(self.tmp, "manifest.json"), "w"), indent=1)
         dst = os.path.join(HERE, self.name)
@@ -100,6 +109,7 @@ def main():
         c.run(["search", "db.igd", "-r", "chr1", str(s), str(e)])
         c.run(["search", "db.igd", "-r", "chr1", str(s), str(e), "-v", "500"])
         c.run(["search", "db.igd", "-r", "chr1", str(s), str(e), "-f"])
+    c.hitmap(0); c.hitmap(500)
     c.finish()
 
     # 2. quirk: empty first tile -> default finds nothing, -v N does
@@ -123,6 +133,7 @@ def main():
     q_modes(c, "q.bed", vs=(1, 500))
     c.run(["search", "db.igd", "-r", "chr1", "100", "30000"])
     c.run(["search", "db.igd", "-r", "chr1", "100", "30000", "-v", "1"])
+    c.hitmap(0); c.hitmap(300)
     c.finish()
 
     # 3. branch: tiles with exactly 1,2,15,16,17 records (the <16 branch of get_overlaps_v),
@@ -152,6 +163,7 @@ def main():
     rows += [("chr1", 0, 40 * nbp), ("chr1", 19 * nbp, 500 * nbp), ("chr1", 21 * nbp, 22 * nbp)]
     c.queries("q.bed", rows)
     q_modes(c, "q.bed", vs=(1, 60, 500, 900))
+    c.hitmap(0); c.hitmap(60)
     c.finish()
 
     # 4. parse: what the query reader accepts / skips (parse_bed + ks_getuntil)
@@ -227,6 +239,7 @@ def main():
     c.queries("q100.bed", rows[:100])
     q_modes(c, "q.bed", vs=(500,), full=False)
     c.run(["search", "db.igd", "-q", "q100.bed", "-f"])
+    c.hitmap(0); c.hitmap(500)
     c.finish()
 
     # 7. BASELINE config 1: 8 files x 10k intervals (-b 14) made by the product's deterministic

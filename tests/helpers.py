@@ -102,6 +102,8 @@ def orc():
         lib.orc_enumerate_batch.restype = C.c_int64
         lib.orc_enumerate_batch.argtypes = [C.c_void_p, i32p, i32p, i32p, C.c_int64, i64p,
                                             C.POINTER(OrcHit), C.c_int64]
+        lib.orc_getMap.restype = C.c_int64
+        lib.orc_getMap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_void_p]
         lib.free = C.CDLL(None).free
         lib.free.argtypes = [C.c_void_p]
         _orc = lib
@@ -180,6 +182,11 @@ class Oracle:
         self.lib.orc_enumerate_batch(self.h, _p32(ichr), _p32(qs), _p32(qe), n, _p64(qoff), buf, total)
         arr = np.frombuffer(buf, dtype=np.int32).reshape(-1, 3)[:total].copy()
         return qoff, arr  # columns idx,start,end
+
+    def hitmap(self, v=0):
+        m = np.zeros((self.nfiles, self.nfiles), np.uint32)
+        tot = self.lib.orc_getMap(self.h, 1 if v > 0 else 0, v, m.ctypes.data, None)
+        return m, tot
 
     def file_search(self, qfile, v=0):
         hits = np.zeros(max(self.nfiles, 1), np.int64)

@@ -100,3 +100,23 @@ def test_work_statistics_equal_oracle(big):
         w = o.stats()
         assert (st["pairs"], st["S"], st["B"], st["H"]) == (w["pairs"], w["S"], w["B"], w["H"]), (v, st, w)
     o.close()
+
+
+def test_hitmap_full_scale_equals_reference_cli(big, tmp_path):
+    """`-m` on the roadmap-scale database (1.7e9 overlapping pairs): the matrix file and the stdout
+    of bin/igd are byte-identical to the reference CLI's (~15 s of CPU), and the matrix is symmetric
+    with a diagonal >= the number of records per file."""
+    db, path, _ = big
+    m, tot = db.hitmap(0)
+    assert tot == int(m.sum(dtype=np.uint64)) and (m == m.T).all()
+    assert (np.diag(m) >= 26316).all()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mine = os.path.join(DIR, "hm_gpu.txt")
+    p = subprocess.run([os.path.join(root, "bin", "igd"), "search", path, "-m", "-o", mine], stdout=subprocess.PIPE, check=True)
+    got = np.loadtxt(mine, dtype=np.uint32, skiprows=1)
+    np.testing.assert_array_equal(got, m)
+    if have_ref():
+        theirs = os.path.join(DIR, "hm_ref.txt")
+        r = subprocess.run([REF_BIN, "search", path, "-m", "-o", theirs], stdout=subprocess.PIPE, check=True)
+        assert r.stdout == p.stdout
+        assert open(theirs, "rb").read() == open(mine, "rb").read()

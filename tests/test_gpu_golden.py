@@ -145,3 +145,19 @@ def test_r_flavour_c_entry_points():
     np.testing.assert_array_equal(h32, o.search(ichr, qs, qe)[0])
     L.close_iGD(hnd)
     o.close()
+
+
+@pytest.mark.parametrize("case", ["edge", "quirk", "branch", "smallrand"])
+def test_cli_hitmap_file_identical_to_reference(case):
+    """`igd search db.igd -m [-v N] -o file` writes the bytes the reference wrote (f3)."""
+    d, dst, man = materialize(case)
+    try:
+        for hm in man["meta"]["hitmaps"]:
+            out = os.path.join(d, "g_" + hm["file"])
+            args = [os.path.join(dst, a) if a == "db.igd" else out if a == hm["file"] else a for a in hm["args"]]
+            p = subprocess.run([EXE] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert p.returncode == 0, p.stderr.decode()[-300:]
+            assert p.stdout.decode() == open(os.path.join(dst, hm["stdout"])).read()
+            assert open(out).read() == open(os.path.join(dst, hm["file"])).read(), (case, hm["args"])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

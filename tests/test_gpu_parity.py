@@ -159,3 +159,25 @@ def test_cli_text_identical_to_oracle_cli(workdir):
         args = ["search", path, "-r", ctgs[1], "5000", "30000"] + extra
         got = subprocess.run([exe] + args, stdout=subprocess.PIPE, check=True).stdout.decode()
         assert got == run_oracle_cli(args), extra
+
+
+@pytest.mark.parametrize("case", [0, 1, 3, 5])
+def test_hitmap_matches_oracle(case, workdir):
+    """`-m`: dataset x dataset matrix (getMap / getMap_v) on fuzzed databases, incl. a hot tile
+    with > 256 records (several LDS stages) and records spanning many tiles (the tS skip)."""
+    from igd_amd import Database
+    rng = random.Random(1234 + case)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[case]
+    path, ctgs, span = _random_db(rng, workdir, "m%d" % case, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        for v in (0, 1, 500, 999):
+            want, wtot = orc.hitmap(v)
+            got, gtot = db.hitmap(v)
+            assert gtot == wtot == int(want.sum()), (case, v)
+            np.testing.assert_array_equal(got, want, err_msg="case %d v %d" % (case, v))
+        assert (db.hitmap(0)[0] == db.hitmap(0)[0].T).all()      # the relation is symmetric
+    finally:
+        db.close()
+        orc.close()
