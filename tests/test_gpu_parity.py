@@ -65,6 +65,8 @@ CASES = [
     (1 << 14, 1, 9, 2, 8, 40, 150),     # hot tile with > 512 records (multi-chunk)
     (1 << 12, 1, 3, 1, 40, 1, 0),       # nearly empty
     (1 << 11, 1, 33, 3, 20, 60, 40),
+    (3000, 1, 8, 2, 15, 40, 0),         # tile width that is not a power of two (division path)
+    (40000, 1, 6, 2, 6, 60, 0),         # wider than the compact image allows (exact arrays) and not a power of two
 ]
 
 
@@ -178,6 +180,39 @@ def test_hitmap_matches_oracle(case, workdir):
             assert gtot == wtot == int(want.sum()), (case, v)
             np.testing.assert_array_equal(got, want, err_msg="case %d v %d" % (case, v))
         assert (db.hitmap(0)[0] == db.hitmap(0)[0].T).all()      # the relation is symmetric
+    finally:
+        db.close()
+        orc.close()
+
+
+def test_many_datasets_use_global_counters(workdir):
+    """nFiles * 8 bytes > 128 KiB: no LDS copy of hits[]; the scan kernel adds to the global
+    counters directly (LDS_HITS = false), and idx no longer fits the 16-bit compact image."""
+    import os
+    from igd_amd import Database
+    rng = random.Random(8)
+    nbp = 1 << 12
+    nfiles = 70000
+    files = []
+    for f in range(nfiles):
+        s = rng.randrange(0, 40 * nbp)
+        files.append([("chr1", s, s + rng.randint(1, 3 * nbp), rng.randint(0, 1000))])
+    path = os.path.join(workdir, "many.igd")
+    write_igd_numpy(path, files, nbp=nbp, gtype=1)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        assert db.nfiles == nfiles
+        ichr, qs, qe = _random_queries(rng, [0], nbp, 40 * nbp, 2000)
+        for v in (0, 500):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            for flags in (0, 2):
+                got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                assert gtot == wtot
+                np.testing.assert_array_equal(got, want)
+        order = np.lexsort((qs, ichr))
+        got, gtot = db.search(ichr[order], qs[order], qe[order], 0)
+        np.testing.assert_array_equal(got, orc.search(ichr, qs, qe, 0)[0])
     finally:
         db.close()
         orc.close()
