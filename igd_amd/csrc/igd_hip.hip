@@ -20,20 +20,22 @@
 //         (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); these kernels return at once
 //         when (a) holds.
 //      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
-//   2. scan:   igd_scan_tiles -- one wavefront owns one <=512-record chunk of one tile.  It
-//      loads the chunk's start/end/idx[/value] once, coalesced, into 8 register slots
-//      (record r*64+lane), then runs through the tile's pairs, whose (qs,qe) it fetches 64 at
-//      a time and broadcasts lane by lane with v_readlane.  Per pair and slot the test is
+//   2. scan:   igd_scan_tiles -- one wavefront owns one <=320-record chunk ("unit") of one tile
+//      at a time.  It loads the unit's records once, coalesced, into 5 register slots (record
+//      r*64+lane) -- by default from a compact 6-byte tile-relative image (k_pack_units) -- keeps
+//      two units in flight, and runs through the tile's queries, whose parameters it computes 64
+//      at a time across the lanes and broadcasts with v_readlane.  Per query and slot the test
 //            lob <= start < qe  &&  end > qs  [&& value >= v]
-//      (lob = tile start for a non-first tile: that is the reference's tS prefix skip,
-//      :510-511; the upper bound start<qe is what its bisection computes, :479-487), with a
-//      wave-uniform early exit on the sorted starts (slot minimum >= qe).  A hit is one
-//      ds_add_u64 into a per-workgroup LDS copy of hits[] (privatised counters).
+//      (lob = tile start for a non-first tile: the reference's tS prefix skip, :510-511; the
+//      upper bound start<qe is what its bisection computes, :479-487) costs three vector
+//      instructions and accumulates a per-record hit count; each record that was hit then does
+//      ONE ds_add_u64 into a per-workgroup LDS copy of hits[] (privatised counters).
 //   3. flush/reduce: each workgroup stores its LDS counters to its own slab row with plain
-//      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].
-// Queries spanning more than IGD_SHORT_TILES tiles skip the bucketing and are walked tile by
-// tile by one wave each at the end of the scan kernel (same compare code).
-// No MFMA anywhere: this is integer compare + count, bound by HBM/LDS, not by math.
+//      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].  The same
+//      launch walks, on the exact arrays, the few queries the scan leaves out (more than
+//      IGD_SHORT_TILES tiles long, or needing exact starts: see k_pack_units).
+//   `-f` (igd_enum_tiles) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays.
+// No MFMA anywhere: this is integer compare + count, bound by HBM / VALU issue, not by math.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -68,8 +70,8 @@
 typedef unsigned long long u64;
 
 // tuning / experiment knobs (defaults are the shipped configuration)
-#ifndef IGD_EXP_NOATOMIC
-#define IGD_EXP_NOATOMIC 0    // measurement only: drop the LDS atomics (wrong results)
+#ifndef IGD_BUFFER_LOADS
+#define IGD_BUFFER_LOADS 1    // compact image read with bounds-checked buffer loads (descriptor per unit)
 #endif
 #ifndef IGD_EXP_NOMATCH
 #define IGD_EXP_NOMATCH 0     // measurement only: load everything, compare nothing (wrong results)
@@ -125,7 +127,7 @@ struct __attribute__((aligned(32))) Unit {
 #define UNIT_FLAGS(u) ((u).jf & 15)
 
 struct DbView {
-    int32_t nbp, shift, nCtg, nT, nChunks, nUnits, nFiles;
+    int32_t nbp, shift, nCtg, nT, nUnits, nFiles;
     const Unit *units;
     const int32_t *start, *end, *idx, *value;   // SoA over all records, file order (exact)
     // compact tile-relative image of the same records (6 bytes each), see k_pack_units:
@@ -141,7 +143,7 @@ struct DbView {
 
 struct igd_hip_db {
     int device;
-    int32_t nbp, gType, nCtg, nFiles, nT, nChunks;
+    int32_t nbp, gType, nCtg, nFiles, nT;
     int64_t nRec;
     DbView v;
     // owned device memory of the image
@@ -598,6 +600,31 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
     const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(L.offHi, kk) << 32) |
                                   (unsigned)__builtin_amdgcn_readlane(L.offLo, kk));
     const int64_t base = active ? off : 0;
+#if IGD_BUFFER_LOADS
+    if (PACKED) {
+        // Buffer loads with a per-unit descriptor: hardware bounds checking returns 0 for lanes past
+        // the unit's last record (0 is the "never matches" word) and for unvisited units (n = 0) no
+        // memory is touched at all; the per-lane part of the address is just lane*4 + r*256.
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pse + base), 0, n * 4, 0x00020000);
+        const int vo4 = lane * 4, vo2 = lane * 2;
+        if (USE_V) {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + base), 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, 0, 0);
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, 0, 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + base), 0, n * 2, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, 0, 0);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, 0, 0);
+            }
+        }
+    } else
+#endif
+    {
     // uniform base pointers + (slot*64 + lane): the loads need no per-lane address arithmetic.
     // Lanes past the unit's last record read the next unit's records (the arrays are padded by
     // one chunk); compute_unit discards them.
@@ -618,6 +645,7 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
             R.x[r] = db.idx[at];
             if (USE_V) R.w[r] = db.value[at];
         }
+    }
     }
     if (SORTED) {
         int i = r0 + lane;
@@ -697,7 +725,7 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
         cnt[r] = 0;
         // lanes past the unit's last record hold someone else's data: make them unmatchable;
         // (compact image) so are records that fail the value filter -- v is fixed for the batch
-        bool drop = r * IGD_WAVE + lane >= un;
+        bool drop = (IGD_BUFFER_LOADS && PACKED) ? false : (r * IGD_WAVE + lane >= un);
         if (PACKED && USE_V) {
             drop = drop || (R.x[r] >> 16) < a.v;         // arithmetic shift: the signed 16-bit value
             R.x[r] &= 0xFFFF;
@@ -1429,7 +1457,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         delete db;
         return IGD_HIP_ERR_ARG;
     }
-    db->nChunks = 0;
     db->nUnits = (int32_t)units.size();
 
     int rc;
@@ -1592,7 +1619,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 #undef TRY
 #undef TRYHIP
     DbView &v = db->v;
-    v.nbp = db->nbp; v.nCtg = db->nCtg; v.nT = db->nT; v.nChunks = db->nChunks; v.nFiles = db->nFiles;
+    v.nbp = db->nbp; v.nCtg = db->nCtg; v.nT = db->nT; v.nFiles = db->nFiles;
     v.shift = -1;
     for (int b = 0; b < 31; b++)
         if (db->nbp == (1 << b)) v.shift = b;
