@@ -24,11 +24,11 @@ all: $(LIB)/libigd_hip.so $(LIB)/libigd.so $(LIB)/libigd_py.so $(LIB)/libigdr.so
 $(LIB) bin:
 	mkdir -p $@
 
-$(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip include/igd_hip.h | $(LIB)
-	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $< -lpthread
+$(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip $(SRC)/igd_create.hip include/igd_hip.h | $(LIB)
+	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $(SRC)/igd_hip.hip $(SRC)/igd_create.hip -lpthread
 
-CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_create_min.c
-CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create_min.h include/igd_hip.h
+CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_create.c
+CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create.h include/igd_hip.h
 
 $(LIB)/libigd.so: $(SRC)/igd_cli_abi.c $(CORE_SRC) $(CORE_HDR) include/igd_search.h include/igd_base.h $(LIB)/libigd_hip.so
 	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_cli_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)

@@ -59,6 +59,17 @@ class HipDesc(C.Structure):
                 ("fd", C.c_int), ("fd_offset", C.c_int64)]
 
 
+class HipCreateDesc(C.Structure):
+    _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("n", C.c_int64),
+                ("ctg", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p), ("value", C.c_void_p),
+                ("file", C.c_void_p)]
+
+
+class HipCreated(C.Structure):
+    _fields_ = [("nTile", C.c_void_p), ("nCnt", C.c_void_p), ("nTiles", C.c_int64), ("nRecords", C.c_int64),
+                ("records", C.c_void_p)]
+
+
 class HipHit(C.Structure):
     _fields_ = [("q", C.c_int32), ("idx", C.c_int32), ("start", C.c_int32), ("end", C.c_int32)]
 
@@ -132,8 +143,34 @@ def hip():
         L.igd_hip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]
         L.igd_hip_scan_kernel_name.restype = C.c_char_p
+        L.igd_hip_create.argtypes = [C.POINTER(HipCreateDesc), C.c_int, C.POINTER(HipCreated)]
+        L.igd_hip_created_free.argtypes = [C.POINTER(HipCreated)]
         _hip = L
     return _hip
+
+
+def create_arrays(nbp, gtype, nctg, ctg, start, end, value, file, device=0):
+    """igd_hip_create on numpy int32 arrays -> dict(nTile, nCnt, records[nRecords, 4|3])."""
+    import numpy as np
+    L = hip()
+    arrs = [np.ascontiguousarray(a, dtype=np.int32) if a is not None else None for a in (ctg, start, end, value, file)]
+    p = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in arrs]
+    d = HipCreateDesc(int(nbp), int(gtype), int(nctg), len(arrs[0]), p[0], p[1], p[2], p[3], p[4])
+    out = HipCreated()
+    rc = L.igd_hip_create(C.byref(d), int(device), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("igd_hip_create failed (%d): %s" % (rc, L.igd_hip_last_error().decode()))
+    try:
+        w = 3 if gtype == 0 else 4
+        ntile = np.ctypeslib.as_array(C.cast(out.nTile, C.POINTER(C.c_int32)), (max(int(nctg), 1),))[:nctg].copy()
+        ncnt = np.ctypeslib.as_array(C.cast(out.nCnt, C.POINTER(C.c_int32)), (max(int(out.nTiles), 1),))[:out.nTiles].copy()
+        if out.nRecords > 0:
+            recs = np.ctypeslib.as_array(C.cast(out.records, C.POINTER(C.c_int32)), (int(out.nRecords), w)).copy()
+        else:
+            recs = np.zeros((0, w), np.int32)
+    finally:
+        L.igd_hip_created_free(C.byref(out))
+    return {"nTile": ntile, "nCnt": ncnt, "records": recs}
 
 
 def _bind_core(L):

@@ -94,6 +94,7 @@ static void set_err(const char *what, hipError_t e, const char *file, int line)
     } while (0)
 
 extern "C" const char *igd_hip_last_error(void) { return g_err; }
+extern "C" void igd_hip_set_error_(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }   // igd_create.hip
 
 extern "C" int igd_hip_device_count(void)
 {

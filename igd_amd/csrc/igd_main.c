@@ -7,7 +7,7 @@
 #include <sysexits.h>
 
 #include "igd_search.h"
-#include "igd_create_min.h"
+#include "igd_create.h"
 
 static int usage(int code)
 {
@@ -15,7 +15,7 @@ static int usage(int code)
             "igd (MI355X-native overlap search)\n"
             "usage:   igd <command> [options]\n"
             "         search    Search an igd database on the GPU\n"
-            "         create    Create an igd database (minimal writer)\n");
+            "         create    Create an igd database\n");
     return code;
 }
 
@@ -23,7 +23,7 @@ int main(int argc, char **argv)
 {
     if (argc < 2) return usage(0);
     if (strcmp(argv[1], "search") == 0) return igd_search(argc, argv);
-    if (strcmp(argv[1], "create") == 0) return igd_create_min(argc, argv);
+    if (strcmp(argv[1], "create") == 0) return igd_create(argc, argv);
     fprintf(stderr, "Unknown command\n");
     return usage(EX_USAGE);
 }

@@ -9,7 +9,7 @@
 
 #include "igd_py_abi.h"
 #include "igd_core.h"
-#include "igd_create_min.h"
+#include "igd_create.h"
 
 struct iGD_t {
     igdc_db *core;          /* NULL until open_iGD */
@@ -78,8 +78,16 @@ void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_si
         free(probe);
         return;
     }
+    igdc_create_opts o;
+    o.ipath = iPath; o.opath = oPath; o.name = igdName;
+    o.nbp = tile_size > 0 ? tile_size : 16384;
+    o.mode = IGDC_CREATE_GLOB; o.msg = IGDC_MSG_PY; o.linebuf = 256;       /* src_py/igd_create.c:70 */
+    const char *dv = getenv("IGD_DEVICE");
+    o.device = dv ? atoi(dv) : 0;
+    const int rc = igdc_create(&o);
+    if (rc != 0 && rc != -1) die_no_gpu("create_iGD", rc);
+    if (rc == 0 && iGD) open_iGD(iGD, probe);                              /* src_py/igd_create.c:140-141 */
     free(probe);
-    igdc_create_from_beds(iPath, oPath, igdName, tile_size > 0 ? tile_size : 16384, 1);
 }
 
 void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)

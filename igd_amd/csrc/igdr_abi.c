@@ -3,11 +3,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sysexits.h>
 
 #include "igdr_abi.h"
 #include "igd_core.h"
-#include "igd_create_min.h"
+#include "igd_create.h"
 
 struct iGD_t {
     igdc_db *core;
@@ -120,19 +121,37 @@ void getOverlaps(char **igdFile, char **qFile, int64_t *hits)
     close_iGD(h);
 }
 
-static void create_common(char **iPath, char **oPath, char **igdName, int *binsize)
+/* create_iGD / create_iGD_f, IGDr/src/igd_create.c:19-170, :173-319 (.C: every argument a pointer) */
+static void create_common(char **iPath, char **oPath, char **igdName, int *binsize, int mode)
 {
-    size_t li = strlen(*iPath);
-    char *pat = (char *)malloc(li + 4);
-    strcpy(pat, *iPath);
-    if (li && pat[li - 1] == '/') strcat(pat, "*");
-    else if (li && pat[li - 1] != '*') strcat(pat, "/*");
-    igdc_create_from_beds(pat, *oPath, *igdName, (binsize && *binsize > 0) ? *binsize : 16384, 1);
-    free(pat);
+    const size_t li = strlen(*iPath), lo = strlen(*oPath);
+    char *in = (char *)malloc(li + 4), *out = (char *)malloc(lo + 4);
+    strcpy(in, *iPath);
+    strcpy(out, *oPath);
+    if (lo == 0 || out[lo - 1] != '/') strcat(out, "/");
+    if (mode == IGDC_CREATE_GLOB && li > 0) {
+        if (in[li - 1] == '/') strcat(in, "*");
+        else if (in[li - 1] != '*') strcat(in, "/*");
+    }
+    const size_t L = strlen(out) + strlen(*igdName) + 8;
+    char *probe = (char *)malloc(L);
+    snprintf(probe, L, "%s%s.igd", out, *igdName);
+    struct stat st;
+    if (stat(probe, &st) == 0) printf("The igd database file %s exists!\n", probe);
+    else {
+        igdc_create_opts o;
+        o.ipath = in; o.opath = out; o.name = *igdName;
+        o.nbp = (binsize && *binsize > 0) ? *binsize : 16384;
+        o.mode = mode; o.msg = IGDC_MSG_R; o.linebuf = 256;
+        const char *dv = getenv("IGD_DEVICE");
+        o.device = dv ? atoi(dv) : 0;
+        const int rc = igdc_create(&o);
+        if (rc != 0 && rc != -1) die_no_gpu("create_iGD", rc);
+    }
+    free(probe); free(in); free(out);
 }
-void create_iGD(char **iPath, char **oPath, char **igdName, int *binsize) { create_common(iPath, oPath, igdName, binsize); }
-/* the reference's _f variant reads a file LIST; the minimal writer takes globs only */
-void create_iGD_f(char **iPath, char **oPath, char **igdName, int *binsize) { create_common(iPath, oPath, igdName, binsize); }
+void create_iGD(char **iPath, char **oPath, char **igdName, int *binsize) { create_common(iPath, oPath, igdName, binsize, IGDC_CREATE_GLOB); }
+void create_iGD_f(char **iPath, char **oPath, char **igdName, int *binsize) { create_common(iPath, oPath, igdName, binsize, IGDC_CREATE_LIST); }
 
 #ifdef IGDR_HAVE_R
 /* ---- .Call entry points (need R's headers; not compiled in the build container) ------- */

@@ -139,6 +139,28 @@ void igd_hip_free(void *p);
  * gType-1 databases only.  Blocking. */
 int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total);
 
+/* `igd create`: intervals -> the tile region of an .igd, on the GPU.
+ * Replaces igd_add (src/igd_base.c:118-169: replicate into tiles start/nbp..(end-1)/nbp),
+ * igd_saveT (:333-364: per-tile append in input order) and igd_save (:396-461: per-tile
+ * radix_sort_intv, src/igd_base.h:196-249, then contig-major concatenation).  The records come
+ * out in EXACTLY the reference's order, including its (unstable) order of equal starts.
+ * Input: n intervals in input order (files in glob order, lines in file order), every one with
+ * 0 <= start < end; ctg[] = contig numbers in first-seen order, file[] = index of the source
+ * file (gdata_t.idx); value may be NULL (0).  Host arrays; nothing is retained. */
+typedef struct {
+    int32_t nbp, gType, nCtg;
+    int64_t n;
+    const int32_t *ctg, *start, *end, *value, *file;
+} igd_hip_create_desc;
+typedef struct {
+    int32_t *nTile;           /* [nCtg]   tiles per contig = 1 + max (end-1)/nbp               */
+    int32_t *nCnt;            /* [nTiles] records per tile, contig-major (the header table)     */
+    int64_t nTiles, nRecords;
+    void *records;            /* nRecords x 16 (gType 1) or 12 (gType 0) bytes, file order, pinned */
+} igd_hip_created;
+int  igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_created *out);
+void igd_hip_created_free(igd_hip_created *c);
+
 /* Instrumentation ------------------------------------------------------------------- */
 /* Exact algorithmic-work terms for a device-resident batch (blocking). */
 int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,

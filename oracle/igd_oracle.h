@@ -106,6 +106,16 @@ int64_t orc_enumerate_batch(orc_db *db, const int32_t *ichr, const int32_t *qs, 
  * progress!=NULL receives the reference's progress lines ("%i\n" every 1000 tiles, :783-784). */
 int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *progress);
 
+/* ---- `igd create`, SURVEY 8f row f4 (igd_oracle_create.c) ------------------------------ */
+enum { ORC_CREATE_GLOB = 0, ORC_CREATE_LIST = 1, ORC_CREATE_GTYPE0 = 2, ORC_CREATE_BED4 = 3 };
+/* src/igd_create.c:25-433 + igd_add/igd_saveT/igd_save (src/igd_base.c:118-169, :333-461):
+ * writes <opath><name>.igd and <opath><name>_index.tsv; `out` receives the reference's stdout text. */
+int  orc_create(const char *ipath, const char *opath, const char *name, int32_t nbp, int mode, FILE *out);
+int  orc_igd_create(int argc, char **argv, FILE *out);            /* src/igd_create.c:436-501 */
+/* radix_sort_intv (src/igd_base.h:196-249) applied to n (start, payload) pairs in place: the
+ * exact, unstable order the reference leaves records of one tile in. */
+void orc_tile_sort(int32_t *key, int32_t *src, int64_t n);
+
 /* ---- `igd search` driver (stdout text identical to src/igd_search.c:889-1079) ----- */
 int orc_igd_search(int argc, char **argv, FILE *out);
 

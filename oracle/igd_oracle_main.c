@@ -11,6 +11,8 @@ int main(int argc, char **argv)
 {
     if (argc >= 2 && strcmp(argv[1], "search") == 0)
         return orc_igd_search(argc, argv, stdout);
+    if (argc >= 2 && strcmp(argv[1], "create") == 0)
+        return orc_igd_create(argc, argv, stdout);
     if (argc >= 5 && strcmp(argv[1], "stats") == 0) {
         orc_db *db = orc_open(argv[2]);
         if (!db) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
