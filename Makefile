@@ -13,7 +13,7 @@ CC      ?= gcc
 ARCH    ?= gfx950
 CFLAGS  ?= -O2 -g -std=gnu99 -Wall -Wextra -Wno-unused-parameter -fPIC
 HIPFLAGS?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -Wall -Wno-unused-function $(EXTRA)
-INC     := -Iinclude -Iigd_amd/csrc
+INC     := -Iinclude -Iigd_amd/csrc -Itools
 SRC     := igd_amd/csrc
 LIB     ?= igd_amd/lib
 RPATH   := -Wl,-rpath,'$$ORIGIN' -Wl,-Bsymbolic-functions
@@ -41,14 +41,14 @@ R_INC := $(shell R RHOME >/dev/null 2>&1 && echo "-DIGDR_HAVE_R -I`R RHOME`/incl
 $(LIB)/libigdr.so: $(SRC)/igdr_abi.c $(CORE_SRC) $(CORE_HDR) include/igdr_abi.h $(LIB)/libigd_hip.so
 	$(CC) $(CFLAGS) $(INC) $(R_INC) -shared -o $@ $(SRC)/igdr_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
-$(LIB)/libigd_synth.so: tools/igd_synth.c $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so
-	$(CC) $(CFLAGS) $(INC) -shared -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
+$(LIB)/libigd_synth.so: tools/igd_synth.c tools/igd_synth_writer.c tools/igd_synth_writer.h $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so
+	$(CC) $(CFLAGS) $(INC) -shared -o $@ tools/igd_synth.c tools/igd_synth_writer.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)
 
 bin/igd: $(SRC)/igd_main.c $(LIB)/libigd.so | bin
 	$(CC) $(CFLAGS) $(INC) -o $@ $(SRC)/igd_main.c -L$(LIB) -ligd -ligd_hip -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
 
-bin/igd_synth: tools/igd_synth.c $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so | bin
-	$(CC) $(CFLAGS) $(INC) -DIGD_SYNTH_MAIN -o $@ tools/igd_synth.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
+bin/igd_synth: tools/igd_synth.c tools/igd_synth_writer.c $(SRC)/igd_core.c $(CORE_HDR) $(LIB)/libigd_hip.so | bin
+	$(CC) $(CFLAGS) $(INC) -DIGD_SYNTH_MAIN -o $@ tools/igd_synth.c tools/igd_synth_writer.c $(SRC)/igd_core.c -L$(LIB) -ligd_hip -lz -lpthread -Wl,-rpath,'$$ORIGIN/../igd_amd/lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -62,7 +62,7 @@ class HipDesc(C.Structure):
 class HipCreateDesc(C.Structure):
     _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("n", C.c_int64),
                 ("ctg", C.c_void_p), ("start", C.c_void_p), ("end", C.c_void_p), ("value", C.c_void_p),
-                ("file", C.c_void_p)]
+                ("file", C.c_void_p), ("ctgName", C.c_void_p), ("out_fd", C.c_int)]
 
 
 class HipCreated(C.Structure):
@@ -155,7 +155,7 @@ def create_arrays(nbp, gtype, nctg, ctg, start, end, value, file, device=0):
     L = hip()
     arrs = [np.ascontiguousarray(a, dtype=np.int32) if a is not None else None for a in (ctg, start, end, value, file)]
     p = [a.ctypes.data_as(C.c_void_p) if a is not None else None for a in arrs]
-    d = HipCreateDesc(int(nbp), int(gtype), int(nctg), len(arrs[0]), p[0], p[1], p[2], p[3], p[4])
+    d = HipCreateDesc(int(nbp), int(gtype), int(nctg), len(arrs[0]), p[0], p[1], p[2], p[3], p[4], None, -1)
     out = HipCreated()
     rc = L.igd_hip_create(C.byref(d), int(device), C.byref(out))
     if rc != 0:
@@ -187,7 +187,6 @@ def _bind_core(L):
     L.igdc_parse_bed.argtypes = [C.c_char_p, i32p, i32p, C.c_int]
     L.igdc_read_queries.argtypes = [C.POINTER(CoreDb), C.c_char_p, C.c_int, C.POINTER(CoreQueries)]
     L.igdc_queries_free.argtypes = [C.POINTER(CoreQueries)]
-    L.igdc_create_from_beds.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
     return L
 
 

@@ -12,9 +12,6 @@
  *   igdc_parse_bed      parse_bed    src/igd_base.c:53-72
  *   igdc_lines_*        ks_getuntil  src/kseq.h:82-130 over gzread (src/igd_base.h:192)
  *   igdc_read_queries   the read/parse/lookup part of getOverlaps src/igd_search.c:708-714
- *   igdc_write_igd      igd_add + igd_save src/igd_base.c:118-174,396-461 (format only:
- *                       tests and the benchmark need to MAKE .igd files; `igd create`
- *                       itself is out of scope)
  */
 #ifndef IGD_CORE_H
 #define IGD_CORE_H
@@ -78,17 +75,6 @@ typedef struct {
 int  igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out);
 void igdc_queries_free(igdc_queries *q);
 int  igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe);
-
-/* ---- minimal writer (format of SURVEY.md App. A) ------------------------------------- */
-typedef struct { int32_t file, ctg, start, end, value; } igdc_interval;
-/* Intervals in source order (file by file, line by line); start>=end is dropped like
- * igd_add does (src/igd_base.c:120), and so is start<=-nbp (negative tile index there).  Each interval is copied to
- * every tile start/nbp..(end-1)/nbp; tiles are stable-sorted by start.  Writes
- * <igd_path> and its _index.tsv (nr/avg = lines and mean length per file, as given). */
-int igdc_write_igd(const char *igd_path, int32_t nbp, int32_t gType, int32_t nCtg,
-                   const char *const *ctgNames, int64_t n, const igdc_interval *iv,
-                   int32_t nFiles, const char *const *fileNames, const int32_t *nr,
-                   const double *avg);
 
 #ifdef __cplusplus
 }

@@ -36,11 +36,19 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include "igd_core.h"
 #include "igd_create.h"
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 /* ---- small string dictionary: name -> dense id in first-seen order --------------------------- */
 typedef struct {
@@ -288,6 +296,33 @@ static void *pool_run(void *arg)
     return NULL;
 }
 
+/* per-file arrays -> one array per column at the file's offset, contig numbers made global */
+typedef struct {
+    part *parts; int32_t nparts; const int64_t *poff; int32_t **map;
+    int32_t *ctg, *start, *end, *value, *file;
+    volatile int32_t next;
+} gather;
+
+static void *gather_run(void *arg)
+{
+    gather *G = (gather *)arg;
+    for (;;) {
+        const int32_t f = __sync_fetch_and_add(&G->next, 1);
+        if (f >= G->nparts) break;
+        part *P = &G->parts[f];
+        const int64_t o0 = G->poff[f];
+        const int32_t *map = G->map[f];
+        for (int64_t i = 0; i < P->n; i++) G->ctg[o0 + i] = map[P->ctg[i]];
+        memcpy(G->start + o0, P->start, sizeof(int32_t) * (size_t)P->n);
+        memcpy(G->end + o0, P->end, sizeof(int32_t) * (size_t)P->n);
+        memcpy(G->value + o0, P->value, sizeof(int32_t) * (size_t)P->n);
+        memcpy(G->file + o0, P->file, sizeof(int32_t) * (size_t)P->n);
+        free(P->ctg); free(P->start); free(P->end); free(P->value); free(P->file);
+        P->ctg = P->start = P->end = P->value = P->file = NULL;
+    }
+    return NULL;
+}
+
 static int n_threads(int32_t nf)
 {
     long n = sysconf(_SC_NPROCESSORS_ONLN);
@@ -300,36 +335,6 @@ static int n_threads(int32_t nf)
 }
 
 /* ---- writing ----------------------------------------------------------------------------------- */
-static int write_all(int fd, const void *p, size_t n)
-{
-    const char *c = (const char *)p;
-    while (n > 0) {
-        const ssize_t w = write(fd, c, n > (1u << 30) ? (1u << 30) : n);
-        if (w < 0) { if (errno == EINTR) continue; return -1; }
-        c += w; n -= (size_t)w;
-    }
-    return 0;
-}
-
-static int write_igd(const char *path, int32_t nbp, int32_t gType, const strdict *ctg, const igd_hip_created *C)
-{
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    if (fd < 0) { printf("Can't open file %s", path); return -1; }
-    const int32_t m = ctg->n;
-    const size_t hdr = 12 + 4 * (size_t)m + 4 * (size_t)C->nTiles + 40 * (size_t)m;
-    char *h = (char *)calloc(1, hdr);
-    memcpy(h, &nbp, 4); memcpy(h + 4, &gType, 4); memcpy(h + 8, &m, 4);
-    memcpy(h + 12, C->nTile, 4 * (size_t)m);
-    memcpy(h + 12 + 4 * (size_t)m, C->nCnt, 4 * (size_t)C->nTiles);
-    char *nm = h + 12 + 4 * (size_t)m + 4 * (size_t)C->nTiles;
-    for (int32_t i = 0; i < m; i++) strncpy(nm + 40 * (size_t)i, ctg->name[i], 39);
-    int rc = write_all(fd, h, hdr);
-    if (rc == 0 && C->nRecords > 0) rc = write_all(fd, C->records, (size_t)C->nRecords * (gType == 0 ? 12 : 16));
-    free(h);
-    close(fd);
-    return rc;
-}
-
 /* _index.tsv, src/igd_create.c:93-110 */
 static void write_index(const char *path, char **files, int32_t nf, const int32_t *nr, const double *avg,
                         int64_t *nT, double *l_avg)
@@ -362,6 +367,9 @@ int igdc_create(const igdc_create_opts *o)
     memset(&datasets, 0, sizeof datasets);
     int32_t *ds_nr = NULL; double *ds_avg = NULL; int32_t ds_cap = 0;
     mkdir(o->opath, 0777);
+    const int timing = getenv("IGD_TIMING") != NULL;
+    double t0 = now_s(), t1;
+#define PHASE(what) do { if (timing) { t1 = now_s(); fprintf(stderr, "[igd create] %-28s %9.3f ms\n", what, 1e3 * (t1 - t0)); t0 = t1; } } while (0)
 
     /* 1. the input files */
     if (o->mode == IGDC_CREATE_BED4) {
@@ -441,6 +449,7 @@ int igdc_create(const igdc_create_opts *o)
         }
     }
 
+    PHASE("parse (host threads)");
     int32_t *nr = NULL; double *avg = NULL;
     char **idxNames = files;
     int32_t nIdx = nf;
@@ -461,17 +470,24 @@ int igdc_create(const igdc_create_opts *o)
     end = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
     value = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
     file = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
-    for (int32_t f = 0; f < nparts; f++) {
-        part *P = &parts[f];
-        int32_t *map = (int32_t *)malloc(sizeof(int32_t) * (size_t)(P->names.n ? P->names.n : 1));
-        for (int32_t k = 0; k < P->names.n; k++) map[k] = dict_id(&contigs, P->names.name[k], (size_t)P->names.len[k]);
-        const int64_t o0 = poff[f];
-        for (int64_t i = 0; i < P->n; i++) ctg[o0 + i] = map[P->ctg[i]];
-        memcpy(start + o0, P->start, sizeof(int32_t) * (size_t)P->n);
-        memcpy(end + o0, P->end, sizeof(int32_t) * (size_t)P->n);
-        memcpy(value + o0, P->value, sizeof(int32_t) * (size_t)P->n);
-        memcpy(file + o0, P->file, sizeof(int32_t) * (size_t)P->n);
-        free(map);
+    {
+        gather G;
+        G.parts = parts; G.nparts = nparts; G.poff = poff; G.next = 0;
+        G.ctg = ctg; G.start = start; G.end = end; G.value = value; G.file = file;
+        G.map = (int32_t **)calloc((size_t)(nparts ? nparts : 1), sizeof(int32_t *));
+        for (int32_t f = 0; f < nparts; f++) {              /* sequential: this IS the first-seen order */
+            part *P = &parts[f];
+            G.map[f] = (int32_t *)malloc(sizeof(int32_t) * (size_t)(P->names.n ? P->names.n : 1));
+            for (int32_t k = 0; k < P->names.n; k++)
+                G.map[f][k] = dict_id(&contigs, P->names.name[k], (size_t)P->names.len[k]);
+        }
+        const int nt = n_threads(nparts);
+        pthread_t th[64];
+        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, gather_run, &G);
+        gather_run(&G);
+        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+        for (int32_t f = 0; f < nparts; f++) free(G.map[f]);
+        free(G.map);
     }
     if (o->mode == IGDC_CREATE_BED4) {
         nIdx = datasets.n; idxNames = datasets.name;
@@ -488,18 +504,28 @@ int igdc_create(const igdc_create_opts *o)
         for (int32_t ig = 1; nf10 > 0 && ig <= nf; ig++) if (ig % nf10 == 0) printf(".");
     }
 
+    PHASE("concatenate + contig ids");
     /* 4. the GPU: replicate into tiles, order every tile like the reference, gather the records */
     {
         igd_hip_create_desc D;
         D.nbp = o->nbp; D.gType = o->mode == IGDC_CREATE_GTYPE0 ? 0 : 1; D.nCtg = contigs.n; D.n = n;
         D.ctg = ctg; D.start = start; D.end = end; D.value = o->mode == IGDC_CREATE_GTYPE0 ? NULL : value; D.file = file;
+        D.ctgName = (const char *const *)contigs.name;
+        const size_t L = strlen(o->opath) + strlen(o->name) + 16;
+        char *path = (char *)malloc(L);
+        snprintf(path, L, "%s%s.igd", o->opath, o->name);
+        D.out_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);   /* the engine streams header + tiles into it */
+        if (D.out_fd < 0) { printf("Can't open file %s", path); free(path); rc = -1; goto out; }
+        free(path);
         rc = igd_hip_create(&D, o->device, &C);
+        close(D.out_fd);
         if (rc != IGD_HIP_OK) {
             fprintf(stderr, "igd create: the GPU engine failed (%d): %s\n"
                             "igd create: this build has no CPU path.\n", rc, igd_hip_last_error());
             goto out;
         }
     }
+    PHASE("igd_hip_create (GPU + .igd)");
     if (cli && (o->mode == IGDC_CREATE_GLOB || o->mode == IGDC_CREATE_LIST || (o->mode == IGDC_CREATE_BED4 && datasets.n > 0)))
         printf("nCtgs, nRegions, nTiles: %i\t %lld\t %lld\n", contigs.n, (long long)C.nRecords, (long long)C.nTiles);
     if (cli && (o->mode == IGDC_CREATE_GLOB || o->mode == IGDC_CREATE_LIST)) printf("\n");
@@ -513,13 +539,12 @@ int igdc_create(const igdc_create_opts *o)
         snprintf(path, L, "%s%s_index.tsv", o->opath, o->name);
         write_index(path, idxNames, nIdx, nr, avg, &nT, &l_avg);
         if ((cli && (o->mode == IGDC_CREATE_GTYPE0 || o->mode == IGDC_CREATE_BED4)) || py) printf("igd_create 3\n");
-        snprintf(path, L, "%s%s.igd", o->opath, o->name);
-        if (write_igd(path, o->nbp, o->mode == IGDC_CREATE_GTYPE0 ? 0 : 1, &contigs, &C) != 0) rc = -1;
         if ((cli && (o->mode == IGDC_CREATE_GTYPE0 || o->mode == IGDC_CREATE_BED4)) || py) printf("igd_create 4\n");
         else if (cli) printf("Save igd database to %s%s.igd\n", o->opath, o->name);
         if (cli) printf("Total intervals, l_avg:  %lld %12.3f\n", (long long)nT, l_avg / nT);
         if (rr) printf("igd_create done!\n");
         free(path);
+        PHASE("write _index.tsv");
     }
 out:
     igd_hip_created_free(&C);

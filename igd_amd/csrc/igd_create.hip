@@ -35,6 +35,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <errno.h>
+#include <unistd.h>
 
 #include "igd_hip.h"
 
@@ -50,6 +52,23 @@ extern "C" void igd_hip_set_error_(const char *msg);       // igd_hip.hip
             rc = IGD_HIP_ERR_DEVICE;                                                  \
             goto done;                                                                \
         }                                                                             \
+    } while (0)
+
+#include <chrono>
+static double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// IGD_TIMING=1: wall time of each phase (the stream is drained at every mark, so the sum is a little
+// above an untimed run)
+#define MARK(what)                                                                                   \
+    do {                                                                                             \
+        if (timing) {                                                                                \
+            (void)hipStreamSynchronize(st);                                                          \
+            const double t_ = now_ms();                                                              \
+            fprintf(stderr, "[igd_hip_create] %-26s %9.3f ms\n", what, t_ - tmark);                  \
+            tmark = t_;                                                                              \
+        }                                                                                            \
     } while (0)
 
 #define WAVE 64
@@ -425,6 +444,17 @@ __global__ void __launch_bounds__(WAVE) k_tile_sort(TileArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+static int write_all(int fd, const void *p, size_t n)
+{
+    const char *c = (const char *)p;
+    while (n > 0) {
+        const ssize_t w = write(fd, c, n > ((size_t)1 << 30) ? ((size_t)1 << 30) : n);
+        if (w < 0) { if (errno == EINTR) continue; return -1; }
+        c += w; n -= (size_t)w;
+    }
+    return 0;
+}
+
 extern "C" void igd_hip_created_free(igd_hip_created *c)
 {
     if (!c) return;
@@ -467,6 +497,8 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
     int64_t *tbase = nullptr;
     int64_t nTiles = 0, R = 0, maxTile = 0;
     int cus = 256;
+    const bool timing = getenv("IGD_TIMING") != nullptr;
+    double tmark = now_ms();
     {
         CHK(hipSetDevice(device));
         hipDeviceProp_t prop;
@@ -492,6 +524,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
             CHK(hipMemcpyAsync(dv, d->value, (size_t)n * 4, hipMemcpyHostToDevice, st));
         }
         CHK(hipMemsetAsync(dmT, 0, (size_t)(nCtg > 0 ? nCtg : 1) * 4, st));
+        MARK("init + malloc + H2D");
         const int64_t nbScanN = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
         // 1. spans, tiles per contig
         if (n > 0) {
@@ -514,6 +547,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
         out->nCnt = (int32_t *)calloc((size_t)(nTiles > 0 ? nTiles : 1), sizeof(int32_t));
         if (!out->nCnt) { rc = IGD_HIP_ERR_NOMEM; goto done; }
         if (R == 0) goto done;
+        MARK("span + scan");
         // 3. pairs + tile counts
         const size_t rb4 = (size_t)R * 4;
         CHK(hipMalloc(&kA, rb4)); CHK(hipMalloc(&vA, rb4)); CHK(hipMalloc(&kB, rb4)); CHK(hipMalloc(&vB, rb4));
@@ -534,6 +568,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
             CHK(e); CHK(e2);
         }
         for (int64_t t = 0; t < nTiles; t++) if (out->nCnt[t] > maxTile) maxTile = out->nCnt[t];
+        MARK("expand + tile offsets");
         // 5. stable radix sort of the pairs by tile number
         {
             const int64_t nBlocks = (R + RS_BLOCK - 1) / RS_BLOCK;
@@ -558,6 +593,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
             (void)hipFree(sumsH);
             CHK(e); CHK(e2);
         }
+        MARK("radix sort by tile");
         // 6. the reference's sort inside every tile + gather into records
         (void)hipFree(kB); kB = nullptr;
         (void)hipFree(vB); vB = nullptr;
@@ -578,11 +614,59 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
             k_tile_sort<<<(unsigned)(want > 0 ? want : 1), WAVE, 0, st>>>(a);
             CHK(hipGetLastError());
         }
-        CHK(hipHostMalloc(&out->records, (size_t)R * recBytes, hipHostMallocDefault));
-        CHK(hipMemcpyAsync(out->records, dout, (size_t)R * recBytes, hipMemcpyDeviceToHost, st));
-        CHK(hipStreamSynchronize(st));
+        MARK("tile sort + gather");
+        if (d->out_fd < 0) {
+            CHK(hipHostMalloc(&out->records, (size_t)R * recBytes, hipHostMallocDefault));
+            MARK("pinned alloc");
+            CHK(hipMemcpyAsync(out->records, dout, (size_t)R * recBytes, hipMemcpyDeviceToHost, st));
+            CHK(hipStreamSynchronize(st));
+            MARK("D2H records");
+        }
     }
 done:
+    if (rc == IGD_HIP_OK && d->out_fd >= 0) {
+        // the .igd: header, then the tiles streamed through two pinned buffers
+        const size_t hdr = 12 + 4 * (size_t)nCtg + 4 * (size_t)nTiles + 40 * (size_t)nCtg;
+        char *h = (char *)calloc(1, hdr);
+        if (!h) rc = IGD_HIP_ERR_NOMEM;
+        else {
+            memcpy(h, &d->nbp, 4); memcpy(h + 4, &d->gType, 4); memcpy(h + 8, &nCtg, 4);
+            memcpy(h + 12, out->nTile, 4 * (size_t)nCtg);
+            memcpy(h + 12 + 4 * (size_t)nCtg, out->nCnt, 4 * (size_t)nTiles);
+            char *nm = h + 12 + 4 * (size_t)nCtg + 4 * (size_t)nTiles;
+            for (int32_t i = 0; i < nCtg; i++)
+                if (d->ctgName && d->ctgName[i]) strncpy(nm + 40 * (size_t)i, d->ctgName[i], 39);
+            if (write_all(d->out_fd, h, hdr) != 0) { igd_hip_set_error_("igd_hip_create: write failed"); rc = IGD_HIP_ERR_ARG; }
+            free(h);
+        }
+        const size_t total = (size_t)R * recBytes, CH = (size_t)32 << 20;
+        char *stage[2] = { nullptr, nullptr };
+        hipEvent_t ev[2] = { nullptr, nullptr };
+        if (rc == IGD_HIP_OK && total > 0) {
+            bool ok = hipHostMalloc((void **)&stage[0], CH, hipHostMallocDefault) == hipSuccess &&
+                      hipHostMalloc((void **)&stage[1], CH, hipHostMallocDefault) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            const size_t nch = (total + CH - 1) / CH;
+            for (size_t k = 0; ok && k <= nch; k++) {
+                if (k < nch) {
+                    const size_t len = k + 1 < nch ? CH : total - k * CH;
+                    ok = hipMemcpyAsync(stage[k & 1], (const char *)dout + k * CH, len, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipEventRecord(ev[k & 1], st) == hipSuccess;
+                }
+                if (ok && k > 0) {                       // chunk k-1 goes to the file while chunk k is in flight
+                    const size_t j = k - 1, len = j + 1 < nch ? CH : total - j * CH;
+                    ok = hipEventSynchronize(ev[j & 1]) == hipSuccess && write_all(d->out_fd, stage[j & 1], len) == 0;
+                }
+            }
+            if (!ok) { igd_hip_set_error_("igd_hip_create: streaming the records to the file failed"); rc = IGD_HIP_ERR_DEVICE; }
+            if (timing) { const double t_ = now_ms(); fprintf(stderr, "[igd_hip_create] %-26s %9.3f ms\n", "D2H + write (overlapped)", t_ - tmark); tmark = t_; }
+        }
+        if (stage[0]) (void)hipHostFree(stage[0]);
+        if (stage[1]) (void)hipHostFree(stage[1]);
+        if (ev[0]) (void)hipEventDestroy(ev[0]);
+        if (ev[1]) (void)hipEventDestroy(ev[1]);
+    }
     (void)hipFree(dc); (void)hipFree(ds); (void)hipFree(de); (void)hipFree(dv); (void)hipFree(df); (void)hipFree(dmT);
     (void)hipFree(dspan); (void)hipFree(kA); (void)hipFree(vA); (void)hipFree(kB); (void)hipFree(vB);
     (void)hipFree(dcnt); (void)hipFree(dhist); (void)hipFree(droff); (void)hipFree(dsums); (void)hipFree(dtot);

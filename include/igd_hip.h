@@ -146,11 +146,17 @@ int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64
  * out in EXACTLY the reference's order, including its (unstable) order of equal starts.
  * Input: n intervals in input order (files in glob order, lines in file order), every one with
  * 0 <= start < end; ctg[] = contig numbers in first-seen order, file[] = index of the source
- * file (gdata_t.idx); value may be NULL (0).  Host arrays; nothing is retained. */
+ * file (gdata_t.idx); value may be NULL (0).  Host arrays; nothing is retained.
+ * Output: out_fd < 0 -> the records come back in pinned host memory (igd_hip_created.records);
+ * out_fd >= 0 -> the engine writes the complete .igd (header of SURVEY.md App. A with ctgName[],
+ * zero-padded to 40 bytes, then the tiles) to that descriptor through two pinned staging buffers,
+ * device->host copies overlapping the write()s, and records stays NULL. */
 typedef struct {
     int32_t nbp, gType, nCtg;
     int64_t n;
     const int32_t *ctg, *start, *end, *value, *file;
+    const char *const *ctgName;   /* [nCtg], needed only with out_fd >= 0                       */
+    int out_fd;
 } igd_hip_create_desc;
 typedef struct {
     int32_t *nTile;           /* [nCtg]   tiles per contig = 1 + max (end-1)/nbp               */

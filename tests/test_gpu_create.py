@@ -218,3 +218,49 @@ def test_engine_c_abi_direct_and_python_flavour():
         same_igd(os.path.join(d, "out", "pydb.igd"), os.path.join(d, "o2", "pydb.igd"))
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_golden_smallrand_beds_give_the_reference_database():
+    """tests/golden/smallrand holds gzip'd BED inputs AND the db.igd the reference created from them
+    (-b 14): `bin/igd create` must reproduce that file (tile bytes included), and searching our file
+    must print what the reference printed when searching its own."""
+    from test_golden_oracle import materialize
+    d, dst, man = materialize("smallrand")
+    try:
+        p = subprocess.run([IGD_BIN, "create", os.path.join(dst, "beds") + "/", d + "/w", "db"], stdout=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0
+        same_igd(d + "/w/db.igd", os.path.join(dst, "db.igd"))
+        assert open(d + "/w/db_index.tsv", "rb").read() == open(os.path.join(dst, "db_index.tsv"), "rb").read()
+        for run in man["runs"]:
+            if run["args"][0] != "search" or "-m" in run["args"]:
+                continue
+            args = [d + "/w/db.igd" if x == "db.igd" else os.path.join(dst, x) if x.endswith(".bed") else x for x in run["args"]]
+            got = subprocess.run([IGD_BIN] + args, stdout=subprocess.PIPE, timeout=600).stdout.decode()
+            assert got.replace(d + "/w/db.igd", "db.igd") == open(os.path.join(dst, run["stdout"])).read().replace(os.path.join(dst, "db.igd"), "db.igd")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_fewer_than_ten_files_and_gtype0():
+    """the reference's default create divides by n_files/10 (SIGFPE below 10 files): ours must not."""
+    from helpers import Oracle, write_bed
+    d = short_tmpdir("igw")
+    try:
+        beds = os.path.join(d, "b")
+        os.makedirs(beds)
+        write_bed(os.path.join(beds, "a.bed"), [("chr1", 5, 50, "n", 3), ("chr2", 70000, 70001, "n", 9), ("chr1", 9, 9, "n", 1)])
+        write_bed(os.path.join(beds, "b.bed"), [("chr2", 16384, 40000, "n", 7)])
+        for gt in (1, 0):
+            out = os.path.join(d, "o%d" % gt)
+            p = subprocess.run([IGD_BIN, "create", beds, out, "x", "-s", str(gt)], stdout=subprocess.PIPE, timeout=600)
+            assert p.returncode == 0
+            o = Oracle(os.path.join(out, "x.igd"))
+            assert (o.nfiles, o.gtype, o.ctg_names()) == (2, gt, ["chr1", "chr2"])
+            h, _ = o.search(np.array([0, 1, 1], np.int32), np.array([0, 16000, 69999], np.int32), np.array([100, 17000, 70001], np.int32))
+            np.testing.assert_array_equal(h, [2, 0])       # query 2 starts in chr2's EMPTY tile 0: rule NEST drops it
+            o.close()
+        # a second create into the same place is refused like the reference refuses it
+        p = subprocess.run([IGD_BIN, "create", beds, os.path.join(d, "o1"), "x"], stdout=subprocess.PIPE, timeout=600)
+        assert b"exists!" in p.stdout
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

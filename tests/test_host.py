@@ -172,63 +172,6 @@ def test_bsearch_is_last_start_below_qe(N):
             assert L.bSearch(g.ctypes.data, 0, n - 1, qe) == want
 
 
-def test_product_writer_equals_reference_create_on_counts(N):
-    """smallrand: the same BED files through the product's minimal `create`; the oracle's counts
-    on that .igd must equal the reference's stdout on ITS .igd (tie order inside a tile may differ
-    -- the reference's radix sort is not stable -- so counts, not -f text)."""
-    d, dst, man = materialize("smallrand")
-    try:
-        out = os.path.join(d, "w")
-        os.makedirs(out)
-        L = N.cli()
-        assert L.igdc_create_from_beds((os.path.join(dst, "beds") + "/*").encode(), out.encode(), b"db", 16384, 1) == 0
-        mine = os.path.join(out, "db.igd")
-        ref_tsv = open(os.path.join(dst, "db_index.tsv")).read().splitlines()
-        my_tsv = open(os.path.join(out, "db_index.tsv")).read().splitlines()
-        assert [l.split("\t")[:3] for l in my_tsv] == [l.split("\t")[:3] for l in ref_tsv]
-        # same header tables as the reference's file
-        a, b = Oracle(mine, preload=False), Oracle(os.path.join(dst, "db.igd"), preload=False)
-        assert (a.nbp, a.gtype, a.nctg, a.nfiles, a.ctg_names()) == (b.nbp, b.gtype, b.nctg, b.nfiles, b.ctg_names())
-        lib = orc()
-        for i in range(a.nctg):
-            assert lib.orc_ntile(a.h, i) == lib.orc_ntile(b.h, i)
-            for j in range(lib.orc_ntile(a.h, i)):
-                assert lib.orc_ncnt(a.h, i, j) == lib.orc_ncnt(b.h, i, j)
-        a.close(); b.close()
-        for run in man["runs"][:2]:
-            args = [mine if x == "db.igd" else os.path.join(dst, x) if x == "q.bed" else x for x in run["args"]]
-            got = parse_hits_table(run_oracle_cli(args), 12)
-            want = parse_hits_table(open(os.path.join(dst, run["stdout"])).read(), 12)
-            np.testing.assert_array_equal(got[0], want[0])
-            assert got[1] == want[1]
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-
-
-def test_writer_handles_fewer_than_ten_files_and_gtype0(N):
-    """the reference's create divides by n_files/10 (SIGFPE below 10 files): ours must not."""
-    d = short_tmpdir("igw")
-    try:
-        beds = os.path.join(d, "b")
-        os.makedirs(beds)
-        write_bed(os.path.join(beds, "a.bed"), [("chr1", 5, 50, "n", 3), ("chr2", 70000, 70001, "n", 9), ("chr1", 9, 9, "n", 1)])
-        write_bed(os.path.join(beds, "b.bed"), [("chr2", 16384, 40000, "n", 7)])
-        L = N.cli()
-        for gt in (1, 0):
-            out = os.path.join(d, "o%d" % gt)
-            assert L.igdc_create_from_beds((beds + "/*").encode(), out.encode(), b"x", 16384, gt) == 0
-            o = Oracle(os.path.join(out, "x.igd"))
-            assert (o.nfiles, o.gtype, o.ctg_names()) == (2, gt, ["chr1", "chr2"])
-            h, _ = o.search(np.array([0, 1, 1], np.int32), np.array([0, 16000, 69999], np.int32), np.array([100, 17000, 70001], np.int32))
-            # query 2 starts in chr2's EMPTY tile 0: rule NEST drops it although tile 1 overlaps
-            np.testing.assert_array_equal(h, [2, 0])
-            if gt == 1:
-                np.testing.assert_array_equal(o.search(np.array([1], np.int32), np.array([16000], np.int32), np.array([17000], np.int32), 1)[0], [0, 1])
-            o.close()
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
-
-
 def test_generator_queries_sorted_and_reproducible(N):
     from igd_amd import synth
     a = synth.make_queries(5000, seed=7, genome=synth.HG38)

@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include "igd_core.h"
+#include "igd_synth_writer.h"
 
 static const char *HG38_NAME[24] = {"chr1", "chr2", "chr3", "chr4", "chr5", "chr6", "chr7", "chr8",
     "chr9", "chr10", "chr11", "chr12", "chr13", "chr14", "chr15", "chr16", "chr17", "chr18",
