@@ -28,7 +28,7 @@ $(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip $(SRC)/igd_create.hip include/igd_hip.h
 	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $(SRC)/igd_hip.hip $(SRC)/igd_create.hip -lpthread
 
 CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_create.c
-CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create.h include/igd_hip.h
+CORE_HDR := $(SRC)/igd_core.h $(SRC)/igd_create_host.h include/igd_create.h include/igd_hip.h
 
 $(LIB)/libigd.so: $(SRC)/igd_cli_abi.c $(CORE_SRC) $(CORE_HDR) include/igd_search.h include/igd_base.h $(LIB)/libigd_hip.so
 	$(CC) $(CFLAGS) $(INC) -shared -o $@ $(SRC)/igd_cli_abi.c $(CORE_SRC) -L$(LIB) -ligd_hip -lz -lpthread $(RPATH)

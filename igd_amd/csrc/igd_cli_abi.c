@@ -16,6 +16,8 @@
 
 #include "igd_search.h"
 #include "igd_core.h"
+#include "igd_create_host.h"
+#include "../../include/igd_create.h"
 
 /* IGD_TIMING=1: wall-clock phases of `igd search` on stderr (stdout stays the reference's) */
 static double now_s(void)
@@ -523,3 +525,24 @@ int igd_search(int argc, char **argv)                                        /* 
     free(g_core_path); g_core_path = NULL;
     return EX_OK;
 }
+
+/* ---- create_igd*, src/igd_create.h:10-14 --------------------------------------------------- */
+static void create_with(char *iPath, char *oPath, char *igdName, int mode)
+{
+    igdc_create_opts o;
+    o.ipath = iPath; o.opath = oPath; o.name = igdName;
+    o.nbp = tile_size > 0 ? tile_size : 16384;            /* igd_init, src/igd_base.c:522 */
+    o.mode = mode; o.msg = IGDC_MSG_CLI;
+    o.linebuf = mode == IGDC_CREATE_GTYPE0 ? 256 : 1024;
+    const char *dv = getenv("IGD_DEVICE");
+    o.device = dv ? atoi(dv) : 0;
+    const int rc = igdc_create(&o);
+    if (rc < 0) {
+        fprintf(stderr, "igd create: no usable GPU (%d): %s\n", rc, igd_hip_last_error());
+        exit(EX_UNAVAILABLE);
+    }
+}
+void create_igd(char *iPath, char *oPath, char *igdName) { create_with(iPath, oPath, igdName, IGDC_CREATE_GLOB); }
+void create_igd0(char *iPath, char *oPath, char *igdName) { create_with(iPath, oPath, igdName, IGDC_CREATE_GTYPE0); }
+void create_igd_f(char *iPath, char *oPath, char *igdName) { create_with(iPath, oPath, igdName, IGDC_CREATE_LIST); }
+void create_igd_bed4(char *iPath, char *oPath, char *igdName) { create_with(iPath, oPath, igdName, IGDC_CREATE_BED4); }

@@ -41,7 +41,7 @@
 #include <zlib.h>
 
 #include "igd_core.h"
-#include "igd_create.h"
+#include "igd_create_host.h"
 
 static double now_s(void)
 {
@@ -111,7 +111,7 @@ static void dict_free(strdict *d)
 static int load_file(const char *path, char **buf, size_t *len)
 {
     gzFile z = gzopen(path, "r");
-    if (!z) return -1;
+    if (!z) return 1;
     gzbuffer(z, 1 << 20);
     size_t cap = 1 << 22, n = 0;
     char *b = (char *)malloc(cap);
@@ -380,7 +380,7 @@ int igdc_create(const igdc_create_opts *o)
     } else if (o->mode == IGDC_CREATE_LIST) {               /* src/igd_create.c:131-163 */
         if (cli) printf("Create igd from %s: \n", o->ipath);
         FILE *fl = fopen(o->ipath, "r");
-        if (!fl) { printf("Can't open file %s", o->ipath); return -1; }
+        if (!fl) { printf("Can't open file %s", o->ipath); return 1; }
         char buf[1024];
         int32_t cap = 0;
         while (fgets(buf, 1024, fl) != NULL) {
@@ -398,13 +398,13 @@ int igdc_create(const igdc_create_opts *o)
             }
         }
         fclose(fl);
-        if (nf < 1) { printf("Too few files (add to path /*): %i\n", nf); free(files); return -1; }
+        if (nf < 1) { printf("Too few files (add to path /*): %i\n", nf); free(files); return 1; }
     } else {
         if (o->mode == IGDC_CREATE_GTYPE0 || py) { if (cli || py) printf("igd_create 0\n"); }
         else if (cli) printf("Create igd from %s: \n", o->ipath);
         if (glob(o->ipath, 0, NULL, &g) != 0) {
             printf(o->mode == IGDC_CREATE_GTYPE0 || py ? "wrong dir path: %s" : "wrong dir path: %s\n", o->ipath);
-            return -1;
+            return 1;
         }
         globbed = 1;
         files = g.gl_pathv;
@@ -422,7 +422,7 @@ int igdc_create(const igdc_create_opts *o)
     if (o->mode == IGDC_CREATE_BED4) {
         X.exact = 1; X.nCols = 32;                          /* src/igd_create.c:349 */
         parts[0].minC = COLCAP;
-        if (parse_file(&X, &parts[0], files[0], 0) != 0) rc = -1;
+        if (parse_file(&X, &parts[0], files[0], 0) != 0) rc = 1;
     } else {
         pool Q;
         Q.files = files; Q.nf = nf; Q.parts = parts; Q.mode = o->mode; Q.linebuf = o->linebuf; Q.next = 0;
@@ -433,7 +433,7 @@ int igdc_create(const igdc_create_opts *o)
         for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
         int minC = COLCAP, maxC = 0;
         for (int32_t f = 0; f < nf; f++) {
-            if (parts[f].failed) rc = -1;                   /* gzopen failed: the reference returns */
+            if (parts[f].failed) rc = 1;                   /* gzopen failed: the reference returns */
             if (parts[f].minC < minC) minC = parts[f].minC;
             if (parts[f].maxC > maxC) maxC = parts[f].maxC;
         }
@@ -515,10 +515,11 @@ int igdc_create(const igdc_create_opts *o)
         char *path = (char *)malloc(L);
         snprintf(path, L, "%s%s.igd", o->opath, o->name);
         D.out_fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);   /* the engine streams header + tiles into it */
-        if (D.out_fd < 0) { printf("Can't open file %s", path); free(path); rc = -1; goto out; }
-        free(path);
+        if (D.out_fd < 0) { printf("Can't open file %s", path); free(path); rc = 1; goto out; }
         rc = igd_hip_create(&D, o->device, &C);
         close(D.out_fd);
+        if (rc != IGD_HIP_OK) unlink(path);                  /* no half-written database left behind */
+        free(path);
         if (rc != IGD_HIP_OK) {
             fprintf(stderr, "igd create: the GPU engine failed (%d): %s\n"
                             "igd create: this build has no CPU path.\n", rc, igd_hip_last_error());
@@ -609,7 +610,7 @@ int igd_create(int argc, char **argv)
         const char *dv = getenv("IGD_DEVICE");
         o.device = dv ? atoi(dv) : 0;
         const int rc = igdc_create(&o);
-        if (rc != 0 && rc != -1) { free(probe); free(ipath); free(opath); return 1; }
+        if (rc < 0) { free(probe); free(ipath); free(opath); return 1; }
     }
     free(probe); free(ipath); free(opath);
     return 0;

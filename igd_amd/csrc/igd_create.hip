@@ -17,7 +17,8 @@
 // gather use all 64 lanes, the cycle-following runs on lane 0 over LDS -- and thousands of tiles
 // in flight.  Everything before it is ordinary data-parallel work:
 //
-//   k_span          per interval: tile span, per-contig tile count (max), replica count
+//   k_span          per interval: tile span, per-contig tile count (max), replica count; the
+//                   interval as one 16-byte record (so that the gather at the end is ONE access)
 //   scan            replica offsets (exclusive scan, int64)
 //   k_expand        (tile, interval) pairs in input order + per-tile counts
 //   scan            tile offsets
@@ -174,8 +175,10 @@ static hipError_t exclusive_scan(const T *in, int64_t n, O *out, int64_t *sums, 
 // ---------------------------------------------------------------------------------------------
 // igd_add, src/igd_base.c:124-126,131,145-147: tile span of every interval; mTiles[c] = 1 + max n2
 __global__ void __launch_bounds__(256) k_span(const int32_t *__restrict__ ctg, const int32_t *__restrict__ start,
-                                              const int32_t *__restrict__ end, int64_t n, int32_t nbp, int32_t nCtg,
-                                              uint32_t *__restrict__ span, int32_t *__restrict__ mTiles)
+                                              const int32_t *__restrict__ end, const int32_t *__restrict__ value,
+                                              const int32_t *__restrict__ file, int64_t n, int32_t nbp, int32_t nCtg,
+                                              uint32_t *__restrict__ span, int32_t *__restrict__ mTiles,
+                                              int4 *__restrict__ rec4)
 {
     __shared__ int32_t lmax[CTG_LDS];
     const bool in_lds = nCtg <= CTG_LDS;
@@ -184,8 +187,10 @@ __global__ void __launch_bounds__(256) k_span(const int32_t *__restrict__ ctg, c
         __syncthreads();
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t n1 = start[i] / nbp, n2 = (end[i] - 1) / nbp;
+        const int32_t s = start[i], e = end[i];
+        const int32_t n1 = s / nbp, n2 = (e - 1) / nbp;
         span[i] = (uint32_t)(n2 - n1 + 1);
+        rec4[i] = make_int4(file[i], s, e, value ? value[i] : 0);      // the record as the .igd stores it: ONE gather later
         const int32_t c = ctg[i];
         if (in_lds) {
             if (lmax[c] < n2 + 1) atomicMax(&lmax[c], n2 + 1);
@@ -297,7 +302,7 @@ struct KV { int32_t key; uint32_t rec; };
 struct TileArgs {
     const int64_t *tileOff;                       // [nTiles+1]
     const uint32_t *vals;                         // intervals of every tile, input order
-    const int32_t *start, *end, *value, *file;
+    const int4 *rec4;                             // {idx,start,end,value} per interval
     void *out;                                    // AoS records
     KV *scratch;                                  // R entries: tiles larger than TS_CAP sort here
     int2 *gstack;                                 // R/64 + nTiles entries (segments of big tiles)
@@ -309,14 +314,11 @@ struct TileArgs {
 
 __device__ __forceinline__ void emit_record(const TileArgs &a, int64_t at, KV e)
 {
+    const int4 r = a.rec4[e.rec];                 // the line was fetched when the key was read: an L2 hit
     if (a.gType == 0) {
         int32_t *o = (int32_t *)a.out + at * 3;
-        o[0] = a.file[e.rec]; o[1] = e.key; o[2] = a.end[e.rec];
-    } else {
-        int4 r;
-        r.x = a.file[e.rec]; r.y = e.key; r.z = a.end[e.rec]; r.w = a.value ? a.value[e.rec] : 0;
-        ((int4 *)a.out)[at] = r;
-    }
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else ((int4 *)a.out)[at] = r;
 }
 
 __global__ void __launch_bounds__(WAVE) k_tile_sort(TileArgs a)
@@ -346,7 +348,7 @@ __global__ void __launch_bounds__(WAVE) k_tile_sort(TileArgs a)
 
         for (int32_t i = lane; i < n; i += WAVE) {
             const uint32_t rec = a.vals[off + i];
-            KV e; e.key = a.start[rec]; e.rec = rec;
+            KV e; e.key = a.rec4[rec].y; e.rec = rec;
             A[i] = e;
         }
         __syncthreads();
@@ -490,6 +492,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
     uint32_t *dspan = nullptr, *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr, *dcnt = nullptr, *dhist = nullptr;
     int64_t *droff = nullptr, *dsums = nullptr, *dtot = nullptr, *dtbase = nullptr, *dtoff = nullptr, *ddig = nullptr;
     KV *dscr = nullptr;
+    int4 *drec = nullptr;
     int2 *dgst = nullptr;
     int8_t *dgsh = nullptr;
     unsigned int *dnext = nullptr;
@@ -510,7 +513,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
         if (!out->nTile || !tbase) { rc = IGD_HIP_ERR_NOMEM; goto done; }
         const size_t nb4 = (size_t)(n > 0 ? n : 1) * 4;
         CHK(hipMalloc(&dc, nb4)); CHK(hipMalloc(&ds, nb4)); CHK(hipMalloc(&de, nb4)); CHK(hipMalloc(&df, nb4));
-        CHK(hipMalloc(&dspan, nb4)); CHK(hipMalloc(&droff, nb4 * 2));
+        CHK(hipMalloc(&dspan, nb4)); CHK(hipMalloc(&droff, nb4 * 2)); CHK(hipMalloc(&drec, nb4 * 4));
         CHK(hipMalloc(&dmT, (size_t)(nCtg > 0 ? nCtg : 1) * 4));
         CHK(hipMalloc(&dtbase, ((size_t)nCtg + 1) * 8));
         CHK(hipMalloc(&dtot, 64));
@@ -528,7 +531,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
         const int64_t nbScanN = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
         // 1. spans, tiles per contig
         if (n > 0) {
-            k_span<<<cus * 8, 256, 0, st>>>(dc, ds, de, n, d->nbp, nCtg, dspan, dmT);
+            k_span<<<cus * 8, 256, 0, st>>>(dc, ds, de, dv, df, n, d->nbp, nCtg, dspan, dmT, drec);
             CHK(hipGetLastError());
         }
         CHK(hipMemcpyAsync(out->nTile, dmT, (size_t)nCtg * 4, hipMemcpyDeviceToHost, st));
@@ -607,7 +610,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
         CHK(hipMemsetAsync(dnext, 0, 4, st));
         {
             TileArgs a;
-            a.tileOff = dtoff; a.vals = vA; a.start = ds; a.end = de; a.value = dv; a.file = df;
+            a.tileOff = dtoff; a.vals = vA; a.rec4 = drec;
             a.out = dout; a.scratch = dscr; a.gstack = dgst; a.gshift = dgsh; a.next = dnext;
             a.nTiles = nTiles; a.gType = d->gType;
             const int64_t want = nTiles < (int64_t)cus * 14 ? nTiles : (int64_t)cus * 14;
@@ -671,7 +674,7 @@ done:
     (void)hipFree(dspan); (void)hipFree(kA); (void)hipFree(vA); (void)hipFree(kB); (void)hipFree(vB);
     (void)hipFree(dcnt); (void)hipFree(dhist); (void)hipFree(droff); (void)hipFree(dsums); (void)hipFree(dtot);
     (void)hipFree(dtbase); (void)hipFree(dtoff); (void)hipFree(ddig); (void)hipFree(dscr); (void)hipFree(dgst);
-    (void)hipFree(dgsh); (void)hipFree(dnext); (void)hipFree(dout);
+    (void)hipFree(dgsh); (void)hipFree(dnext); (void)hipFree(dout); (void)hipFree(drec);
     if (st) (void)hipStreamDestroy(st);
     free(tbase);
     if (rc != IGD_HIP_OK) igd_hip_created_free(out);

@@ -1,6 +1,6 @@
-/* igd_create.h -- host side of `igd create`; see igd_create.c. */
-#ifndef IGD_CREATE_H
-#define IGD_CREATE_H
+/* igd_create_host.h -- host side of `igd create`; see igd_create.c. */
+#ifndef IGD_CREATE_HOST_H
+#define IGD_CREATE_HOST_H
 #include <stdint.h>
 #include <stdio.h>
 #ifdef __cplusplus
@@ -28,8 +28,8 @@ typedef struct {
     int device;               /* GPU                                                                 */
 } igdc_create_opts;
 
-/* 0, or -1 when nothing was written (bad path / unreadable file: the reference returns silently),
- * or an IGD_HIP_ERR_* of the engine (no GPU: there is no CPU path). */
+/* 0; 1 when nothing was written (bad path / unreadable file: the reference returns silently);
+ * < 0: an IGD_HIP_ERR_* of the engine (no GPU: there is no CPU path). */
 int igdc_create(const igdc_create_opts *o);
 
 /* `igd create <in> <out> <name> [-b 11..19] [-s 0|1|2] [-f]`, src/igd_create.c:436-501 */

@@ -7,7 +7,7 @@
 #include <sysexits.h>
 
 #include "igd_search.h"
-#include "igd_create.h"
+#include "igd_create_host.h"
 
 static int usage(int code)
 {

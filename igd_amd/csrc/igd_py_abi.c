@@ -9,7 +9,7 @@
 
 #include "igd_py_abi.h"
 #include "igd_core.h"
-#include "igd_create.h"
+#include "igd_create_host.h"
 
 struct iGD_t {
     igdc_db *core;          /* NULL until open_iGD */
@@ -85,7 +85,7 @@ void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_si
     const char *dv = getenv("IGD_DEVICE");
     o.device = dv ? atoi(dv) : 0;
     const int rc = igdc_create(&o);
-    if (rc != 0 && rc != -1) die_no_gpu("create_iGD", rc);
+    if (rc < 0) die_no_gpu("create_iGD", rc);
     if (rc == 0 && iGD) open_iGD(iGD, probe);                              /* src_py/igd_create.c:140-141 */
     free(probe);
 }

@@ -8,7 +8,7 @@
 
 #include "igdr_abi.h"
 #include "igd_core.h"
-#include "igd_create.h"
+#include "igd_create_host.h"
 
 struct iGD_t {
     igdc_db *core;
@@ -146,7 +146,7 @@ static void create_common(char **iPath, char **oPath, char **igdName, int *binsi
         const char *dv = getenv("IGD_DEVICE");
         o.device = dv ? atoi(dv) : 0;
         const int rc = igdc_create(&o);
-        if (rc != 0 && rc != -1) die_no_gpu("create_iGD", rc);
+        if (rc < 0) die_no_gpu("create_iGD", rc);
     }
     free(probe); free(in); free(out);
 }

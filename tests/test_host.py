@@ -188,7 +188,7 @@ def test_generator_queries_sorted_and_reproducible(N):
 # --------------------------------------------------------------------------------------------
 # C ABI surface
 HEADER_LIBS = {"igd_hip.h": "libigd_hip.so", "igd_search.h": "libigd.so", "igd_base.h": "libigd.so",
-               "igd_py_abi.h": "libigd_py.so", "igdr_abi.h": "libigdr.so"}
+               "igd_py_abi.h": "libigd_py.so", "igdr_abi.h": "libigdr.so", "igd_create.h": "libigd.so"}
 
 
 def _declared_functions(header):
@@ -235,3 +235,21 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback(N):
     # ... and the package never imports the oracle
     src = "".join(open(os.path.join(ROOT, "igd_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "igd_amd")) if f.endswith(".py"))
     assert "oracle" not in src.lower().replace("no cpu", "")
+
+
+def test_create_without_gpu_fails_loudly_and_leaves_no_database(N):
+    """`igd create` has no CPU path either: on a GPU-less host it must say so, exit non-zero and not
+    leave a half-written .igd behind."""
+    if N.hip().igd_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    d = short_tmpdir("igc")
+    try:
+        os.makedirs(d + "/in")
+        write_bed(d + "/in/a.bed", [("chr1", 5, 50, "n", 3)])
+        p = subprocess.run([os.path.join(ROOT, "bin", "igd"), "create", d + "/in", d + "/out", "db"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode != 0
+        assert b"no CPU path" in p.stderr
+        assert not os.path.exists(d + "/out/db.igd")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
