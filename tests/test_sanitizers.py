@@ -31,7 +31,11 @@ def sanbin():
     src = ["igd_amd/csrc/igd_main.c", "igd_amd/csrc/igd_cli_abi.c", "igd_amd/csrc/igd_core.c", "igd_amd/csrc/igd_create.c"]
     subprocess.check_call(["gcc", "-std=gnu99", *SAN, "-Iinclude", "-Iigd_amd/csrc", "-o", igd, *src,
                            "-Ligd_amd/lib", "-ligd_hip", "-lz", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "igd_amd/lib")], cwd=ROOT)
-    yield {"orc": orc, "igd": igd, "dir": d}
+    ing = os.path.join(d, "ingest_san")
+    subprocess.check_call(["gcc", "-std=gnu99", *SAN, "-Iinclude", "-Iigd_amd/csrc", "-o", ing, "tests/c/ingest_san_main.c",
+                           "igd_amd/csrc/igd_core.c", "-Ligd_amd/lib", "-ligd_hip", "-lz", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "igd_amd/lib")], cwd=ROOT)
+    yield {"orc": orc, "igd": igd, "ingest": ing, "dir": d}
     shutil.rmtree(d, ignore_errors=True)
 
 
@@ -104,5 +108,35 @@ def test_search_host_code_clean_until_the_gpu_is_needed(sanbin):
         shutil.copytree(case, dst)
         for run in json.load(open(os.path.join(case, "manifest.json")))["runs"][:4]:
             run_clean([sanbin["igd"]] + run["args"], cwd=dst)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_query_ingest_clean_threaded_and_sequential(sanbin):
+    """igdc_read_queries on the parse fixtures (odd lines, CRLF, gz) and on a large text that takes the
+    threaded path; threaded and sequential runs must agree."""
+    d = short_tmpdir("igs")
+    try:
+        case = os.path.join(GOLDEN, "parse")
+        beds = sorted(glob.glob(case + "/*.bed*"))
+        assert beds
+        rng = random.Random(4)
+        big = d + "/big.bed"
+        with open(big, "w") as fh:
+            for i in range(300000):
+                c = rng.choice(["chr1", "chr2", "chrX", "chr9", "1", "chr"])
+                s = rng.randrange(0, 10 ** 7)
+                fh.write("%s\t%d\t%d%s\n" % (c, s, s + rng.randrange(-5, 5000), rng.choice(["", "\tname\t5", "\r"])))
+            fh.write("chr1\t5")                                   # no newline at EOF, short line
+        for bed in beds + [big]:
+            for rc in ("1", "0"):
+                outs = []
+                for env in ({}, {"IGD_PARSE_SEQUENTIAL": "1"}, {"IGD_PARSE_THREADS": "7"}):
+                    p = subprocess.run([sanbin["ingest"], case + "/db.igd", bed, rc], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                       env=dict(ENV, **env), timeout=600)
+                    err = p.stderr.decode(errors="replace")
+                    assert "AddressSanitizer" not in err and "runtime error" not in err and p.returncode == 0, err[-3000:]
+                    outs.append(p.stdout.split()[:2])
+                assert outs[0] == outs[1] == outs[2], (bed, rc, outs)
     finally:
         shutil.rmtree(d, ignore_errors=True)
