@@ -626,6 +626,193 @@ int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *pro
 }
 
 /* ------------------------------ `igd search` driver -------------------------------- */
+/* ------------------------------ Seqpare (`search -q f.bed -s`) ---------------------------
+ * SURVEY 8f row f4.  seq_overlaps src/igd_search.c:253-352, seqOverlaps :354-451,
+ * readBED / ailist_add src/igd_base.c:601-649, output :1054-1061.  gType-1 databases only (the
+ * reference reads 16-byte records unconditionally).
+ *
+ * Two library-dependent details of the reference are fixed here the way glibc <= 2.36 behaves
+ * (its qsort is a stable merge sort whenever the temporary buffer can be allocated):
+ *   - queries of a contig are ordered by start, ties in file order   (qsort(compare_qstart), :370)
+ *   - overlaps of a query by dataset index, ties in discovery order  (qsort(compare_fidx),  :382)
+ * The reference's quirk idx_t = n1 (the QUERY's first tile, also for records found in later
+ * tiles, :291,:337) is kept: a "column" is (index inside its tile, first tile of the query). */
+typedef struct { int32_t idx_t, idx_g, idx_f; float sm; } sq_ovl;
+typedef struct { int32_t start, end; } sq_iv;
+typedef struct { char *name; sq_iv *iv; int64_t n, cap; } sq_ctg;
+
+static void sq_push(sq_ovl **L, int32_t *nn, int32_t *mm, int32_t it, int32_t ig, int32_t f, float sm)
+{
+    if (*nn == *mm) { *mm = *mm ? 2 * *mm : 1024; *L = (sq_ovl *)realloc(*L, sizeof(sq_ovl) * (size_t)*mm); }
+    sq_ovl *p = &(*L)[(*nn)++];
+    p->idx_t = it; p->idx_g = ig; p->idx_f = f; p->sm = sm;
+}
+
+/* seq_overlaps, src/igd_search.c:253-352 */
+static void sq_overlaps(orc_db *db, const char *chrm, int32_t qs, int32_t qe, sq_ovl **L, int32_t *nn, int32_t *mm)
+{
+    const float qlen = (float)(qe - qs);
+    const int32_t ichr = orc_get_id(db, chrm);
+    if (ichr < 0) return;
+    int32_t n1 = qs / db->nbp, n2 = (qe - 1) / db->nbp;
+    const int32_t mTile = db->nTile[ichr] - 1;
+    if (n1 > mTile || n1 < 0) return;
+    if (n2 > mTile) n2 = mTile;
+    int32_t cnt = db->nCnt[ichr][n1];
+    if (cnt <= 0) return;                                   /* everything is nested in if(tmpi>0), :266 */
+    const int rs = db->rs;
+    const int32_t *g = fetch_tile(db, ichr, n1, cnt);
+    if (qe > R_START(g, rs, 0)) {
+        const int32_t tL = bisect_inline(g, rs, cnt, qe);
+        for (int32_t i = tL; i >= 0; i--)
+            if (R_END(g, rs, i) > qs) {
+                const int32_t re = R_END(g, rs, i), r0 = R_START(g, rs, i);
+                const float st = (float)((qe < re ? qe : re) - (qs > r0 ? qs : r0));
+                const float rlen = (float)(re - r0);
+                sq_push(L, nn, mm, n1, i, R_IDX(g, rs, i), st / (qlen + rlen - st));
+            }
+    }
+    int32_t bd = db->nbp * (n1 + 1);
+    for (int32_t j = n1 + 1; j <= n2; j++, bd += db->nbp) {
+        cnt = db->nCnt[ichr][j];
+        if (cnt <= 0) continue;
+        g = fetch_tile(db, ichr, j, cnt);
+        if (qe <= R_START(g, rs, 0)) continue;
+        int32_t tS = 0;
+        while (tS < cnt && R_START(g, rs, tS) < bd) tS++;
+        const int32_t tL = bisect_inline(g, rs, cnt, qe);
+        for (int32_t i = tL; i >= tS; i--)
+            if (R_END(g, rs, i) > qs) {
+                const int32_t re = R_END(g, rs, i), r0 = R_START(g, rs, i);
+                const float st = (float)((qe < re ? qe : re) - (qs > r0 ? qs : r0));
+                const float rlen = (float)(re - r0);
+                sq_push(L, nn, mm, n1, i, R_IDX(g, rs, i), st / (qlen + rlen - st));    /* idx_t = n1, :337 */
+            }
+    }
+}
+
+static void sq_stable_sort_iv(sq_iv *a, int64_t n)          /* by start, ties keep their order */
+{
+    if (n < 2) return;
+    sq_iv *t = (sq_iv *)malloc(sizeof(sq_iv) * (size_t)n), *src = a, *dst = t;
+    for (int64_t w = 1; w < n; w <<= 1) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = (src[j].start < src[i].start) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        sq_iv *x = src; src = dst; dst = x;
+    }
+    if (src != a) memcpy(a, src, sizeof(sq_iv) * (size_t)n);
+    free(t);
+}
+
+static void sq_stable_sort_ovl(sq_ovl *a, int64_t n)        /* by idx_f, ties keep their order */
+{
+    if (n < 2) return;
+    sq_ovl *t = (sq_ovl *)malloc(sizeof(sq_ovl) * (size_t)n), *src = a, *dst = t;
+    for (int64_t w = 1; w < n; w <<= 1) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) dst[k++] = (src[j].idx_f < src[i].idx_f) ? src[j++] : src[i++];
+            while (i < mid) dst[k++] = src[i++];
+            while (j < hi) dst[k++] = src[j++];
+        }
+        sq_ovl *x = src; src = dst; dst = x;
+    }
+    if (src != a) memcpy(a, src, sizeof(sq_ovl) * (size_t)n);
+    free(t);
+}
+
+/* seqOverlaps, src/igd_search.c:354-451.  sm[nFiles].  Returns 0, -1 if the file cannot be read. */
+int orc_seqOverlaps(orc_db *db, const char *qfile, double *sm)
+{
+    lreader r;
+    if (lr_open(&r, qfile) != 0) return -1;
+    sq_ctg *ctg = NULL;
+    int32_t nctg = 0, mctg = 0;
+    while (lr_next(&r) >= 0) {                                /* readBED, src/igd_base.c:628-649 */
+        int32_t st, en;
+        char *name = orc_parse_bed(r.line, &st, &en);
+        if (!name) continue;
+        if ((uint32_t)st > (uint32_t)en) continue;             /* ailist_add: uint32 s > e, :603 */
+        int32_t k = 0;
+        while (k < nctg && strcmp(ctg[k].name, name) != 0) k++;
+        if (k == nctg) {
+            if (nctg == mctg) { mctg = mctg ? 2 * mctg : 32; ctg = (sq_ctg *)realloc(ctg, sizeof(sq_ctg) * (size_t)mctg); }
+            ctg[nctg].name = strdup(name); ctg[nctg].iv = NULL; ctg[nctg].n = ctg[nctg].cap = 0;
+            nctg++;
+        }
+        sq_ctg *c = &ctg[k];
+        if (c->n == c->cap) { c->cap = c->cap ? 2 * c->cap : 64; c->iv = (sq_iv *)realloc(c->iv, sizeof(sq_iv) * (size_t)c->cap); }
+        c->iv[c->n].start = st; c->iv[c->n].end = en; c->n++;
+    }
+    lr_close(&r);
+    const int32_t nfiles = db->nFiles;
+    int64_t Nq = 0;
+    db->preChr = -6; db->preIdx = -8;
+    for (int32_t m = 0; m < nfiles; m++) sm[m] = 0.0;
+    for (int32_t ci = 0; ci < nctg; ci++) {
+        sq_ctg *c = &ctg[ci];
+        const int64_t nq = c->n;
+        Nq += nq;
+        sq_stable_sort_iv(c->iv, nq);
+        sq_ovl **olps = (sq_ovl **)calloc((size_t)(nq ? nq : 1), sizeof(sq_ovl *));
+        int32_t *nh = (int32_t *)calloc((size_t)(nq ? nq : 1), sizeof(int32_t));
+        sq_ovl *L = NULL; int32_t nn = 0, mm = 0;
+        for (int64_t j = 0; j < nq; j++) {
+            nn = 0;
+            sq_overlaps(db, c->name, c->iv[j].start, c->iv[j].end, &L, &nn, &mm);
+            if (nn > 0) {
+                sq_stable_sort_ovl(L, nn);
+                olps[j] = (sq_ovl *)malloc(sizeof(sq_ovl) * (size_t)nn);
+                memcpy(olps[j], L, sizeof(sq_ovl) * (size_t)nn);
+            }
+            nh[j] = nn;
+        }
+        free(L);
+        int32_t *kst0 = (int32_t *)calloc((size_t)(nq ? nq : 1), sizeof(int32_t));
+        int32_t *kst = (int32_t *)calloc((size_t)(nq ? nq : 1), sizeof(int32_t));
+        int32_t *nst0 = (int32_t *)calloc((size_t)(nq ? nq : 1), sizeof(int32_t));
+        for (int32_t m = 0; m < nfiles; m++) {
+            float maxf = 0.0f;
+            int64_t maxj = 0; int32_t maxk = 0;
+            for (int64_t j = 0; j < nq; j++) {                /* 1. the best pair of dataset m, :392-409 */
+                int32_t k = kst[j];
+                while (k < nh[j] && olps[j][k].idx_f < m) k++;
+                kst0[j] = k;
+                while (k < nh[j] && olps[j][k].idx_f == m) {
+                    if (olps[j][k].sm > maxf) { maxf = olps[j][k].sm; maxk = k; maxj = j; }
+                    k++;
+                }
+                kst[j] = k;
+                nst0[j] = k - kst0[j];
+            }
+            while (maxf > 0.0f) {                             /* 2. take it, drop its row and column, :412-430 */
+                sm[m] += maxf;
+                nst0[maxj] = 0;
+                const int32_t it = olps[maxj][maxk].idx_t, ig = olps[maxj][maxk].idx_g;
+                maxf = 0.0f;
+                for (int64_t j = 0; j < nq; j++) {
+                    if (nst0[j] <= 0) continue;
+                    for (int32_t k = kst0[j]; k < kst0[j] + nst0[j]; k++) {
+                        if (olps[j][k].idx_g == ig && olps[j][k].idx_t == it) olps[j][k].sm = 0.0f;
+                        else if (olps[j][k].sm > maxf) { maxf = olps[j][k].sm; maxk = k; maxj = j; }
+                    }
+                }
+            }
+        }
+        free(nst0); free(kst); free(kst0); free(nh);
+        for (int64_t j = 0; j < nq; j++) free(olps[j]);
+        free(olps);
+    }
+    for (int32_t m = 0; m < nfiles; m++) sm[m] = sm[m] / ((double)Nq + db->fileNr[m] - sm[m]);   /* :446-449 */
+    for (int32_t k = 0; k < nctg; k++) { free(ctg[k].name); free(ctg[k].iv); }
+    free(ctg);
+    return 0;
+}
+
 /* src/igd_search.c:889-1079.  Same flag loop (:931-971), same dispatch (:975-1053), same
  * text.  `-m` and `-s` are outside the hot path and are not restated. */
 int orc_igd_search(int argc, char **argv, FILE *out)
@@ -702,8 +889,15 @@ int orc_igd_search(int argc, char **argv, FILE *out)
         fprintf(out, "index\t number of regions\t number of hits\t File_name\n");
         for (int32_t i = 0; i < db->nFiles; i++)
             fprintf(out, "%i\t%i\t%lld\t%s\n", i, db->fileNr[i], (long long)hits[i], db->fileName[i]);
+    } else if (mode == 3) {                                      /* :1054-1061          */
+        double *smv = (double *)calloc((size_t)db->nFiles + 1, sizeof(double));
+        orc_seqOverlaps(db, qfName, smv);
+        fprintf(out, "index\t number of regions\t similarity\t dataset name\n");
+        for (int32_t i = 0; i < db->nFiles; i++)
+            fprintf(out, "%i\t%i\t%10.6f\t%s\n", i, db->fileNr[i], smv[i], db->fileName[i]);
+        free(smv);
     } else {
-        fprintf(out, "oracle: mode not on the hot path (-m/-s) or missing -q/-r\n");
+        fprintf(out, "oracle: missing -q/-r\n");
     }
     free(hits);
     orc_close(db);

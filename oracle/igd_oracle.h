@@ -106,6 +106,10 @@ int64_t orc_enumerate_batch(orc_db *db, const int32_t *ichr, const int32_t *qs, 
  * progress!=NULL receives the reference's progress lines ("%i\n" every 1000 tiles, :783-784). */
 int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *progress);
 
+/* ---- Seqpare similarity (`search -q f.bed -s`), SURVEY 8f row f4 -------------------------- */
+/* seqOverlaps src/igd_search.c:354-451 over seq_overlaps :253-352: sm[nFiles].  0 / -1 (file). */
+int orc_seqOverlaps(orc_db *db, const char *qfile, double *sm);
+
 /* ---- `igd create`, SURVEY 8f row f4 (igd_oracle_create.c) ------------------------------ */
 enum { ORC_CREATE_GLOB = 0, ORC_CREATE_LIST = 1, ORC_CREATE_GTYPE0 = 2, ORC_CREATE_BED4 = 3 };
 /* src/igd_create.c:25-433 + igd_add/igd_saveT/igd_save (src/igd_base.c:118-169, :333-461):
