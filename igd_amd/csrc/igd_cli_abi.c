@@ -238,6 +238,94 @@ int64_t getOverlaps_v(char *qFile, int64_t *hits, int32_t v)                 /* 
     return file_query(qFile, v, IGD_HIP_RULE_FLAT, hits);
 }
 
+/* ------------------------------- Seqpare (-s) ------------------------------------------ */
+/* seqOverlaps, src/igd_search.c:354-451.  The query file is read like readBED reads it
+ * (src/igd_base.c:628-649: parse_bed's accept rule, ailist_add drops uint32 start > end), contigs in
+ * first-seen order, each contig's queries ordered by start with ties in file order (the reference's
+ * qsort(compare_qstart) is glibc's stable merge sort).  Enumeration, grouping, the greedy matching
+ * and the ordered double sums run on the GPU (igd_hip_seqpare); here only sm/(Nq + nr - sm). */
+typedef struct { char *name; int32_t id; int32_t *qs, *qe; int64_t n, cap; } sq_ctg;
+
+static void sq_sort(int32_t *qs, int32_t *qe, int64_t n)
+{
+    if (n < 2) return;
+    int32_t *ts = (int32_t *)malloc(sizeof(int32_t) * (size_t)n), *te = (int32_t *)malloc(sizeof(int32_t) * (size_t)n);
+    int32_t *as = qs, *ae = qe, *bs = ts, *be = te;
+    for (int64_t w = 1; w < n; w <<= 1) {
+        for (int64_t lo = 0; lo < n; lo += 2 * w) {
+            const int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int64_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                if (as[j] < as[i]) { bs[k] = as[j]; be[k++] = ae[j++]; }
+                else { bs[k] = as[i]; be[k++] = ae[i++]; }
+            }
+            while (i < mid) { bs[k] = as[i]; be[k++] = ae[i++]; }
+            while (j < hi) { bs[k] = as[j]; be[k++] = ae[j++]; }
+        }
+        int32_t *x = as; as = bs; bs = x;
+        x = ae; ae = be; be = x;
+    }
+    if (as != qs) { memcpy(qs, as, sizeof(int32_t) * (size_t)n); memcpy(qe, ae, sizeof(int32_t) * (size_t)n); }
+    free(ts); free(te);
+}
+
+void seqOverlaps(char *qFile, double *sm)
+{
+    iGD_t *G = cur_igd();
+    if (!G) return;
+    const int32_t nfiles = G->nFiles;
+    for (int32_t m = 0; m < nfiles; m++) sm[m] = 0.0;
+    igdc_lines *r = igdc_lines_open(qFile);
+    if (!r) return;                                           /* the reference dereferences NULL here */
+    sq_ctg *ctg = NULL;
+    int32_t nctg = 0, mctg = 0;
+    int64_t Nq = 0;
+    char *line;
+    while ((line = igdc_lines_next(r, NULL)) != NULL) {
+        int32_t st, en;
+        char *name = igdc_parse_bed(line, &st, &en, 1);
+        if (!name || (uint32_t)st > (uint32_t)en) continue;
+        int32_t k = nctg - 1;                                  /* BED files are grouped by contig */
+        while (k >= 0 && strcmp(ctg[k].name, name) != 0) k--;
+        if (k < 0) {
+            if (nctg == mctg) { mctg = mctg ? 2 * mctg : 32; ctg = (sq_ctg *)realloc(ctg, sizeof(sq_ctg) * (size_t)mctg); }
+            k = nctg++;
+            ctg[k].name = strdup(name); ctg[k].id = get_id(name);
+            ctg[k].qs = ctg[k].qe = NULL; ctg[k].n = ctg[k].cap = 0;
+        }
+        sq_ctg *c = &ctg[k];
+        if (c->n == c->cap) {
+            c->cap = c->cap ? 2 * c->cap : 64;
+            c->qs = (int32_t *)realloc(c->qs, sizeof(int32_t) * (size_t)c->cap);
+            c->qe = (int32_t *)realloc(c->qe, sizeof(int32_t) * (size_t)c->cap);
+        }
+        c->qs[c->n] = st; c->qe[c->n] = en; c->n++;
+        Nq++;
+    }
+    igdc_lines_close(r);
+    int64_t n = 0;
+    for (int32_t k = 0; k < nctg; k++) if (ctg[k].id >= 0) n += ctg[k].n;
+    int32_t *ichr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1)), *qs = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    int32_t *qe = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1)), *grp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
+    int64_t at = 0;
+    int32_t ng = 0;
+    for (int32_t k = 0; k < nctg; k++) {
+        if (ctg[k].id < 0) continue;                          /* unknown contig: counts in Nq, overlaps nothing */
+        sq_sort(ctg[k].qs, ctg[k].qe, ctg[k].n);
+        for (int64_t i = 0; i < ctg[k].n; i++, at++) { ichr[at] = ctg[k].id; qs[at] = ctg[k].qs[i]; qe[at] = ctg[k].qe[i]; grp[at] = ng; }
+        ng++;
+    }
+    double *sums = (double *)calloc((size_t)nfiles + 1, sizeof(double));
+    if (n > 0) {
+        const int rc = igd_hip_seqpare(engine(), ichr, qs, qe, n, grp, ng, sums);
+        if (rc != IGD_HIP_OK) die_no_gpu("seqpare", rc);
+    }
+    for (int32_t m = 0; m < nfiles; m++) sm[m] = sums[m] / ((double)Nq + G->finfo[m].nr - sums[m]);   /* :446-449 */
+    free(sums); free(ichr); free(qs); free(qe); free(grp);
+    for (int32_t k = 0; k < nctg; k++) { free(ctg[k].name); free(ctg[k].qs); free(ctg[k].qe); }
+    free(ctg);
+}
+
 /* ------------------------------- full enumeration (-f) -------------------------------- */
 typedef struct { char *buf; size_t n, cap; } obuf;
 static void ob_flush(obuf *o) { if (o->n) fwrite(o->buf, 1, o->n, stdout); o->n = 0; }
@@ -381,7 +469,7 @@ static int usage_search(void)
             "    -f                         print every overlap (with -q or -r)\n"
             "    -m                         dataset x dataset hit map, written to -o <name> (default Hitsmap)\n"
             "    -c                         accepted, no effect\n"
-            "    -s                         Seqpare: not part of this build\n"
+            "    -s                         Seqpare similarity of the query file with every dataset\n"
             "  environment: IGD_DEVICE=<n> selects the GPU (default 0)\n");
     return EX_OK;
 }
@@ -503,8 +591,16 @@ int igd_search(int argc, char **argv)                                        /* 
             for (int32_t i = 0; i < nfiles; i++) free(hitmap[i]);
             free(hitmap);
         }
-    } else if (mode == 3) {
-        printf("igd: -s (Seqpare) is not part of the MI355X search build\n");
+    } else if (mode == 3) {                                                   /* :1054-1061 */
+        if (IGD->gType != 1) printf("igd: -s needs a database created with 16-byte records (gType 1)\n");
+        else {
+            double *sm = (double *)malloc(sizeof(double) * (size_t)(nfiles + 1));
+            seqOverlaps(qfName, sm);
+            printf("index\t number of regions\t similarity\t dataset name\n");
+            for (int32_t i = 0; i < nfiles; i++)
+                printf("%i\t%i\t%10.6f\t%s\n", i, IGD->finfo[i].nr, sm[i], IGD->finfo[i].fileName);
+            free(sm);
+        }
     } else {
         free(hits);
         return usage_search();

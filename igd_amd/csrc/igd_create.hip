@@ -22,7 +22,7 @@
 //   scan            replica offsets (exclusive scan, int64)
 //   k_expand        (tile, interval) pairs in input order + per-tile counts
 //   scan            tile offsets
-//   k_rs_hist / k_rs_scatter   STABLE LSD byte radix sort of the pairs by tile number: afterwards
+//   ss_rs_hist / ss_rs_scatter   STABLE LSD byte radix sort of the pairs by tile number: afterwards
 //                   every tile holds its intervals in input order -- what the reference's temp
 //                   files hold (files in glob order, lines in file order)
 //   k_tile_sort     the reference's sort per tile, then gather {idx,start,end,value} -> AoS records
@@ -72,105 +72,10 @@ static double now_ms()
         }                                                                                            \
     } while (0)
 
-#define WAVE 64
-#define SCAN_WG 256
-#define SCAN_PER 8
-#define SCAN_TILE (SCAN_WG * SCAN_PER)
-#define RS_WG 256
-#define RS_WAVES (RS_WG / WAVE)
-#define RS_STRIPS 8                                  // strips of 64 per wave
-#define RS_BLOCK (RS_WG * RS_STRIPS)                 // 2048 pairs per workgroup
+#include "igd_sortscan.hpp"
+
 #define TS_CAP 1024                                  // tile records sorted in LDS; larger tiles in HBM scratch
 #define CTG_LDS 2048                                 // contigs whose tile count is reduced in LDS
-
-// ---------------------------------------------------------------------------------------------
-// exclusive scan, int64 result (three launches: tile sums, scan of sums by one workgroup, apply)
-template <typename T>
-__global__ void __launch_bounds__(SCAN_WG) k_scan_sums(const T *__restrict__ in, int64_t n, int64_t *__restrict__ sums)
-{
-    __shared__ int64_t red[SCAN_WG / WAVE];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    int64_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; k++) {
-        const int64_t i = base + k * SCAN_WG + threadIdx.x;
-        if (i < n) s += (int64_t)in[i];
-    }
-    for (int o = WAVE / 2; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int64_t t = 0;
-        for (int w = 0; w < SCAN_WG / WAVE; w++) t += red[w];
-        sums[blockIdx.x] = t;
-    }
-}
-
-__global__ void __launch_bounds__(1024) k_scan_of_sums(int64_t *__restrict__ sums, int64_t nb, int64_t *__restrict__ total)
-{
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    for (int64_t base = 0; base < nb; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t v = i < nb ? sums[i] : 0;
-        int64_t x = v;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const int64_t y = __shfl_up(x, o);
-            if (lane >= o) x += y;
-        }
-        if (lane == WAVE - 1) wsum[w] = x;
-        __syncthreads();
-        int64_t pre = carry;
-        for (int k = 0; k < w; k++) pre += wsum[k];
-        if (i < nb) sums[i] = pre + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = pre + x;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
-
-template <typename T, typename O>
-__global__ void __launch_bounds__(SCAN_WG) k_scan_apply(const T *__restrict__ in, int64_t n, const int64_t *__restrict__ sums, O *__restrict__ out)
-{
-    __shared__ int64_t wsum[SCAN_WG / WAVE];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_PER;
-    int64_t v[SCAN_PER], s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; k++) {
-        v[k] = base + k < n ? (int64_t)in[base + k] : 0;
-        s += v[k];
-    }
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    int64_t x = s;
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const int64_t y = __shfl_up(x, o);
-        if (lane >= o) x += y;
-    }
-    if (lane == WAVE - 1) wsum[w] = x;
-    __syncthreads();
-    int64_t pre = sums[blockIdx.x] + x - s;
-    for (int k = 0; k < w; k++) pre += wsum[k];
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; k++) {
-        if (base + k < n) out[base + k] = (O)pre;
-        pre += v[k];
-    }
-}
-
-template <typename T, typename O>
-static hipError_t exclusive_scan(const T *in, int64_t n, O *out, int64_t *sums, int64_t *d_total, hipStream_t st)
-{
-    if (n <= 0) return hipMemsetAsync(d_total, 0, 8, st);
-    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
-    k_scan_sums<T><<<(unsigned)nb, SCAN_WG, 0, st>>>(in, n, sums);
-    k_scan_of_sums<<<1, 1024, 0, st>>>(sums, nb, d_total);
-    k_scan_apply<T, O><<<(unsigned)nb, SCAN_WG, 0, st>>>(in, n, sums, out);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------------------------
 // igd_add, src/igd_base.c:124-126,131,145-147: tile span of every interval; mTiles[c] = 1 + max n2
@@ -219,79 +124,6 @@ __global__ void __launch_bounds__(256) k_expand(const int32_t *__restrict__ ctg,
             vals[o + j] = (uint32_t)i;
             atomicAdd(&tileCnt[t0 + j], 1u);
         }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Stable LSD radix sort by tile number, one byte per pass.
-// A workgroup owns RS_BLOCK consecutive pairs; wave w owns the w-th quarter, in strips of 64, so
-// "earlier in the input" = (lower block, lower wave, lower strip, lower lane).
-__global__ void __launch_bounds__(RS_WG) k_rs_hist(const uint32_t *__restrict__ keys, int64_t n, int shift,
-                                                   uint32_t *__restrict__ hist, int64_t nBlocks)
-{
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_BLOCK;
-#pragma unroll
-    for (int k = 0; k < RS_STRIPS; k++) {
-        const int64_t i = base + k * RS_WG + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-    }
-    __syncthreads();
-    hist[(int64_t)threadIdx.x * nBlocks + blockIdx.x] = h[threadIdx.x];      // digit-major: one scan gives every base
-}
-
-__global__ void __launch_bounds__(RS_WG) k_rs_scatter(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                      int64_t n, int shift, const int64_t *__restrict__ digitBase,
-                                                      int64_t nBlocks, uint32_t *__restrict__ keysOut,
-                                                      uint32_t *__restrict__ valsOut)
-{
-    __shared__ int64_t woff[RS_WAVES][256];
-    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
-    const int64_t base = (int64_t)blockIdx.x * RS_BLOCK + (int64_t)w * (RS_STRIPS * WAVE);
-    for (int k = 0; k < RS_WAVES; k++) woff[k][threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t key[RS_STRIPS], val[RS_STRIPS];
-#pragma unroll
-    for (int k = 0; k < RS_STRIPS; k++) {
-        const int64_t i = base + k * WAVE + lane;
-        key[k] = i < n ? keys[i] : 0xffffffffu;
-        val[k] = i < n ? vals[i] : 0u;
-        if (i < n) atomicAdd((unsigned long long *)&woff[w][(key[k] >> shift) & 255u], 1ull);
-    }
-    __syncthreads();
-    {   // digit d (= threadIdx.x): global base of this block, then the waves in order
-        int64_t g = digitBase[(int64_t)threadIdx.x * nBlocks + blockIdx.x];
-        for (int k = 0; k < RS_WAVES; k++) {
-            const int64_t t = woff[k][threadIdx.x];
-            woff[k][threadIdx.x] = g;
-            g += t;
-        }
-    }
-    __syncthreads();
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int k = 0; k < RS_STRIPS; k++) {
-        const int64_t i = base + k * WAVE + lane;
-        const bool valid = i < n;
-        const uint32_t d = (key[k] >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        if (valid) {
-            const int rank = __popcll(peers & lt);
-            const int64_t pos = woff[w][d] + rank;
-            keysOut[pos] = key[k];
-            valsOut[pos] = val[k];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (valid && (peers & lt) == 0) woff[w][d] += __popcll(peers);      // one leader per digit
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -582,16 +414,7 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
             CHK(hipMalloc(&sumsH, (size_t)((nh + SCAN_TILE - 1) / SCAN_TILE + 1) * 8));
             int bits = 0;
             while (bits < 32 && (nTiles - 1) >> bits) bits++;
-            hipError_t e = hipSuccess;
-            for (int shift = 0; shift < bits && e == hipSuccess; shift += 8) {
-                k_rs_hist<<<(unsigned)nBlocks, RS_WG, 0, st>>>(kA, R, shift, dhist, nBlocks);
-                e = exclusive_scan<uint32_t, int64_t>(dhist, nh, ddig, sumsH, dtot, st);
-                if (e != hipSuccess) break;
-                k_rs_scatter<<<(unsigned)nBlocks, RS_WG, 0, st>>>(kA, vA, R, shift, ddig, nBlocks, kB, vB);
-                e = hipGetLastError();
-                uint32_t *tk = kA; kA = kB; kB = tk;
-                uint32_t *tv = vA; vA = vB; vB = tv;
-            }
+            hipError_t e = radix_sort_pairs(&kA, &vA, &kB, &vB, R, bits, dhist, ddig, sumsH, dtot, st);
             hipError_t e2 = hipStreamSynchronize(st);
             (void)hipFree(sumsH);
             CHK(e); CHK(e2);

@@ -139,6 +139,15 @@ void igd_hip_free(void *p);
  * gType-1 databases only.  Blocking. */
 int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total);
 
+/* Seqpare (`search -q f.bed -s`): seqOverlaps src/igd_search.c:354-451 over
+ * seq_overlaps :253-352.  Queries as the reference orders them: the contigs of the query file in
+ * first-seen order, inside a contig by start (ties in file order); qgroup[i] = number of the query's
+ * contig in that order (0..nGroups-1, non-decreasing).  sums[m] (nFiles doubles) receives the sum of
+ * the greedily matched similarities of dataset m, added up in the reference's order; the caller
+ * finishes with sm = sums/(Nq + nr - sums) (:446-449).  gType-1 databases; one batch; blocking. */
+int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                    const int32_t *qgroup, int32_t nGroups, double *sums);
+
 /* `igd create`: intervals -> the tile region of an .igd, on the GPU.
  * Replaces igd_add (src/igd_base.c:118-169: replicate into tiles start/nbp..(end-1)/nbp),
  * igd_saveT (:333-364: per-tile append in input order) and igd_save (:396-461: per-tile

@@ -15,8 +15,9 @@
  * used the call prints the reason on stderr and aborts -- there is no CPU fallback.
  * GPU selection: environment variable IGD_DEVICE (default 0).
  *
- * Out of scope (declared by the reference, not provided here):
- * seq_overlaps/seqOverlaps (Seqpare).
+ * Seqpare: seqOverlaps (src/igd_search.c:354-451) is provided; its per-query helper seq_overlaps
+ * (:253-352, fills an overlaps_t for ONE query) is not -- the matching needs all queries at once and
+ * runs on the GPU.
  */
 #ifndef __IGD_SEARCH_H__
 #define __IGD_SEARCH_H__
@@ -44,6 +45,9 @@ int64_t getOverlaps_f0(char *qFile);                                            
  * the number of pairs counted */
 int64_t getMap(uint32_t **hitmap);                                                     /* :772-826 */
 int64_t getMap_v(uint32_t **hitmap, int32_t v);                                        /* :829-886 */
+
+/* `-s`: Seqpare similarity of the query file with every dataset; sm[nFiles] --------- */
+void seqOverlaps(char *qFile, double *sm);                                             /* :354-451 */
 
 /* `igd search <db.igd> [-q file | -r chr s e | -m] [-v N] [-f] [-o name] [-c]`        :889-1079 */
 int igd_search(int argc, char **argv);

@@ -6,6 +6,7 @@
   stdout.txt              its stdout (paths replaced by IN/ and OUT/)
   q.bed, search_f.txt     queries and the reference's `search -f` output on ref.igd (prints records in
                           tile order, i.e. it exposes the sort's order of equal starts)
+  search_s.txt            the reference's `search -q q.bed -s` (Seqpare) output on ref.igd
 """
 import os
 import random
@@ -48,5 +49,7 @@ for i in range(60):
 open(out + "/q.bed", "w").write("\n".join(q) + "\n")
 p = subprocess.run([REF_BIN, "search", tmp + "/o/db.igd", "-q", out + "/q.bed", "-f"], stdout=subprocess.PIPE, check=True)
 open(out + "/search_f.txt", "w").write(p.stdout.decode().replace(tmp + "/o/db.igd", "DB"))
+p = subprocess.run([REF_BIN, "search", tmp + "/o/db.igd", "-q", out + "/q.bed", "-s"], stdout=subprocess.PIPE, check=True)
+open(out + "/search_s.txt", "w").write(p.stdout.decode())
 shutil.rmtree(tmp, ignore_errors=True)
 print("wrote", out, {f: os.path.getsize(os.path.join(out, f)) for f in os.listdir(out) if os.path.isfile(os.path.join(out, f))})
