@@ -160,6 +160,7 @@ struct igd_hip_db {
     int32_t nUnits;
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
+    int32_t *d_qw;                // [wsQueries] per-query tile word of the merge join (k_query_bounds)
     char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
     size_t arenaSize, arenaUsed;
     int32_t epoch;                // batch counter: device-side flags are compared against it
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       const int32_t *__restrict__ qe, int nq, int rule,
                                                       int packed, int32_t *__restrict__ firstQ,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
-                                                      u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
+                                                      u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
+                                                      int32_t *__restrict__ qw)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST
@@ -305,6 +307,10 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
         const int prev = i ? tile_key(db, ichr[i - 1], qs[i - 1]) : -1;
         if (k < prev) ctl[CTL_UNSORTED] = epoch;
         lo = prev + 1; hi = k;
+        // The scan kernel's view of the query: (global number of its first tile) << 4 | min(n2 - n1, 15),
+        // -1 when it visits nothing (unknown contig, tile out of range) -- so that the scan does not
+        // redo the two divisions for every unit that looks at the query.
+        int word = -1;
         // what the scan kernel leaves to k_exact_walk
         if (c >= 0 && c < db.nCtg) {
             const int n1 = tile_of(db, s0);
@@ -313,11 +319,14 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                 const int e0 = qe[i];
                 int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
                 if (n2 > mT) n2 = mT;
+                const int span = n2 > n1 ? n2 - n1 : 0;
+                word = ((db.ctgBase[c] + n1) << 4) | (span < 15 ? span : 15);
                 if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
                 if (packed && e0 <= (int)((unsigned)n1 * (unsigned)db.nbp))
                     fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
             }
         }
+        qw[i] = word;
     }
     // short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
     // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
@@ -581,6 +590,7 @@ struct ScanArgs {
     const int2 *walkList;        // exact-walk list of this batch's path (k_exact_walk only)
     const int32_t *ctl;
     const int32_t *q_ichr, *q_qs, *q_qe;
+    const int32_t *q_w;          // merge join: per query (first global tile << 4 | span), from k_query_bounds
     int nq, v, rule, epoch;
     int mode;                    // 0: device decides (ctl[CTL_UNSORTED]); 1: sorted promised; 2: bucket
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
@@ -652,7 +662,7 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
     if (SORTED) {
         int i = r0 + lane;
         i = (active && i < r1) ? i : 0;
-        R.q0 = a.q_ichr[i];
+        R.q0 = a.q_w[i];
         R.q1 = a.q_qs[i];
         R.q2 = a.q_qe[i];
     } else {
@@ -736,26 +746,25 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
     }
     int nLater = 0;                                      // covering queries for which this is NOT the first tile
     if (SORTED) {
-        const int ctg = __builtin_amdgcn_readlane(L.ctg, kk);
+        const int ut = __builtin_amdgcn_readlane(L.tile, kk);   // global tile number of this unit
         // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); which of the
         // previous tiles are empty is a property of the database (flag bits 1..3 of the unit)
         const int deadk = a.rule == IGD_HIP_RULE_NEST ? (jf & 15) : 0;
         for (int p = r0; p < r1; p += IGD_WAVE) {
-            int qc = (p + lane < r1) ? R.q0 : -1, qs_ = R.q1, qe_ = R.q2;
+            int w = (p + lane < r1) ? R.q0 : -1, qs_ = R.q1, qe_ = R.q2;
             if (p != r0) {
                 const int i = p + lane;
                 const bool in = i < r1;
-                qc = in ? a.q_ichr[i] : -1;
+                w = in ? a.q_w[i] : -1;
                 qs_ = in ? a.q_qs[i] : 0;
                 qe_ = in ? a.q_qe[i] : 0;
             }
-            const int n1 = tile_of(db, qs_);
-            const int n2 = tile_of(db, (int)((unsigned)qe_ - 1u));
-            const int k = uj - n1;                       // 0: this is the query's first tile
+            const int k = ut - (w >> 4);                 // 0: this is the query's first tile
             // k == 0 with qe <= T is left to k_exact_walk when the compact image is read;
-            // tiles further than IGD_SHORT_TILES-1 behind are too (long queries)
-            const bool later = k > 0 && k < IGD_SHORT_TILES && n2 >= uj && !((deadk >> k) & 1);
-            const bool covers = qc == ctg && n1 >= 0 && ((k == 0 && !(PACKED && qe_ <= T)) || later);
+            // tiles further than IGD_SHORT_TILES-1 behind are too (long queries).  The span is clamped
+            // to the query's own contig, so k <= span also says "same contig".
+            const bool later = k > 0 && k < IGD_SHORT_TILES && (w & 15) >= k && !((deadk >> k) & 1);
+            const bool covers = w >= 0 && ((k == 0 && !(PACKED && qe_ <= T)) || later);
             int P0, P1 = 0, P2 = 0;
             if (PACKED) P0 = query_word(qs_, qe_, k == 0, T, db.nbp);
             else {
@@ -801,12 +810,16 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
         }
     }
     // one LDS atomic per record that was hit, with the number of queries that hit it
+    // records that start before the tile (s' = 0, low half 65535) were matched by every
+    // "later tile" query, none of which may count them (the reference's tS skip, :510-511);
+    // most units have no such query at all
+    if (PACKED && nLater != 0) {
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+    }
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
-        int c = cnt[r];
-        // records that start before the tile (s' = 0, low half 65535) were matched by every
-        // "later tile" query, none of which may count them (the reference's tS skip, :510-511)
-        if (PACKED) c -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+        const int c = cnt[r];
         if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
     }
 }
@@ -1339,7 +1352,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total};
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
@@ -1689,13 +1702,16 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     if (db->d_pairs) (void)hipFree(db->d_pairs);
     if (db->d_long) (void)hipFree(db->d_long);
     if (db->d_fix) (void)hipFree(db->d_fix);
-    db->d_pairs = nullptr; db->d_long = nullptr; db->d_fix = nullptr;
+    if (db->d_qw) (void)hipFree(db->d_qw);
+    db->d_pairs = nullptr; db->d_long = nullptr; db->d_fix = nullptr; db->d_qw = nullptr;
     db->wsQueries = 0;
     int rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr);
     if (rc != IGD_HIP_OK) return rc;
     rc = dalloc(&db->d_long, (size_t)cap, nullptr);
     if (rc != IGD_HIP_OK) return rc;
     rc = dalloc(&db->d_fix, (size_t)cap * 2, nullptr);     // a query can be both long and WALK_FIRST
+    if (rc != IGD_HIP_OK) return rc;
+    rc = dalloc(&db->d_qw, (size_t)cap, nullptr);
     if (rc != IGD_HIP_OK) return rc;
     db->wsQueries = cap;
     db->pairBytes = pb;
@@ -1776,7 +1792,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const int gridQ = (int)(((nq > db->nFiles ? nq : db->nFiles) + 255) / 256);
     if (mode != 2)
         k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt);
+                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw);
     if (mode != 1) {
         rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                                   mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
@@ -1785,7 +1801,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
     ScanArgs a;
     a.firstQ = db->d_firstQ; a.pairN = db->d_pairN; a.pairPos = db->d_pairPos; a.pairs = (const int2 *)db->d_pairs;
-    a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe;
+    a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe; a.q_w = db->d_qw;
     a.total = (u64 *)d_total;
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     if (db->ldsHits) {
