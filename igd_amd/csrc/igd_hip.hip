@@ -119,11 +119,11 @@ struct __attribute__((aligned(32))) Unit {
     int64_t off;      // index of the unit's first record in the SoA arrays
     int32_t tile;     // global tile id
     int32_t n;        // records in this unit
-    int32_t bd;       // tile start coordinate j*nbp (INT_MIN for j == 0)
+    int32_t mx01;     // compact image: largest e' of slot 0 | of slot 1 << 16   (k_pack_units;
     int32_t jf;       // (j << 4) | flags; j = tile index inside its contig;
                       // flag bit 0: first unit of its tile; bit k (1..3): tile j-k of the contig is EMPTY
-    int32_t ctg;      // contig index
-    int32_t mT;       // last tile index of the contig (nTile - 1)
+    int32_t mx23;     //                slots 2, 3                                    a slot is 64
+    int32_t mx45;     //                slots 4, 5                                    consecutive records)
 };
 #define UNIT_J(u) ((u).jf >> 4)
 #define UNIT_FLAGS(u) ((u).jf & 15)
@@ -513,7 +513,12 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 // first-tile query with qe <= T (an inverted query reaching back over the tile start) is the one
 // case that needs the exact starts: the grouping kernels list it for k_exact_walk (WALK_FIRST).
 // 6 bytes per record (4 + 2; 8 with the 16-bit value) instead of 12 (16).
-__global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restrict__ pse,
+// Slot summaries: the scan kernel reads a unit as IGD_SLOTS slots of 64 consecutive records.  The
+// component-wise maximum of a slot's words, (65535 - min s') | max e' << 16, passes the query
+// test exactly when SOME word in the slot COULD pass it, so a query whose word fails against the
+// summary skips the slot.  The low half is read from the slot's first record (the tile is sorted by
+// start); the high halves are stored in the unit descriptor (mx01, mx23, mx45).
+__global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict__ unitsOut, uint32_t *__restrict__ pse,
                                                     uint16_t *__restrict__ px, uint32_t *__restrict__ pv,
                                                     int32_t *__restrict__ flag /* bit 0: a value needs > 16 bits; bit 1: malformed tile */)
 {
@@ -522,15 +527,20 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restr
     const int nw = (gridDim.x * blockDim.x) >> 6;
     int wide = 0;
     for (int ui = gw; ui < db.nUnits; ui += nw) {
-        const Unit u = db.units[ui];
+        const Unit u = unitsOut[ui];
         const int T = (int)((unsigned)UNIT_J(u) * (unsigned)db.nbp);
-        for (int i = lane; i < u.n; i += IGD_WAVE) {
+        unsigned mx[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        for (int i0 = 0; i0 < u.n; i0 += IGD_WAVE) {
+            const int i = i0 + lane;
+            unsigned edv = 0u;
+            if (i < u.n) {
             const int64_t r = u.off + i;
             const int st = db.start[r], en = db.end[r];
             const unsigned sp = st < T ? 0u : (unsigned)(st - T) + 1u;
             long long ed = (long long)en - T;
             if (ed > db.nbp) ed = db.nbp;
             if (ed < 1) ed = 1;
+            edv = (unsigned)ed;
             pse[r] = (65535u - sp) | ((unsigned)ed << 16);
             px[r] = (uint16_t)db.idx[r];
             if (pv) {
@@ -540,6 +550,17 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, uint32_t *__restr
             }
             // a record that does not belong to its tile (malformed file): keep the exact path
             if (!(st < T + db.nbp && en > T)) wide |= 2;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned y = (unsigned)__shfl_xor((int)edv, o);
+                edv = y > edv ? y : edv;
+            }
+            if (i0 / IGD_WAVE < 6) mx[i0 / IGD_WAVE] = edv;
+        }
+        if (lane == 0) {
+            unitsOut[ui].mx01 = (int)(mx[0] | mx[1] << 16);
+            unitsOut[ui].mx23 = (int)(mx[2] | mx[3] << 16);
+            unitsOut[ui].mx45 = (int)(mx[4] | mx[5] << 16);
         }
     }
     if (wide) atomicOr(flag, wide);
@@ -572,13 +593,13 @@ struct Raw {
 };
 
 // A Unit held one-per-lane in VGPRs, and its wave-uniform broadcast.
-struct UnitRegs { int32_t offLo, offHi, tile, n, bd, jf, ctg, mT; };
+struct UnitRegs { int32_t offLo, offHi, tile, n, mx01, jf, mx23, mx45; };
 __device__ __forceinline__ UnitRegs load_unit_regs(const Unit *p)
 {
     const int4 a = ((const int4 *)p)[0], b = ((const int4 *)p)[1];
     UnitRegs r;
     r.offLo = a.x; r.offHi = a.y; r.tile = a.z; r.n = a.w;
-    r.bd = b.x; r.jf = b.y; r.ctg = b.z; r.mT = b.w;
+    r.mx01 = b.x; r.jf = b.y; r.mx23 = b.z; r.mx45 = b.w;
     return r;
 }
 
@@ -718,6 +739,42 @@ __device__ __forceinline__ void match_raw(const Raw &R, int (&cnt)[IGD_SLOTS], i
     }
 }
 
+// Compact image: the queries of `live` (one per lane, word P0) against the unit, slot by slot.  A
+// query is compared with the records of a slot only if its word passes against the slot's summary
+// W[r] -- the same packed test, done for 64 queries at once; on the benchmark that leaves 1.8 of
+// 4.9 slots per (query, unit).  cnt[r] += hit; no exec masking, no LDS.
+__device__ __forceinline__ void match_slots(const Raw &R, int (&cnt)[IGD_SLOTS], const uint32_t (&W)[IGD_SLOTS], int P0,
+                                            unsigned long long live)
+{
+    igd_u16x2 qv;
+    __builtin_memcpy(&qv, &P0, 4);
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        igd_u16x2 wv;
+        __builtin_memcpy(&wv, &W[r], 4);
+        const igd_u16x2 mw = __builtin_elementwise_max(wv, qv);
+        uint32_t mww;
+        __builtin_memcpy(&mww, &mw, 4);
+        unsigned long long m = __ballot(mww == W[r]) & live;
+#if IGD_EXP_NOMATCH
+        asm volatile("" ::"v"(R.a[r]), "v"(R.x[r]));
+        continue;
+#endif
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int q = __builtin_amdgcn_readlane(P0, src);
+            igd_u16x2 rec, qw;
+            __builtin_memcpy(&rec, &R.a[r], 4);
+            __builtin_memcpy(&qw, &q, 4);
+            const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);   // v_pk_max_u16
+            uint32_t mxw;
+            __builtin_memcpy(&mxw, &mx, 4);
+            cnt[r] += mxw == R.a[r] ? 1 : 0;             // both halves already >= the query's
+        }
+    }
+}
+
 template <bool SORTED, bool USE_V, bool PACKED>
 __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a, const UnitRegs &L, int Lr0,
                                              int Lr1, int kk, int lane, Raw &R, u64 *hits)
@@ -727,10 +784,22 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
     if (!active) return;
     const int un = __builtin_amdgcn_readlane(L.n, kk);
     if (un == 0) return;                                 // placeholder of an empty tile
-    const int bd = __builtin_amdgcn_readlane(L.bd, kk);
     const int jf = __builtin_amdgcn_readlane(L.jf, kk);
     const int uj = jf >> 4;
     const int T = (int)((unsigned)uj * (unsigned)db.nbp);
+    const int bd = uj == 0 ? INT_MIN : T;                // tile start; "no lower bound" in tile 0 (src/igd_search.c:496,529)
+    // slot summaries (see k_pack_units): the largest word a record of the slot could have
+    uint32_t W[IGD_SLOTS];
+    if (PACKED) {
+        const uint32_t m01 = (uint32_t)__builtin_amdgcn_readlane(L.mx01, kk), m23 = (uint32_t)__builtin_amdgcn_readlane(L.mx23, kk),
+                       m45 = (uint32_t)__builtin_amdgcn_readlane(L.mx45, kk);
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const uint32_t mw = r < 2 ? m01 : r < 4 ? m23 : m45;
+            const uint32_t hi = (r & 1) ? (mw & 0xFFFF0000u) : (mw << 16);
+            W[r] = ((uint32_t)__builtin_amdgcn_readlane((int)R.a[r], 0) & 0xFFFFu) | hi;   // first record of the slot: smallest s'
+        }
+    }
     int cnt[IGD_SLOTS];
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
@@ -773,13 +842,16 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
                 P2 = qs_;
             }
             unsigned long long m = __ballot(covers);
-            if (PACKED) nLater += __popcll(__ballot(covers && later));
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                if (PACKED) match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, src), 0, 0, a.v);
-                else match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, src),
-                                              __builtin_amdgcn_readlane(P1, src), __builtin_amdgcn_readlane(P2, src), a.v);
+            if (PACKED) {
+                nLater += __popcll(__ballot(covers && later));
+                match_slots(R, cnt, W, P0, m);
+            } else {
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, src),
+                                             __builtin_amdgcn_readlane(P1, src), __builtin_amdgcn_readlane(P2, src), a.v);
+                }
             }
         }
     } else {
@@ -802,11 +874,11 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
                 P1 = (int)((unsigned)py_ - (unsigned)P0);
                 P2 = px_;
             }
-            for (int k = 0; k < m; k++) {
-                if (PACKED) match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, k), 0, 0, a.v);
-                else match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, k), __builtin_amdgcn_readlane(P1, k),
-                                              __builtin_amdgcn_readlane(P2, k), a.v);
-            }
+            if (PACKED) match_slots(R, cnt, W, P0, m >= IGD_WAVE ? ~0ull : ((1ull << m) - 1ull));
+            else
+                for (int k = 0; k < m; k++)
+                    match_raw<USE_V, PACKED>(R, cnt, __builtin_amdgcn_readlane(P0, k), __builtin_amdgcn_readlane(P1, k),
+                                             __builtin_amdgcn_readlane(P2, k), a.v);
         }
     }
     // one LDS atomic per record that was hit, with the number of queries that hit it
@@ -1465,13 +1537,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                     u.off = off + r0;
                     u.tile = (int32_t)t;
                     u.n = cnt - r0 < IGD_CHUNK ? cnt - r0 : IGD_CHUNK;
-                    u.bd = tileBd[t];
+                    u.mx01 = u.mx23 = u.mx45 = 0;
                     int fl = r0 == 0 ? 1 : 0;
                     for (int k = 1; k < IGD_SHORT_TILES && k <= j; k++)
                         if (d->nCnt[t - k] <= 0) fl |= 1 << k;
                     u.jf = (j << 4) | fl;
-                    u.ctg = c;
-                    u.mT = d->nTile[c] - 1;
                     units.push_back(u);
                 }
                 off += cnt;
@@ -1671,7 +1741,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         hipError_t e = hipMemset(db->d_ctl, 0, 16 * 4);
         if (e == hipSuccess) {
-            k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_pse, db->d_px, db->d_pxv, db->d_ctl);
+            k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_units, db->d_pse, db->d_px, db->d_pxv, db->d_ctl);
             e = hipStreamSynchronize(db->stream);
         }
         int32_t fl = 0;
