@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
     }
     const int lane = threadIdx.x & 63;
+    // Once any wave has found the batch unordered nothing this kernel produces is going to be read
+    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
     int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
     int val = i;
     if (i < nq) {

@@ -1,0 +1,13 @@
+#!/bin/bash
+# tools/profile_all.sh -- run ON THE GPU BOX (via gpurun): refreshes every summary kept under profiles/r01/
+python tools/prep.py > gpurun_out/prep.log 2>&1
+bash tools/profile.sh sorted > gpurun_out/p_sorted.log 2>&1
+bash tools/profile.sh auto --grouping auto > gpurun_out/p_auto.log 2>&1
+bash tools/profile.sh shuffled --shuffled > gpurun_out/p_shuffled.log 2>&1
+bash tools/profile.sh v500 --v 500 > gpurun_out/p_v500.log 2>&1
+bash tools/profile.sh exact --exact-arrays > gpurun_out/p_exact.log 2>&1
+bash tools/profile.sh dense --queries 12500000 --steps 10 --warmup 2 --no-cpu > gpurun_out/p_dense.log 2>&1
+python tools/measure_misc.py > gpurun_out/misc.json 2> gpurun_out/misc.err
+bash tools/profile_create.sh > gpurun_out/p_create.log 2>&1
+bash tools/seqpare_bench.sh 10000 100000 300000 1000000 > /dev/null 2>&1
+ls gpurun_out
