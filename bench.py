@@ -204,22 +204,26 @@ def main():
         args.grouping = "auto" if args.shuffled else "sorted"
     gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
 
-    gflags |= 8          # IGD_HIP_FLAG_ZERO_FIRST: each step's hits[] starts from zero (the API adds)
-
+    # A job = K batches (steps) whose per-file counts ACCUMULATE in hits[] -- the reference's hits[] is
+    # one accumulator over the whole query file (src/igd_search.c:925,1032-1039) and the engine adds --
+    # followed by the path's ONE exchange: a SUM all-reduce of hits[nFiles] (no-op at N=1).  Both are
+    # inside the timed region.
     def step():
         db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
                       v=args.v, stream=stream, flags=gflags)
-        allreduce_hits(d_hits)              # the one collective of the path (no-op at N=1)
 
     for _ in range(args.warmup):
         step()
+    allreduce_hits(d_hits)                  # also warms RCCL up (first call builds the communicator)
     torch.cuda.synchronize(dev)
     barrier()
     torch.cuda.synchronize(dev)
     db.profile_begin(args.steps)
     t0 = time.perf_counter()
+    d_hits.zero_()
     for _ in range(args.steps):
         step()
+    allreduce_hits(d_hits)                  # the one collective of the path
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
@@ -234,7 +238,9 @@ def main():
     st = db.batch_stats(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, v=args.v)
     mode = "v" if (args.v > 0 and db.gtype == 1) else "hits"
     algo_bytes = db.algorithmic_bytes(st, Q, mode)
-    hits_one = d_hits.cpu().numpy()       # the last step's (all-reduced) vector
+    hits_job = d_hits.cpu().numpy()       # K identical batches per rank, summed over ranks
+    assert args.steps > 0 and (hits_job % args.steps == 0).all(), "hits[] is not K times one batch"
+    hits_one = hits_job // args.steps     # one batch per rank, summed over ranks
 
     if rank == 0:
         value = world * Q * args.steps / elapsed
@@ -252,7 +258,8 @@ def main():
                                       "generation-order" if args.shuffled else "position-sorted",
                                       "-v %d signal filter" % args.v if mode == "v" else "hits-only"),
                        "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
-                       "collective": "all-reduce int64[%d] per step" % db.nfiles if world > 1 else "none"},
+                       "collective": ("ONE sum all-reduce of int64[%d] per job (after the %d batches), inside the timed region"
+                                      % (db.nfiles, args.steps)) if world > 1 else "none"},
             "roofline": {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(mode, args),
                          "algorithmic_bytes_per_launch": algo_bytes,
