@@ -13,9 +13,9 @@
 //   1. group the queries by tile.  Two ways, chosen ON THE DEVICE per batch:
 //      a. queries already ordered by (contig, start) -- what a position-sorted BED gives:
 //         k_query_bounds finds, in one pass and without atomics, the first query of every
-//         tile (firstQ[]) and verifies the order; the scan kernel then reads the queries of
-//         tile t and of the up-to-3 tiles before it straight from the caller's arrays
-//         (a merge join: both sides stream);
+//         tile (firstQ[]), verifies the order and leaves per query one word (first global tile,
+//         tile span); the scan kernel then reads the queries of tile t and of the up-to-3 tiles
+//         before it straight from the caller's arrays (a merge join: both sides stream);
 //      b. any other order: every (query, visited tile) pair is counting-sorted by tile id
 //         (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); these kernels return at once
 //         when (a) holds.
@@ -24,7 +24,9 @@
 //      at a time.  It loads the unit's records once, coalesced, into 5 register slots (record
 //      r*64+lane) -- by default from a compact 6-byte tile-relative image (k_pack_units) -- keeps
 //      two units in flight, and runs through the tile's queries, whose parameters it computes 64
-//      at a time across the lanes and broadcasts with v_readlane.  Per query and slot the test
+//      at a time across the lanes.  Each slot has a summary word (component-wise max of its 64
+//      record words); the queries that pass against it -- one vector compare for all 64 -- are
+//      broadcast with v_readlane one at a time, and per query and slot the test
 //            lob <= start < qe  &&  end > qs  [&& value >= v]
 //      (lob = tile start for a non-first tile: the reference's tS prefix skip, :510-511; the
 //      upper bound start<qe is what its bisection computes, :479-487) costs three vector
@@ -34,7 +36,9 @@
 //      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].  The same
 //      launch walks, on the exact arrays, the few queries the scan leaves out (more than
 //      IGD_SHORT_TILES tiles long, or needing exact starts: see k_pack_units).
-//   `-f` (igd_enum_tiles) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays.
+//   `-f` (igd_enum_tiles) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays;
+//   Seqpare `-s` (igd_hip_seqpare) = the `-f` kernel emitting similarities + radix sorts into the
+//   greedy order (igd_sortscan.hpp) + a wave-per-group matching kernel (k_seq_greedy).
 // No MFMA anywhere: this is integer compare + count, bound by HBM / VALU issue, not by math.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
