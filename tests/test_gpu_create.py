@@ -264,3 +264,19 @@ def test_fewer_than_ten_files_and_gtype0():
         assert b"exists!" in p.stdout
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14)])
+def test_odd_inputs(which, b):
+    """header-only database, 3000 contigs (global atomicMax path of k_span), intervals covering > 10^5 tiles,
+    CRLF lines without a final newline -- same bytes as the oracle (pinned to the reference on the same inputs
+    by tests/test_oracle_create.py::test_odd_inputs_files_are_identical)."""
+    from test_oracle_create import write_odd_inputs
+    d = short_tmpdir()
+    try:
+        write_odd_inputs(d, which)
+        outs = run_pair(d, d + "/in/", ["-b", str(b)])
+        assert outs["gpu"] == outs["orc"]
+        assert_same_files(d)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -187,3 +187,45 @@ def test_value_column_quirk_of_the_creeping_column_limit():
         assert (f4[:, 3] == 0).sum() >= 3            # the two short lines and the line after the 3-column one
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def write_odd_inputs(d, which):
+    """inputs off the beaten path, shared with tests/test_gpu_create.py"""
+    os.makedirs(d + "/in")
+    rng = random.Random(1234)
+    if which == "nothing_valid":                 # every line has start >= end: header-only database
+        for f in range(10):
+            open(d + "/in/f%02d.bed" % f, "w").write("".join("chr1\t%d\t%d\tx\t1\n" % (100 + i, 100 + i - f % 2) for i in range(20)))
+    elif which == "many_contigs":                # more contigs than the LDS table of k_span holds
+        for f in range(10):
+            rows = []
+            for i in range(700):
+                c = "chrUn_%04d" % rng.randrange(0, 3000)
+                s = rng.randrange(0, 200000)
+                rows.append("%s\t%d\t%d\tx\t%d" % (c, s, s + rng.randrange(1, 40000), i))
+            open(d + "/in/f%02d.bed" % f, "w").write("\n".join(rows) + "\n")
+    elif which == "huge_spans":                  # intervals covering thousands of tiles, one covering a contig
+        for f in range(10):
+            rows = ["chr1\t%d\t%d\tx\t7" % (1000 * f, 1000 * f + 30000000 + f), "chr2\t0\t250000000\tw\t1"]
+            for i in range(50):
+                s = rng.randrange(0, 1 << 27)
+                rows.append("chr1\t%d\t%d\ty\t%d" % (s, s + rng.choice([1, 5000, 3000000]), i))
+            open(d + "/in/f%02d.bed" % f, "w").write("\n".join(rows) + "\n")
+    elif which == "no_trailing_newline_crlf":
+        for f in range(10):
+            body = "\r\n".join("chr%d\t%d\t%d\tn\t%d" % (1 + i % 2, 10 * i, 10 * i + 25, i) for i in range(40))
+            open(d + "/in/f%02d.bed" % f, "wb").write(body.encode())      # CRLF, last line unterminated
+
+
+@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14)])
+def test_odd_inputs_files_are_identical(which, b):
+    build_oracle()
+    d = short_tmpdir()
+    try:
+        write_odd_inputs(d, which)
+        outs = run_both(d, d + "/in/", ["-b", str(b)])
+        assert outs["ref"] == outs["orc"]
+        assert open(d + "/ref/db_index.tsv", "rb").read() == open(d + "/orc/db_index.tsv", "rb").read()
+        same_igd(d + "/ref/db.igd", d + "/orc/db.igd")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
