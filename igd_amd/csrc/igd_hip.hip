@@ -60,6 +60,9 @@
 #endif
 #define IGD_CHUNK (IGD_WAVE * IGD_SLOTS)     // records per work chunk (320)
 #define IGD_SHORT_TILES 4                    // queries spanning more tiles take the long path
+#ifndef IGD_WPE
+#define IGD_WPE 8                            // scan kernel: waves per SIMD the register budget is cut for
+#endif
 #ifndef IGD_WG
 #define IGD_WG 1024                          // threads per scan workgroup (16 waves; 2 workgroups per CU)
 #endif
@@ -651,15 +654,15 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + base), 0, n * 4, 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, 0, 0);
-                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, 0, 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);   // slot offset: an immediate
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4, r * 256, 0);
             }
         } else {
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + base), 0, n * 2, 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, 0, 0);
-                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, 0, 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2, r * 128, 0);
             }
         }
     } else
@@ -907,7 +910,7 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
 // SORTED = false: bucketed pairs
 // In the device-decides mode both are enqueued and the one that does not apply returns at once.
 template <bool SORTED, bool USE_V, bool LDS_HITS, bool PACKED>
-__global__ __launch_bounds__(IGD_WG, 8) void igd_scan_tiles(DbView db, ScanArgs a)
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, ScanArgs a)
 {
     {
         const bool uns = __builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch;
@@ -1576,7 +1579,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         int cus = prop0.multiProcessorCount > 0 ? prop0.multiProcessorCount : 256;
         db->ldsBytes = (int)((size_t)d->nFiles * 8);
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
-        int perCU = 2048 / IGD_WG;                       // 32 waves per CU
+        int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
         if (db->ldsHits && db->ldsBytes > 0) {
             int fit = (160 * 1024) / (db->ldsBytes + 256);
