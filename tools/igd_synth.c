@@ -87,7 +87,7 @@ int igd_synth_db(const char *igd_path, int32_t nFiles, int32_t perFile, uint64_t
 {
     genome_t g; genome_init(&g, genome);
     const int64_t n = (int64_t)nFiles * perFile;
-    igdc_interval *iv = (igdc_interval *)malloc(sizeof(igdc_interval) * (size_t)(n ? n : 1));
+    igdc_interval *iv = (igdc_interval *)calloc((size_t)(n ? n : 1), sizeof(igdc_interval));
     int32_t *nr = (int32_t *)calloc((size_t)nFiles + 1, sizeof(int32_t));
     double *avg = (double *)calloc((size_t)nFiles + 1, sizeof(double));
     char **names = (char **)calloc((size_t)nFiles + 1, sizeof(char *));
