@@ -16,9 +16,10 @@
 //         tile (firstQ[]), verifies the order and leaves per query one word (first global tile,
 //         tile span); the scan kernel then reads the queries of tile t and of the up-to-3 tiles
 //         before it straight from the caller's arrays (a merge join: both sides stream);
-//      b. any other order: every (query, visited tile) pair is counting-sorted by tile id
-//         (k_count_pairs -> 2-kernel scan -> k_scatter_pairs); these kernels return at once
-//         when (a) holds.
+//      b. any other order: every (query, visited tile) pair is grouped by tile id without global
+//         atomics (k_split_local -> k_split_totals -> k_split_fine: LDS counting in two levels);
+//         these kernels return at once when (a) holds.  (`-f` keeps the atomic counting sort
+//         k_count_pairs -> 2-kernel scan -> k_scatter_pairs, which also carries the query id.)
 //      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
 //   2. scan:   igd_scan_tiles -- one wavefront owns one <=320-record chunk ("unit") of one tile
 //      at a time.  It loads the unit's records once, coalesced, into 5 register slots (record
@@ -135,6 +136,8 @@ struct __attribute__((aligned(32))) Unit {
 #define UNIT_J(u) ((u).jf >> 4)
 #define UNIT_FLAGS(u) ((u).jf & 15)
 
+struct SpTuple { int32_t t, s, e; };     // split path: one (tile, qs, qe) pair on its way to its tile: 12 bytes, one dwordx3 access
+
 struct DbView {
     int32_t nbp, shift, nCtg, nT, nUnits, nFiles;
     const Unit *units;
@@ -168,6 +171,10 @@ struct igd_hip_db {
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
     int32_t *d_qw;                // [wsQueries] per-query tile word of the merge join (k_query_bounds)
+    uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
+    SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
+    int32_t *d_spBase;            // pairs per coarse bucket
+    int spShift, spCoarse;        // coarse bucket = tile >> spShift; spShift < 0: split path not applicable
     char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
     size_t arenaSize, arenaUsed;
     int32_t epoch;                // batch counter: device-side flags are compared against it
@@ -409,6 +416,202 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
     }
     for (int k = 0; k < ntl; k++)
         if (db.tileCnt[gt0 + k] > 0) atomicAdd(&pairCnt[gt0 + k], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// Bucket path without global atomics ("split"): 10^6 random atomicAdds on the per-tile counters cost
+// ~40 us each way on this part (device-scope atomics are resolved beyond the XCD-private L2s), so the
+// (query, tile) pairs are grouped in two levels with LDS atomics only:
+//   k_split_local   a workgroup takes 1024 queries, counts their pairs per COARSE bucket (tile >> shift,
+//                   <= 1024 buckets) in LDS, and writes them, grouped by bucket, into its own region
+//                   + one table row (offset | count << 16 per bucket);
+//   k_split_totals  column sums of the table -> first pair of every bucket (one workgroup);
+//   k_split_fine    one workgroup per bucket collects the bucket's segments from all regions, counts per
+//                   tile in LDS (the bucket spans 2^shift tiles), writes pairN/pairPos of its tiles and
+//                   the pairs, tile by tile, into `pairs`.
+// Output = exactly what count/scan/scatter leave (pairN, pairPos = END of each tile's range, pairs).
+#ifndef SP_WG
+#define SP_WG 1024
+#endif
+#ifndef SP_PER
+#define SP_PER 4
+#endif
+#define SP_Q (SP_WG * SP_PER) // queries per workgroup of k_split_local: more queries = longer segments per (workgroup, bucket)
+#define SPF_WG 256           // threads of k_split_fine
+#define SP_CAP (SP_Q * IGD_SHORT_TILES)
+#define SP_MAXC 1024
+
+__global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t *__restrict__ ichr,
+                                                       const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
+                                                       int nq, int rule, int packed, int shift, int nCoarse,
+                                                       uint32_t *__restrict__ table, SpTuple *__restrict__ reg,
+                                                       int2 *__restrict__ longList, int32_t *__restrict__ ctl, int gate,
+                                                       int epoch, u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
+{
+    {
+        const int gi = blockIdx.x * SP_WG + threadIdx.x;
+        if (zeroHits) for (int f = gi; f < db.nFiles; f += gridDim.x * SP_WG) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
+        if (zeroTotal && gi == 0) *zeroTotal = 0;
+        if (gate == 0 && gi == 0) {
+            ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+            ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+            ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
+        }
+    }
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    __shared__ uint32_t hist[SP_MAXC], cur[SP_MAXC], wsum[SP_WG / IGD_WAVE];
+    for (int b = threadIdx.x; b < nCoarse; b += SP_WG) hist[b] = 0;
+    __syncthreads();
+    int gt0[SP_PER], ntl[SP_PER], s_[SP_PER], e_[SP_PER];
+#pragma unroll
+    for (int k = 0; k < SP_PER; k++) {
+        const int i = blockIdx.x * SP_Q + k * SP_WG + threadIdx.x;
+        ntl[k] = 0; gt0[k] = 0; s_[k] = 0; e_[k] = 0;
+        if (i < nq) {
+            const int s = qs[i], e = qe[i];
+            int g, n;
+            if (query_span(db, ichr[i], s, e, rule, g, n)) {
+                const int kind = walk_kind(db, s, e, n, packed);
+                if (kind >= 0) longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
+                else {
+                    int live = 0;                         // bit j: tile g+j is not empty
+                    for (int j = 0; j < n; j++) live |= (db.tileCnt[g + j] > 0) << j;
+                    gt0[k] = g; ntl[k] = live; s_[k] = s; e_[k] = e;
+                    for (int j = 0; j < n; j++)
+                        if ((live >> j) & 1) atomicAdd(&hist[(g + j) >> shift], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the buckets: thread t owns buckets 4t .. 4t+3 (SP_MAXC = 4 * SP_WG)
+        const int b0 = threadIdx.x * (SP_MAXC / SP_WG);
+        uint32_t c[SP_MAXC / SP_WG], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SP_MAXC / SP_WG; k++) { c[k] = b0 + k < nCoarse ? hist[b0 + k] : 0u; sum += c[k]; }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        uint32_t x = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t run = x - sum;
+        for (int k = 0; k < w; k++) run += wsum[k];
+#pragma unroll
+        for (int k = 0; k < SP_MAXC / SP_WG; k++) {
+            if (b0 + k < nCoarse) {
+                table[(size_t)blockIdx.x * nCoarse + b0 + k] = run | (c[k] << 16);
+                cur[b0 + k] = run;
+            }
+            run += c[k];
+        }
+    }
+    __syncthreads();
+    const size_t rb = (size_t)blockIdx.x * SP_CAP;
+#pragma unroll
+    for (int k = 0; k < SP_PER; k++)
+        for (int live = ntl[k], j = 0; live; live >>= 1, j++)
+            if (live & 1) {
+                const int t = gt0[k] + j;
+                const uint32_t pos = atomicAdd(&cur[t >> shift], 1u);
+                SpTuple tu; tu.t = t; tu.s = s_[k]; tu.e = e_[k];
+                reg[rb + pos] = tu;
+            }
+}
+
+// column sums of the table: workgroup g owns 64 buckets, its 16 waves share the rows
+__global__ __launch_bounds__(1024) void k_split_totals(const uint32_t *__restrict__ table, int nWG, int nCoarse,
+                                                       int32_t *__restrict__ totals, const int32_t *__restrict__ ctl, int gate)
+{
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    __shared__ uint32_t part[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    uint32_t tot = 0;
+    if (b < nCoarse)
+        for (int w = wv; w < nWG; w += 16) tot += table[(size_t)w * nCoarse + b] >> 16;
+    part[wv][lane] = tot;
+    __syncthreads();
+    if (wv == 0 && b < nCoarse) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) t += part[k][lane];
+        totals[b] = (int32_t)t;
+    }
+}
+
+#define SP_ROWS 4     // table rows a thread keeps in flight
+__global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
+                                                      const SpTuple *__restrict__ reg, const int32_t *__restrict__ totals,
+                                                      int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
+                                                      int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate)
+{
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    extern __shared__ uint32_t sp_lds[];
+    const int F = 1 << shift;
+    uint32_t *cnt = sp_lds, *start = sp_lds + F;
+    __shared__ uint32_t wsum[SPF_WG / IGD_WAVE], baseSh;
+    const int b = blockIdx.x, t0 = b << shift;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
+    {   // first pair of this bucket = pairs of all earlier buckets
+        uint32_t x = 0;
+        for (int k = threadIdx.x; k < b; k += SPF_WG) x += (uint32_t)totals[k];
+        for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o);
+        if (lane == 0) wsum[wv] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < SPF_WG / IGD_WAVE; k++) t += wsum[k]; baseSh = t; }
+    for (int w0 = threadIdx.x; w0 < nWG; w0 += SPF_WG * SP_ROWS) {
+        uint32_t e[SP_ROWS];
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) { const int w = w0 + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) {
+            const size_t at = (size_t)(w0 + r * SPF_WG) * SP_CAP + (e[r] & 0xFFFFu);
+            const int c = (int)(e[r] >> 16);
+            for (int j = 0; j < c; j++) atomicAdd(&cnt[reg[at + j].t - t0], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
+        const int per = F / SPF_WG, f0 = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (int k = 0; k < per; k++) sum += cnt[f0 + k];
+        uint32_t x = sum;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+            if (lane >= o) x += y;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wv] = x;
+        __syncthreads();
+        uint32_t run = baseSh + x - sum;
+        for (int k = 0; k < wv; k++) run += wsum[k];
+        for (int k = 0; k < per; k++) {
+            const uint32_t c = cnt[f0 + k];
+            start[f0 + k] = run;
+            if (t0 + f0 + k < nT) { pairN[t0 + f0 + k] = (int32_t)c; pairPos[t0 + f0 + k] = (int32_t)(run + c); }
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int w0 = threadIdx.x; w0 < nWG; w0 += SPF_WG * SP_ROWS) {
+        uint32_t e[SP_ROWS];
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) { const int w = w0 + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) {
+            const size_t at = (size_t)(w0 + r * SPF_WG) * SP_CAP + (e[r] & 0xFFFFu);
+            const int c = (int)(e[r] >> 16);
+            for (int j = 0; j < c; j++) {
+                const SpTuple tu = reg[at + j];
+                const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
+                pairs[pos] = make_int2(tu.s, tu.e);
+            }
+        }
+    }
 }
 
 // step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol).  The
@@ -1434,7 +1637,8 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw};
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw,
+                    db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
@@ -1783,6 +1987,11 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     if (db->d_long) (void)hipFree(db->d_long);
     if (db->d_fix) (void)hipFree(db->d_fix);
     if (db->d_qw) (void)hipFree(db->d_qw);
+    {
+        void *ws[] = { db->d_spTable, db->d_spT, db->d_spBase };
+        for (void *q : ws) if (q) (void)hipFree(q);
+        db->d_spTable = nullptr; db->d_spT = nullptr; db->d_spBase = nullptr;
+    }
     db->d_pairs = nullptr; db->d_long = nullptr; db->d_fix = nullptr; db->d_qw = nullptr;
     db->wsQueries = 0;
     int rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr);
@@ -1793,6 +2002,18 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     if (rc != IGD_HIP_OK) return rc;
     rc = dalloc(&db->d_qw, (size_t)cap, nullptr);
     if (rc != IGD_HIP_OK) return rc;
+    {   // split path geometry: <= SP_MAXC coarse buckets of 2^shift tiles, 2^shift counters x 2 in LDS
+        int sh = 8;
+        while (sh < 13 && ((db->nT + (1 << sh) - 1) >> sh) > SP_MAXC) sh++;
+        db->spShift = (((db->nT + (1 << sh) - 1) >> sh) <= SP_MAXC && sh <= 12) ? sh : -1;   // 2 * 4 * 2^12 = 32 KiB of LDS
+        db->spCoarse = db->spShift >= 0 ? (db->nT + (1 << sh) - 1) >> sh : 0;
+        if (db->spShift >= 0) {
+            const size_t nWG = (size_t)((cap + SP_Q - 1) / SP_Q);
+            if ((rc = dalloc(&db->d_spTable, nWG * (size_t)db->spCoarse, nullptr)) != IGD_HIP_OK) return rc;
+            if ((rc = dalloc(&db->d_spT, nWG * SP_CAP, nullptr)) != IGD_HIP_OK) return rc;
+            if ((rc = dalloc(&db->d_spBase, SP_MAXC + 2, nullptr)) != IGD_HIP_OK) return rc;
+        }
+    }
     db->wsQueries = cap;
     db->pairBytes = pb;
     return IGD_HIP_OK;
@@ -1817,6 +2038,22 @@ static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d
                                                 db->d_ctl, gate);
     k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairPos, db->d_pairs,
                                                 db->d_ctl, gate);
+    HIPCHK(hipGetLastError());
+    return IGD_HIP_OK;
+}
+
+// The same grouping without global atomics (k_split_*); (qs,qe) pairs only.
+static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
+                        int nq, int rule, int gate, int packed, hipStream_t st, u64 *zeroHits, u64 *zeroTotal)
+{
+    const int nWG = (nq + SP_Q - 1) / SP_Q;
+    k_split_local<<<nWG, SP_WG, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
+                                         db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal);
+    k_split_totals<<<(db->spCoarse + 63) / 64, 1024, 0, st>>>(db->d_spTable, nWG, db->spCoarse, db->d_spBase, db->d_ctl, gate);
+    k_split_fine<<<db->spCoarse, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
+                                                                          db->d_spT, db->d_spBase,
+                                                                          db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs,
+                                                                          db->d_ctl, gate);
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
@@ -1874,8 +2111,13 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
                                               db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw);
     if (mode != 1) {
-        rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
-                                  mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
+        static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
+        if (db->spShift >= 0 && !oldBucket)
+            rc = launch_split(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+                              mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
+        else
+            rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+                                      mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         if (rc != IGD_HIP_OK) return rc;
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
