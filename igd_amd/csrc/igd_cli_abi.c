@@ -8,7 +8,9 @@
  * There is no CPU search here; if no HIP device is usable the process stops with a message.
  */
 #define _GNU_SOURCE
+#include <pthread.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include <sysexits.h>
 
@@ -328,8 +330,6 @@ void seqOverlaps(char *qFile, double *sm)
 
 /* ------------------------------- full enumeration (-f) -------------------------------- */
 typedef struct { char *buf; size_t n, cap; } obuf;
-static void ob_flush(obuf *o) { if (o->n) fwrite(o->buf, 1, o->n, stdout); o->n = 0; }
-static void ob_room(obuf *o, size_t need) { if (o->n + need > o->cap) ob_flush(o); }
 static void ob_int(obuf *o, int32_t x)
 {
     char t[12];
@@ -342,7 +342,41 @@ static void ob_int(obuf *o, int32_t x)
 static void ob_str(obuf *o, const char *s, size_t L) { memcpy(o->buf + o->n, s, L); o->n += L; }
 
 /* Prints what get_overlaps_f1/_f0 print for each query of the batch, in order
- * ("Query %s, %i, %i: \n" at :548, one "%i\t %i\t %i\t %s\n" per overlap at :577,:610). */
+ * ("Query %s, %i, %i: \n" at :548, one "%i\t %i\t %i\t %s\n" per overlap at :577,:610).  The text
+ * (35 bytes per overlap: > 1 GB for 10^6 queries) is formatted by several threads, each into its own
+ * buffer for a contiguous range of queries, and written out in order. */
+typedef struct {
+    const igdc_queries *q; char **names; const iGD_t *G; const size_t *flen;
+    int64_t q0;                       /* first query of the engine call this block belongs to   */
+    const int64_t *qoff; const igd_hip_hit *hit;
+    int64_t i0, i1;                   /* queries [i0, i1) of that call                           */
+    obuf o;
+} fmt_job;
+
+static void *fmt_run(void *arg)
+{
+    fmt_job *J = (fmt_job *)arg;
+    obuf *o = &J->o;
+    const iGD_t *G = J->G;
+    for (int64_t i = J->i0; i < J->i1; i++) {
+        const int32_t c = J->q->ichr[J->q0 + i], qs = J->q->qs[J->q0 + i], qe = J->q->qe[J->q0 + i];
+        const int32_t n1 = qs / G->nbp;
+        if (n1 > G->nTile[c] - 1 || n1 < 0) continue;           /* :544-545 */
+        const char *nm = J->names[J->q0 + i];
+        ob_str(o, "Query ", 6);
+        ob_str(o, nm, strlen(nm));
+        ob_str(o, ", ", 2); ob_int(o, qs); ob_str(o, ", ", 2); ob_int(o, qe);
+        ob_str(o, ": \n", 3);
+        int32_t k = 0;
+        for (int64_t h = J->qoff[i]; h < J->qoff[i + 1]; h++, k++) {
+            const int32_t f = J->hit[h].idx;
+            ob_int(o, k); ob_str(o, "\t ", 2); ob_int(o, J->hit[h].start); ob_str(o, "\t ", 2);
+            ob_int(o, J->hit[h].end); ob_str(o, "\t ", 2); ob_str(o, G->finfo[f].fileName, J->flen[f]); o->buf[o->n++] = '\n';
+        }
+    }
+    return NULL;
+}
+
 static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 {
     if (q->n == 0) return 0;
@@ -351,38 +385,57 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
     int64_t *qoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->n + 1));
     igd_hip_hit *hit = NULL;
     int64_t total = 0, grand = 0;
-    obuf o;
-    o.cap = 1 << 20; o.n = 0; o.buf = (char *)malloc(o.cap + 4096);
-    const int64_t step = igd_hip_max_batch();
+    size_t *flen = (size_t *)malloc(sizeof(size_t) * (size_t)(G->nFiles + 1));
+    size_t maxL = 0;
+    for (int32_t f = 0; f < G->nFiles; f++) { flen[f] = strlen(G->finfo[f].fileName); if (flen[f] > maxL) maxL = flen[f]; }
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    const char *ev = getenv("IGD_PRINT_THREADS");
+    int nt = ev && atoi(ev) > 0 ? atoi(ev) : (ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu));
+    if (nt > 64) nt = 64;
+    const int64_t step = igd_hip_max_batch(), blockHits = (int64_t)4 << 20;
+    fflush(stdout);
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
         int rc = igd_hip_enumerate(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, &hit, &total);
         if (rc != IGD_HIP_OK) die_no_gpu("enumerate", rc);
-        for (int64_t i = 0; i < m; i++) {
-            const int32_t c = q->ichr[q0 + i], qs = q->qs[q0 + i], qe = q->qe[q0 + i];
-            const int32_t n1 = qs / G->nbp;
-            if (n1 > G->nTile[c] - 1 || n1 < 0) continue;           /* :544-545 */
-            ob_room(&o, 128);
-            ob_str(&o, "Query ", 6);
-            ob_str(&o, names[q0 + i], strlen(names[q0 + i]));
-            ob_str(&o, ", ", 2); ob_int(&o, qs); ob_str(&o, ", ", 2); ob_int(&o, qe);
-            ob_str(&o, ": \n", 3);
-            int32_t k = 0;
-            for (int64_t h = qoff[i]; h < qoff[i + 1]; h++, k++) {
-                const char *fn = G->finfo[hit[h].idx].fileName;
-                size_t L = strlen(fn);
-                ob_room(&o, 64 + L);
-                if (L + 64 > o.cap) { ob_flush(&o); printf("%i\t %i\t %i\t %s\n", k, hit[h].start, hit[h].end, fn); continue; }
-                ob_int(&o, k); ob_str(&o, "\t ", 2); ob_int(&o, hit[h].start); ob_str(&o, "\t ", 2);
-                ob_int(&o, hit[h].end); ob_str(&o, "\t ", 2); ob_str(&o, fn, L); o.buf[o.n++] = '\n';
+        for (int64_t b0 = 0; b0 < m;) {                          /* blocks of ~4 M overlaps (or 1 M queries) */
+            int64_t b1 = b0 + 1;
+            while (b1 < m && qoff[b1 + 1] - qoff[b0] <= blockHits && b1 - b0 < (1 << 20)) b1++;
+            fmt_job job[64];
+            pthread_t th[64];
+            int used = 0;
+            int64_t i0 = b0;
+            for (int t = 0; t < nt && i0 < b1; t++) {            /* equal shares of the block's overlaps (+queries) */
+                int64_t i1 = b1;
+                if (t + 1 < nt) {
+                    const int64_t want = qoff[b0] + (qoff[b1] - qoff[b0] + (b1 - b0)) * (t + 1) / nt;
+                    i1 = i0;
+                    while (i1 < b1 && qoff[i1 + 1] + (i1 + 1 - b0) <= want) i1++;
+                    if (i1 == i0) i1 = i0 + 1;
+                }
+                fmt_job *J = &job[used];
+                J->q = q; J->names = names; J->G = G; J->flen = flen; J->q0 = q0; J->qoff = qoff; J->hit = hit;
+                J->i0 = i0; J->i1 = i1;
+                J->o.n = 0;
+                J->o.cap = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + maxL) + 64;
+                J->o.buf = (char *)malloc(J->o.cap);
+                if (used > 0) pthread_create(&th[used], NULL, fmt_run, J);
+                used++;
+                i0 = i1;
             }
+            fmt_run(&job[0]);
+            for (int t = 0; t < used; t++) {
+                if (t > 0) pthread_join(th[t], NULL);
+                if (job[t].o.n) fwrite(job[t].o.buf, 1, job[t].o.n, stdout);
+                free(job[t].o.buf);
+            }
+            b0 = b1;
         }
         igd_hip_free(hit);
         hit = NULL;
         grand += total;
     }
-    ob_flush(&o);
-    free(o.buf);
+    free(flen);
     free(qoff);
     return grand;
 }
