@@ -156,6 +156,20 @@ class Database:
         _chk(self._H.igd_hip_hitmap(self.dev, 1 if v > 0 else 0, int(v), m.ctypes.data, C.byref(total)), "igd_hip_hitmap")
         return m, total.value
 
+    def seqpare(self, ichr, qs, qe, qgroup, ngroups, n_queries_total=None, nr=None):
+        """`-s` (Seqpare, seqOverlaps src/igd_search.c:354-451).  Queries in the reference's order: contigs
+        of the query file in first-seen order (qgroup = 0,1,.. non-decreasing), inside a contig by start
+        (stable).  Returns the per-dataset sums of matched similarities; with n_queries_total (all accepted
+        query lines, known contig or not) and nr (regions per dataset) the similarity S = sum/(Nq+nr-sum)."""
+        a = [np.ascontiguousarray(x, dtype=np.int32) for x in (ichr, qs, qe, qgroup)]
+        sums = np.zeros(max(self.nfiles, 1), np.float64)
+        _chk(self._H.igd_hip_seqpare(self.dev, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]),
+                                     a[3].ctypes.data, int(ngroups), sums.ctypes.data), "igd_hip_seqpare")
+        sums = sums[:self.nfiles]
+        if n_queries_total is None or nr is None:
+            return sums
+        return sums / (float(n_queries_total) + np.asarray(nr, np.float64) - sums)
+
     def batch_stats(self, d_ichr, d_qs, d_qe, nq, v=0):
         rule, vf = self.cli_dispatch(self.gtype, v)
         st = N.HipStats()

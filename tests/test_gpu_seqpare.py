@@ -116,3 +116,44 @@ int main(int argc, char **argv) {
         assert out.splitlines() == open(g + "/search_s.txt").read().splitlines()[1:]
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_python_database_seqpare_matches_golden_reference_numbers():
+    """igd_amd.Database.seqpare (ctypes over igd_hip_seqpare) with the query grouping done in Python."""
+    from igd_amd import Database
+    g = os.path.join(GOLDEN, "create")
+    d = short_tmpdir()
+    try:
+        shutil.copy(g + "/ref.igd", d + "/db.igd")
+        shutil.copy(g + "/ref_index.tsv", d + "/db_index.tsv")
+        db = Database(d + "/db.igd")
+        # contigs of the database, from the oracle-independent header reader of the test helpers
+        from test_oracle_create import split_igd
+        _, cn, _ = split_igd(d + "/db.igd")
+        cid = {n.decode(): i for i, n in enumerate(cn)}
+        groups, order = {}, []
+        nq_total = 0
+        for line in open(g + "/q.bed"):
+            f = line.rstrip("\n").split("\t")
+            if len(f) < 3 or not f[0].startswith("chr") or int(f[2]) <= 0 or int(f[1]) > int(f[2]):
+                continue
+            nq_total += 1
+            if f[0] not in groups:
+                groups[f[0]] = []
+                order.append(f[0])
+            groups[f[0]].append((int(f[1]), int(f[2])))
+        ichr, qs, qe, grp = [], [], [], []
+        ng = 0
+        for name in order:
+            if name not in cid:
+                continue
+            for s, e in sorted(groups[name], key=lambda x: x[0]):        # stable, by start
+                ichr.append(cid[name]); qs.append(s); qe.append(e); grp.append(ng)
+            ng += 1
+        nr = [int(l.split("\t")[2]) for l in open(d + "/db_index.tsv").read().splitlines()[1:]]
+        sm = db.seqpare(ichr, qs, qe, grp, ng, n_queries_total=nq_total, nr=nr)
+        want = [l.split("\t")[2].strip() for l in open(g + "/search_s.txt").read().splitlines()[1:]]
+        assert ["%.6f" % x for x in sm] == want
+        db.close()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
