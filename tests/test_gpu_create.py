@@ -266,7 +266,8 @@ def test_fewer_than_ten_files_and_gtype0():
         shutil.rmtree(d, ignore_errors=True)
 
 
-@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14)])
+@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14),
+                                     ("subdir_and_empty_file", 14)])
 def test_odd_inputs(which, b):
     """header-only database, 3000 contigs (global atomicMax path of k_span), intervals covering > 10^5 tiles,
     CRLF lines without a final newline -- same bytes as the oracle (pinned to the reference on the same inputs

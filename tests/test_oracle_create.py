@@ -211,13 +211,21 @@ def write_odd_inputs(d, which):
                 s = rng.randrange(0, 1 << 27)
                 rows.append("chr1\t%d\t%d\ty\t%d" % (s, s + rng.choice([1, 5000, 3000000]), i))
             open(d + "/in/f%02d.bed" % f, "w").write("\n".join(rows) + "\n")
+    elif which == "subdir_and_empty_file":       # a directory and an empty file among the inputs: 0 regions, "-nan" average
+        for f in range(11):
+            rows = ["chr1\t%d\t%d\tx\t%d" % (s, s + rng.randrange(1, 5000), i) for i, s in enumerate(rng.sample(range(100000), 50))]
+            open(d + "/in/f%02d.bed" % f, "w").write("\n".join(rows) + "\n")
+        os.makedirs(d + "/in/sub")
+        open(d + "/in/sub/inner.bed", "w").write("chr1\t1\t2\n")
+        open(d + "/in/zempty.bed", "w").write("")
     elif which == "no_trailing_newline_crlf":
         for f in range(10):
             body = "\r\n".join("chr%d\t%d\t%d\tn\t%d" % (1 + i % 2, 10 * i, 10 * i + 25, i) for i in range(40))
             open(d + "/in/f%02d.bed" % f, "wb").write(body.encode())      # CRLF, last line unterminated
 
 
-@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14)])
+@pytest.mark.parametrize("which,b", [("nothing_valid", 14), ("many_contigs", 13), ("huge_spans", 11), ("no_trailing_newline_crlf", 14),
+                                     ("subdir_and_empty_file", 14)])
 def test_odd_inputs_files_are_identical(which, b):
     build_oracle()
     d = short_tmpdir()
