@@ -26,7 +26,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def build_oracle():
     if not (os.path.exists(ORACLE_LIB) and os.path.exists(ORACLE_BIN)) or any(
         os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(ORACLE_LIB)
-        for f in ("igd_oracle.c", "igd_oracle.h")
+        for f in ("igd_oracle.c", "igd_oracle_create.c", "igd_oracle_main.c", "igd_oracle.h")
     ):
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
     return ORACLE_LIB
