@@ -203,13 +203,28 @@ int32_t get_overlaps_v(char *chrm, int32_t qs, int32_t qe, int32_t v, int64_t *h
 }
 
 /* ------------------------------- query files ------------------------------------------ */
+/* the query file is parsed (host threads) while the database goes to the GPU (first search only) */
+typedef struct { const char *qFile; igdc_queries q; int rc; } parse_job;
+static void *parse_run(void *arg)
+{
+    parse_job *J = (parse_job *)arg;
+    J->rc = igdc_read_queries(g_core, J->qFile, 1, &J->q);
+    return NULL;
+}
+
 static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
 {
     if (!g_core || !cur_igd()) { engine(); }
-    igdc_queries q;
+    parse_job J;
+    J.qFile = qFile; J.rc = -1;
     double t0 = now_s();
-    if (igdc_read_queries(g_core, qFile, 1, &q) != 0) return 0;      /* :701-702 */
-    phase("read + parse queries", &t0);
+    pthread_t th;
+    const int threaded = !(g_core->dev) && pthread_create(&th, NULL, parse_run, &J) == 0;
+    if (threaded) { engine(); pthread_join(th, NULL); }
+    else parse_run(&J);
+    if (J.rc != 0) return 0;                                         /* :701-702 */
+    igdc_queries q = J.q;
+    phase(threaded ? "database -> GPU  ||  read + parse queries" : "read + parse queries", &t0);
     int64_t total = 0;
     if (q.n > 0) {
         igd_hip_db *dev = engine();

@@ -353,6 +353,13 @@ static void write_index(const char *path, char **files, int32_t nf, const int32_
     fclose(fpi);
 }
 
+static void *warm_gpu(void *arg)
+{
+    (void)arg;
+    (void)igd_hip_device_count();          /* first HIP call: loads and initialises the runtime */
+    return NULL;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 int igdc_create(const igdc_create_opts *o)
 {
@@ -412,6 +419,10 @@ int igdc_create(const igdc_create_opts *o)
         if ((o->mode == IGDC_CREATE_GTYPE0 && cli) || py || rr) printf("igd_create 1: %i\n", nf);
     }
 
+    /* the HIP runtime starts up (~70 ms) while the files are parsed */
+    pthread_t warm;
+    const int warming = pthread_create(&warm, NULL, warm_gpu, NULL) == 0;
+
     /* 2. parse: one part per file, in parallel; BED4 is one file, one thread */
     nparts = nf;
     parts = (part *)calloc((size_t)nparts, sizeof(part));
@@ -449,7 +460,8 @@ int igdc_create(const igdc_create_opts *o)
         }
     }
 
-    PHASE("parse (host threads)");
+    if (warming) pthread_join(warm, NULL);
+    PHASE("parse (host threads) || HIP start-up");
     int32_t *nr = NULL; double *avg = NULL;
     char **idxNames = files;
     int32_t nIdx = nf;

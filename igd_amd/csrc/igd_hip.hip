@@ -184,7 +184,8 @@ struct igd_hip_db {
     void *d_pairs;                // int2[cap*K] (or int4 for the enumerate path)
     int2 *d_long, *d_fix;         // exact-walk lists: bucket path / merge-join path
     int32_t *d_ctl;               // control words (CTL_*)
-    int64_t wsQueries;            // capacity in queries
+    int64_t wsQueries;            // capacity in queries (merge-join arrays)
+    int64_t wsBucket;             // capacity in queries of the bucket-path structures
     int pairBytes;
     u64 *d_slab;
     int grid, ldsBytes;
@@ -1977,31 +1978,33 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 }
 
 // workspace for `nq` queries with `pairBytes` per pair slot
+// Per-batch workspace.  pairBytes == 0: the caller promised an ordered batch -- only the merge join's
+// arrays are needed (the CLI's common case: no 100+ MB of bucket structures to allocate first).
 static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
 {
-    if (nq <= db->wsQueries && pairBytes <= db->pairBytes) return IGD_HIP_OK;
-    HIPCHK(hipDeviceSynchronize());
-    int64_t cap = nq > db->wsQueries ? nq : db->wsQueries;
-    int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
-    if (db->d_pairs) (void)hipFree(db->d_pairs);
-    if (db->d_long) (void)hipFree(db->d_long);
-    if (db->d_fix) (void)hipFree(db->d_fix);
-    if (db->d_qw) (void)hipFree(db->d_qw);
-    {
-        void *ws[] = { db->d_spTable, db->d_spT, db->d_spBase };
-        for (void *q : ws) if (q) (void)hipFree(q);
-        db->d_spTable = nullptr; db->d_spT = nullptr; db->d_spBase = nullptr;
+    int rc;
+    if (nq > db->wsQueries) {
+        HIPCHK(hipDeviceSynchronize());
+        if (db->d_fix) (void)hipFree(db->d_fix);
+        if (db->d_qw) (void)hipFree(db->d_qw);
+        db->d_fix = nullptr; db->d_qw = nullptr;
+        db->wsQueries = 0;
+        if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
+        if ((rc = dalloc(&db->d_qw, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+        db->wsQueries = nq;
     }
-    db->d_pairs = nullptr; db->d_long = nullptr; db->d_fix = nullptr; db->d_qw = nullptr;
-    db->wsQueries = 0;
-    int rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr);
-    if (rc != IGD_HIP_OK) return rc;
-    rc = dalloc(&db->d_long, (size_t)cap, nullptr);
-    if (rc != IGD_HIP_OK) return rc;
-    rc = dalloc(&db->d_fix, (size_t)cap * 2, nullptr);     // a query can be both long and WALK_FIRST
-    if (rc != IGD_HIP_OK) return rc;
-    rc = dalloc(&db->d_qw, (size_t)cap, nullptr);
-    if (rc != IGD_HIP_OK) return rc;
+    if (pairBytes == 0 || (nq <= db->wsBucket && pairBytes <= db->pairBytes)) return IGD_HIP_OK;
+    HIPCHK(hipDeviceSynchronize());
+    const int64_t cap = nq > db->wsBucket ? nq : db->wsBucket;
+    const int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
+    {
+        void *ws[] = { db->d_pairs, db->d_long, db->d_spTable, db->d_spT, db->d_spBase };
+        for (void *q : ws) if (q) (void)hipFree(q);
+        db->d_pairs = nullptr; db->d_long = nullptr; db->d_spTable = nullptr; db->d_spT = nullptr; db->d_spBase = nullptr;
+    }
+    db->wsBucket = 0;
+    if ((rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&db->d_long, (size_t)cap, nullptr)) != IGD_HIP_OK) return rc;
     {   // split path geometry: <= SP_MAXC coarse buckets of 2^shift tiles, 2^shift counters x 2 in LDS
         int sh = 8;
         while (sh < 13 && ((db->nT + (1 << sh) - 1) >> sh) > SP_MAXC) sh++;
@@ -2014,7 +2017,7 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
             if ((rc = dalloc(&db->d_spBase, SP_MAXC + 2, nullptr)) != IGD_HIP_OK) return rc;
         }
     }
-    db->wsQueries = cap;
+    db->wsBucket = cap;
     db->pairBytes = pb;
     return IGD_HIP_OK;
 }
@@ -2094,7 +2097,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         }
         return IGD_HIP_OK;
     }
-    int rc = ensure_workspace(db, nq, 8);
+    int rc = ensure_workspace(db, nq, (flags & IGD_HIP_FLAG_SORTED) ? 0 : 8);
     if (rc != IGD_HIP_OK) return rc;
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
     const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
@@ -2219,14 +2222,20 @@ extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int3
     HIPCHK(hipMemsetAsync(db->d_total, 0, 8, st));
     for (int64_t q0 = 0; q0 < nq; q0 += IGD_MAX_BATCH) {
         int64_t m = nq - q0 < IGD_MAX_BATCH ? nq - q0 : IGD_MAX_BATCH;
+        const bool timing = getenv("IGD_TIMING") != nullptr;
+        auto now = []() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+        double t0 = now();
         int rc = ensure_qstage(db, m);
         if (rc != IGD_HIP_OK) return rc;
+        if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[igd timing]   search: query staging alloc     %7.1f ms\n", now() - t0); t0 = now(); }
         HIPCHK(hipMemcpyAsync(db->d_qc, ichr + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(db->d_qs, qs + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(db->d_qe, qe + q0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+        if (timing) { (void)hipStreamSynchronize(st); fprintf(stderr, "[igd timing]   search: H2D queries             %7.1f ms\n", now() - t0); t0 = now(); }
         rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, flags, db->d_hits, db->d_total, st);
         if (rc != IGD_HIP_OK) return rc;
         rc = igd_hip_sync(db, st);                       // staging buffers are reused; promise checked
+        if (timing) fprintf(stderr, "[igd timing]   search: workspace + kernels        %7.1f ms\n", now() - t0);
         if (rc == IGD_HIP_ERR_UNSORTED) {
             // the caller's order promise did not hold for this slice (it added nothing): redo it
             // with the device choosing the grouping
