@@ -161,3 +161,35 @@ def test_cli_hitmap_file_identical_to_reference(case):
             assert open(out).read() == open(os.path.join(dst, hm["file"])).read(), (case, hm["args"])
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_reference_main_linked_against_libigd_prints_reference_output():
+    """the reference's OWN main() (src/igd.c compiled against the reference's headers by
+    oracle/Makefile, where the source lies) linked against this repository's libigd.so -- `search` in
+    every mode and `create` must behave like the reference binary did (golden stdout / files)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "igd_main_on_libigd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/igd_main_on_libigd not built (needs /root/reference at build time)")
+    n = 0
+    for case in CASES:
+        d, dst, man = materialize(case)
+        try:
+            for run in man["runs"]:
+                if "-o" in run["args"]:
+                    continue
+                got = subprocess.run([exe] + run["args"], cwd=dst, stdout=subprocess.PIPE, timeout=600).stdout.decode()
+                assert got == open(os.path.join(dst, run["stdout"])).read(), (case, run["args"])
+                n += 1
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    assert n >= 30
+    d = short_tmpdir()
+    try:
+        g = os.path.join(GOLDEN, "create")
+        p = subprocess.run([exe, "create", g + "/in/", d + "/o", "db", "-b", "12"], stdout=subprocess.PIPE, timeout=600)
+        assert p.stdout.decode().replace(d + "/o/", "OUT/").replace(g + "/in/", "IN/") == open(g + "/stdout.txt").read()
+        from test_oracle_create import same_igd
+        same_igd(d + "/o/db.igd", g + "/ref.igd")
+        assert open(d + "/o/db_index.tsv", "rb").read() == open(g + "/ref_index.tsv", "rb").read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
