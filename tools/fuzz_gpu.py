@@ -59,7 +59,7 @@ def main():
             for cmd in cmds:
                 same = run(IGD, cmd) == run(ORC, cmd)
                 ok = ok and same
-                label = "-r" if "-r" in cmd else "-q" + "".join(x for x in cmd[5:] if x.startswith("-"))
+                label = "-r" if "-r" in cmd else "-q" + "".join(x for x in cmd[4:] if x.startswith("-"))
                 what.append(label + ("" if same else "!"))
             if not s0 and nfiles <= 25:
                 run(IGD, ["search", db, "-m", "-o", d + "/m_gpu.txt"]); run(ORC, ["search", db, "-m", "-o", d + "/m_orc.txt"])
