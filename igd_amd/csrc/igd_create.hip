@@ -336,9 +336,8 @@ extern "C" int igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_
     double tmark = now_ms();
     {
         CHK(hipSetDevice(device));
-        hipDeviceProp_t prop;
-        CHK(hipGetDeviceProperties(&prop, device));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        CHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));   // not hipGetDeviceProperties (~30 ms)
+        if (cus <= 0) cus = 256;
         CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         out->nTile = (int32_t *)calloc((size_t)(nCtg > 0 ? nCtg : 1), sizeof(int32_t));
         tbase = (int64_t *)calloc((size_t)nCtg + 1, sizeof(int64_t));

@@ -1777,11 +1777,12 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 #define TRY(x) do { rc = (x); if (rc != IGD_HIP_OK) { igd_hip_close(db); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); igd_hip_close(db); return IGD_HIP_ERR_DEVICE; } } while (0)
     TRYHIP(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
+    OPEN_PHASE("host tables, stream");
     size_t n = (size_t)d->nRecords;
     {   // launch geometry first: the slab is part of the arena
-        hipDeviceProp_t prop0;
-        TRYHIP(hipGetDeviceProperties(&prop0, device));
-        int cus = prop0.multiProcessorCount > 0 ? prop0.multiProcessorCount : 256;
+        int cus = 0;                                     // one attribute, not hipGetDeviceProperties (~30 ms)
+        TRYHIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        if (cus <= 0) cus = 256;
         db->ldsBytes = (int)((size_t)d->nFiles * 8);
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
@@ -1802,6 +1803,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         else db->arena = nullptr;                        // fall back to individual allocations
         t_arenaOwner = db;
     }
+    OPEN_PHASE("device props, arena");
     TRY(dalloc(&db->d_start, n, acct));
     TRY(dalloc(&db->d_end, n, acct));
     TRY(dalloc(&db->d_idx, n, acct));
@@ -1821,13 +1823,14 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_hits, (size_t)d->nFiles + 1, acct));
     TRY(dalloc(&db->d_total, 4, acct));
     TRYHIP(hipMemcpy(db->d_tileOff, tileOff.data(), ((size_t)nT + 1) * 8, hipMemcpyHostToDevice));
+    OPEN_PHASE("first H2D copy");
     TRYHIP(hipMemcpy(db->d_tileCnt, tileCnt.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_tileBd, tileBd.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgBase, ctgBase.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     if (!units.empty())
         TRYHIP(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(Unit), hipMemcpyHostToDevice));
-    OPEN_PHASE("tables + hipMalloc");
+    OPEN_PHASE("other table copies");
     // records: the AoS region goes through two pinned staging buffers -- the CPU fills one
     // (memcpy from the caller's memory, or pread from the .igd when desc->fd is used) while the
     // previous one is copied to the GPU and transposed there (SoA) on the engine's stream.
