@@ -227,3 +227,19 @@ print(json.dumps(out))
     assert p.returncode == 0, p.stderr.decode()[-800:]
     got = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert got == pins
+
+
+def test_f_output_does_not_depend_on_the_number_of_formatting_threads():
+    """`-f` text is produced by several threads (contiguous query ranges, written in order): any thread count must
+    give the reference's bytes."""
+    for case in ("smallrand", "edge", "gtype0"):
+        d, dst, man = materialize(case)
+        try:
+            run = [r for r in man["runs"] if "-f" in r["args"] and "-q" in r["args"]][0]
+            want = open(os.path.join(dst, run["stdout"])).read()
+            for nt in ("1", "3", "16", "64"):
+                got = subprocess.run([os.path.join(ROOT, "bin", "igd")] + run["args"], cwd=dst, stdout=subprocess.PIPE, timeout=600,
+                                     env=dict(os.environ, IGD_PRINT_THREADS=nt)).stdout.decode()
+                assert got == want, (case, nt)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
