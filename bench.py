@@ -124,6 +124,13 @@ def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5, extra=()):
     return res
 
 
+def box_copy_rate():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_peak.json")))["copy_GBps_read_plus_write"]
+    except Exception:
+        return None
+
+
 def measured_traffic(mode, args):
     """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile.sh
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of THIS command; FETCH_SIZE doubled
@@ -266,6 +273,7 @@ def main():
                          # the same kernel time against the MEASURED HBM bytes (PMC), next to the algorithmic figure
                          "traffic_rate": (traffic / scan_s / 1e9) if (traffic and scan_s > 0) else None,
                          "traffic_frac": (traffic / scan_s / 1e9 / HBM_PEAK_GBS) if (traffic and scan_s > 0) else None,
+                         "box_copy_rate": box_copy_rate(),   # GB/s a device-to-device copy reaches on this class of box (tools/hbm_peak.py)
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bytes_per_query": algo_bytes / Q, "kernel_ms": prof["scan_ms"],
                          "pipeline_ms": prof["pipeline_ms"], "launches_timed": prof["launches"],
