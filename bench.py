@@ -4,15 +4,33 @@ search (igd search -q, hits-only) on a roadmap-scale synthetic .igd, on N MI355X
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of Q device-resident queries per GPU:
-bucket (count/scan/scatter) -> igd_scan_tiles -> slab reduce, then (N>1) ONE RCCL all-reduce of
-the nFiles-long int64 hits vector.  Weak scaling: every rank owns the same database and its
-own Q queries.  Prints ONE JSON line on rank 0 (contract in the task statement), with
-  roofline     : dominant kernel (igd_scan_tiles) -- algorithmic bytes per launch (SURVEY.md 8d
-                 terms, computed exactly on the GPU by igd_hip_batch_stats) / its HIP-event time
+One "step" = one pass of the hot path over one batch of Q device-resident queries per GPU
+(k_query_bounds -> igd_scan_tiles -> k_reduce_slabs; the bucket kernels when the batch is not
+ordered); a job = K steps accumulating into hits[] + (N>1) ONE RCCL all-reduce of the
+nFiles-long int64 hits vector, all inside the timed region.
+
+Workloads (BASELINE.json `configs`):
+  N = 1  config 2: the roadmap-scale .igd + 10^6 position-sorted queries (seed 7);
+  N > 1  config 4: ONE position-sorted set of N x 1.25e7 queries (seed 7), rank r takes the r-th
+         contiguous slab (igd_amd.dist.shard_bounds) -- at N = 8 that is 10^8 queries; weak scaling.
+N > 1 is one process per GPU.  Started by the driver through torch.distributed.run the ranks find
+RANK/WORLD_SIZE/MASTER_* in the environment; started as plain `python bench.py --gpus N` this
+process spawns the N ranks itself -- BEFORE it touches the GPU or imports torch -- and relays
+rank 0's JSON line.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline     : dominant kernel (igd_scan_tiles).  `achieved` / `frac` price its HIP-event time
+                 against the COMPULSORY bytes of the batch, computed in this run by the engine
+                 (igd_hip_batch_traffic: every visited unit's records once in the bytes of the image
+                 read + descriptors + queries + counter rows) -- a fraction that cannot exceed 1.  The
+                 algorithmic bytes of SURVEY.md 8(d) (what the REFERENCE's algorithm touches, computed
+                 exactly on the GPU by igd_hip_batch_stats) are reported next to it as algorithmic_*;
+                 `box` = what a float4 copy / read kernel and pinned PCIe copies reach on this box now.
   cpu_baseline : the REAL reference `igd search -q` (oracle/_ref/igd, kind "reference") on the
                  same .igd and the same queries as BED text, 1 thread; falls back to the oracle
                  port (kind "port") when the prebuilt reference binary did not travel.
+  extra_configs: short timed runs of configs 3 (`-v 500`), shuffled input, config 4's per-GPU share
+                 (1.25e7 queries on one GPU) and config 5 (`-f`) in the same process (N = 1 only).
 The oracle / reference are used here ONLY for that baseline and to check the GPU totals.
 """
 import argparse
@@ -25,14 +43,61 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured copy rate
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); the box's own copy rate is measured below
+CONFIG4_PER_GPU = 12500000
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def ensure_db(path, files, per_file, rank, world, barrier):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--queries", type=int, default=0,
+                    help="queries per GPU per step (default: 10^6 at N=1 = config 2; 1.25e7 at N>1 = config 4)")
+    ap.add_argument("--files", type=int, default=1900)
+    ap.add_argument("--per-file", type=int, default=26316)
+    ap.add_argument("--shuffled", action="store_true", help="queries in generation order, not position-sorted (N=1)")
+    ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
+    ap.add_argument("--dir", default="/tmp/igdb")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
+    ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
+    ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
+                    help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
+                         "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
+                         "promises (contig,start) order -- what a position-sorted BED is -- and the device VERIFIES it "
+                         "in the timed region (a broken promise is an error, never a wrong count); bucket: always "
+                         "counting-sort.  default = sorted for the position-sorted workload, auto with --shuffled")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process only spawns (no torch, no HIP call here, ever)
+def spawn_ranks(n, argv):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+def ensure_db(path, files, per_file, rank, barrier):
     """rank 0 generates the .igd (deterministic, ~20 s for the roadmap scale); others wait."""
     from igd_amd import synth
     done = path + ".done"
@@ -124,54 +189,140 @@ def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5, extra=()):
     return res
 
 
-def box_copy_rate():
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r01", "hbm_peak.json")))["copy_GBps_read_plus_write"]
-    except Exception:
-        return None
-
-
-def measured_traffic(mode, args):
-    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/profile.sh
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of THIS command; FETCH_SIZE doubled
-    as MI355X_MICROARCH.md prescribes for gfx950 streaming reads).  Counters cannot be collected
-    from inside the benchmark process, so the committed summary is reported when it was taken with
-    the same workload; otherwise null."""
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile.sh:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 streaming reads).  Counters cannot be collected from inside the benchmark
+    process: this is a CONSTANT of a committed profile of the same workload, tagged with its source."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        t = json.load(open(path))
-        key = "%s/%s/q%d%s" % (mode, "shuffled" if args.shuffled else "sorted", args.queries, "/exact" if args.exact_arrays else "")
-        return t.get(key, {}).get("hbm_bytes_per_launch")
+        t = json.load(open(path)).get(key)
+        if t:
+            return t.get("hbm_bytes_per_launch"), "profiles/traffic.json[%s] (%s)" % (key, t.get("source", "committed rocprofv3 --pmc run"))
     except Exception:
-        return None
+        pass
+    return None, None
+
+
+class Job:
+    """One resident batch + the timed loop over it (shared by the headline run and extra_configs)."""
+
+    def __init__(self, db, dev, stream, ichr, qs, qe, v, gflags):
+        import torch
+        self.db, self.dev, self.stream, self.v, self.gflags = db, dev, stream, v, gflags
+        self.Q = len(qs)
+        self.d_ichr = torch.from_numpy(ichr).to(dev)
+        self.d_qs = torch.from_numpy(qs).to(dev)
+        self.d_qe = torch.from_numpy(qe).to(dev)
+        self.d_hits = torch.zeros(max(db.nfiles, 1), dtype=torch.int64, device=dev)
+
+    def step(self):
+        self.db.search_dev(self.d_ichr.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr(), self.Q,
+                           self.d_hits.data_ptr(), None, v=self.v, stream=self.stream, flags=self.gflags)
+
+    def run(self, steps, warmup, barrier=lambda: None, collective=lambda t: None):
+        """W untimed steps, then exactly K steps + the path's one collective between barrier+synchronize."""
+        import torch
+        for _ in range(warmup):
+            self.step()
+        collective(self.d_hits)                 # also warms RCCL up (first call builds the communicator)
+        torch.cuda.synchronize(self.dev)
+        barrier()
+        torch.cuda.synchronize(self.dev)
+        self.db.profile_begin(steps)
+        t0 = time.perf_counter()
+        self.d_hits.zero_()
+        for _ in range(steps):
+            self.step()
+        collective(self.d_hits)                 # the one collective of the path
+        torch.cuda.synchronize(self.dev)
+        barrier()
+        t1 = time.perf_counter()
+        self.db.sync(self.stream)               # surfaces a broken --grouping sorted promise
+        prof = self.db.profile_end()
+        return t1 - t0, prof
+
+    def roofline(self, prof, traffic_key=None):
+        db = self.db
+        p = (self.d_ichr.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr())
+        st = db.batch_stats(*p, self.Q, v=self.v)
+        mode = "v" if (self.v > 0 and db.gtype == 1) else "hits"
+        algo = db.algorithmic_bytes(st, self.Q, mode)
+        tr = db.batch_traffic(*p, self.Q, v=self.v, flags=self.gflags)
+        scan_s = prof["scan_ms"] * 1e-3
+        ach = tr["total"] / scan_s / 1e9 if scan_s > 0 else 0.0
+        pmc, src = pmc_traffic(traffic_key) if traffic_key else (None, None)
+        return {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS,
+                "bytes_per_launch": tr["total"], "bytes_source": "compulsory traffic computed in this run (igd_hip_batch_traffic)",
+                "bytes_breakdown": tr,
+                "traffic": pmc, "traffic_source": src,
+                "algorithmic_bytes_per_launch": algo, "algorithmic_achieved": algo / scan_s / 1e9 if scan_s > 0 else 0.0,
+                "algorithmic_frac": algo / scan_s / 1e9 / HBM_PEAK_GBS if scan_s > 0 else 0.0,
+                "algorithmic_bytes_per_query": algo / self.Q,
+                "kernel_ms": prof["scan_ms"], "pipeline_ms": prof["pipeline_ms"], "launches_timed": prof["launches"],
+                "work": st}
+
+
+def extra_configs(db, dev, stream, args, box):
+    """Short driver-visible runs of the other single-GPU configurations (BASELINE configs 3, 4-share, 5)."""
+    import numpy as np
+    from igd_amd import synth
+    out = []
+    Q = 1000000
+    base = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=True)
+    shuf = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=False)
+    dense = synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
+    cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100),
+             ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100),
+             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30)]
+    for name, (ichr, qs, qe), v, gflags, steps in cases:
+        try:
+            job = Job(db, dev, stream, ichr, qs, qe, v, gflags)
+            el, prof = job.run(steps, 3)
+            rl = job.roofline(prof)
+            out.append({"workload": name, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
+                        "ms_per_step": 1e3 * el / steps, "kernel_ms": prof["scan_ms"], "roofline_frac": rl["frac"],
+                        "bytes_per_launch": rl["bytes_per_launch"], "algorithmic_frac": rl["algorithmic_frac"],
+                        "hits_per_step": int(job.d_hits.sum().item()) // steps})
+            del job
+        except Exception as e:                              # a side measurement must not lose the line
+            out.append({"workload": name, "error": str(e)})
+    # config 5: -f through the C API (count + scan + chunked fill + pinned D2H, result in host memory)
+    try:
+        ichr, qs, qe = base
+        db.enumerate_stream(ichr, qs, qe)                   # warm: workspace + pinned buffers
+        best, tot = None, 0
+        for _ in range(3):
+            t = time.perf_counter()
+            _, tot = db.enumerate_stream(ichr, qs, qe)
+            dt = time.perf_counter() - t
+            best = dt if best is None else min(best, dt)
+        nbytes = 16 * tot
+        d2h = box.get("d2h_GBps") or 0.0
+        out.append({"workload": "config 5: -f enumeration of 10^6 position-sorted queries, overlaps streamed to pinned host memory "
+                                "(igd_hip_enumerate_stream, H2D of the queries included)",
+                    "value": Q / best, "unit": "query-intervals/s", "ms_per_call": 1e3 * best, "overlaps": int(tot),
+                    "records_per_s": tot / best, "output_bytes": int(nbytes),
+                    "roofline": {"bound": "pcie-d2h", "achieved": nbytes / best / 1e9, "peak": d2h, "unit": "GB/s",
+                                 "frac": (nbytes / best / 1e9 / d2h) if d2h else None,
+                                 "peak_source": "pinned device->host hipMemcpyAsync of 256 MiB measured in this run"}})
+    except Exception as e:
+        out.append({"workload": "config 5: -f", "error": str(e)})
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--queries", type=int, default=1000000, help="queries per GPU per step")
-    ap.add_argument("--files", type=int, default=1900)
-    ap.add_argument("--per-file", type=int, default=26316)
-    ap.add_argument("--shuffled", action="store_true", help="queries in generation order, not position-sorted")
-    ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
-    ap.add_argument("--dir", default="/tmp/igdb")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
-    ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
-                    help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
-                         "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
-                         "promises (contig,start) order -- what a position-sorted BED is -- and the device VERIFIES it "
-                         "in the timed region (a broken promise is an error, never a wrong count); bucket: always "
-                         "counting-sort.  default = sorted for the position-sorted workload, auto with --shuffled")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from igd_amd import Database, synth
-    from igd_amd.dist import allreduce_hits, init_from_env
+    from igd_amd.database import measure_rates
+    from igd_amd.dist import allreduce_hits, init_from_env, shard_bounds
 
     rank, world, local = init_from_env()
     if world != args.gpus:
@@ -188,17 +339,23 @@ def main():
             dist.barrier()
 
     igd_path = os.path.join(args.dir, "rm%dx%d.igd" % (args.files, args.per_file))
-    ensure_db(igd_path, args.files, args.per_file, rank, world, barrier)
+    ensure_db(igd_path, args.files, args.per_file, rank, barrier)
 
     t = time.time()
     db = Database(igd_path, device=local)
     open_s = time.time() - t
-    Q = args.queries
-    ichr, qs, qe = synth.make_queries(Q, seed=7 + rank, genome=synth.HG38, sorted_=not args.shuffled)
-    d_ichr = torch.from_numpy(ichr).to(dev)
-    d_qs = torch.from_numpy(qs).to(dev)
-    d_qe = torch.from_numpy(qe).to(dev)
-    d_hits = torch.zeros(max(db.nfiles, 1), dtype=torch.int64, device=dev)
+    if world == 1:
+        Q = args.queries or 1000000
+        ichr, qs, qe = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=not args.shuffled)
+        wl = ("%d %s queries per step (seed 7)" % (Q, "generation-order" if args.shuffled else "position-sorted"))
+    else:
+        # config 4: ONE position-sorted set, contiguous slabs
+        Q = args.queries or CONFIG4_PER_GPU
+        lo, hi = shard_bounds(world * Q, world, rank)
+        ichr, qs, qe = synth.make_queries_slab(world * Q, lo, hi, seed=7, genome=synth.HG38)
+        args.shuffled = False
+        wl = ("ONE position-sorted set of %d x %d = %d queries (seed 7), rank r owns the r-th contiguous slab of %d "
+              "(one batch per step)" % (world, Q, world * Q, Q))
     # One explicit (non-default) stream carries everything: torch's memsets/adds, the engine's
     # kernels (it enqueues on the hipStream_t it is given) and the RCCL all-reduce.
     tstream = torch.cuda.Stream(device=dev)
@@ -215,70 +372,42 @@ def main():
     # one accumulator over the whole query file (src/igd_search.c:925,1032-1039) and the engine adds --
     # followed by the path's ONE exchange: a SUM all-reduce of hits[nFiles] (no-op at N=1).  Both are
     # inside the timed region.
-    def step():
-        db.search_dev(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, d_hits.data_ptr(), None,
-                      v=args.v, stream=stream, flags=gflags)
-
-    for _ in range(args.warmup):
-        step()
-    allreduce_hits(d_hits)                  # also warms RCCL up (first call builds the communicator)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    db.profile_begin(args.steps)
-    t0 = time.perf_counter()
-    d_hits.zero_()
-    for _ in range(args.steps):
-        step()
-    allreduce_hits(d_hits)                  # the one collective of the path
-    torch.cuda.synchronize(dev)
-    barrier()
-    t1 = time.perf_counter()
-    db.sync(stream)                      # surfaces a broken --grouping sorted promise
-    prof = db.profile_end()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    job = Job(db, dev, stream, ichr, qs, qe, args.v, gflags)
+    elapsed, prof = job.run(args.steps, args.warmup, barrier, allreduce_hits)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
 
-    # exact algorithmic work of one launch on this rank's batch (outside the timed region)
-    st = db.batch_stats(d_ichr.data_ptr(), d_qs.data_ptr(), d_qe.data_ptr(), Q, v=args.v)
     mode = "v" if (args.v > 0 and db.gtype == 1) else "hits"
-    algo_bytes = db.algorithmic_bytes(st, Q, mode)
-    hits_job = d_hits.cpu().numpy()       # K identical batches per rank, summed over ranks
+    hits_job = job.d_hits.cpu().numpy()      # K identical batches per rank, summed over ranks
     assert args.steps > 0 and (hits_job % args.steps == 0).all(), "hits[] is not K times one batch"
-    hits_one = hits_job // args.steps     # one batch per rank, summed over ranks
+    hits_one = hits_job // args.steps        # one batch per rank, summed over ranks
+    tkey = "%s/%s/q%d%s" % (mode, "shuffled" if args.shuffled else "sorted", Q, "/exact" if args.exact_arrays else "")
+    rl = job.roofline(prof, tkey if world == 1 else None)     # outside the timed region
 
     if rank == 0:
+        box = measure_rates(local)
+        rl["box"] = dict(box, note="measured in this run by igd_hip_measure_rates: float4 copy kernel (read+write bytes), "
+                                   "float4 read-only kernel, pinned D2H / H2D copies")
         value = world * Q * args.steps / elapsed
-        scan_s = prof["scan_ms"] * 1e-3
-        achieved = algo_bytes / scan_s / 1e9 if scan_s > 0 else 0.0
-        traffic = measured_traffic(mode, args)
         line = {
             "metric": "query-intervals/sec (igd search -q, hits-only) on roadmap-scale synthetic .igd",
             "value": value, "unit": "query-intervals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "roadmap-scale synthetic IGD: %d files x %d intervals (%d tile records, "
-                                   "%d tiles of 16384 bp, hg38 contigs) + %d %s queries per GPU per step, "
-                                   "%s, queries and DB resident in HBM"
-                                   % (args.files, args.per_file, db.nrecords, db.ntiles, Q,
-                                      "generation-order" if args.shuffled else "position-sorted",
+            "config": {"workload": "%s: roadmap-scale synthetic IGD, %d files x %d intervals (%d tile records, "
+                                   "%d tiles of 16384 bp, hg38 contigs) replicated per GPU + %s, %s, queries and DB resident in HBM"
+                                   % ("BASELINE config 2" if world == 1 else "BASELINE config 4", args.files, args.per_file,
+                                      db.nrecords, db.ntiles, wl,
                                       "-v %d signal filter" % args.v if mode == "v" else "hits-only"),
-                       "queries_per_gpu": Q, "nfiles": db.nfiles, "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
+                       "queries_per_gpu": Q, "queries_per_step_all_gpus": world * Q, "nfiles": db.nfiles,
+                       "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
                        "collective": ("ONE sum all-reduce of int64[%d] per job (after the %d batches), inside the timed region"
                                       % (db.nfiles, args.steps)) if world > 1 else "none"},
-            "roofline": {"bound": "hbm", "kernel": "igd_scan_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # the same kernel time against the MEASURED HBM bytes (PMC), next to the algorithmic figure
-                         "traffic_rate": (traffic / scan_s / 1e9) if (traffic and scan_s > 0) else None,
-                         "traffic_frac": (traffic / scan_s / 1e9 / HBM_PEAK_GBS) if (traffic and scan_s > 0) else None,
-                         "box_copy_rate": box_copy_rate(),   # GB/s a device-to-device copy reaches on this class of box (tools/hbm_peak.py)
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "bytes_per_query": algo_bytes / Q, "kernel_ms": prof["scan_ms"],
-                         "pipeline_ms": prof["pipeline_ms"], "launches_timed": prof["launches"],
-                         "work": st},
+            "roofline": rl,
             "hits_per_step_total": int(hits_one.sum()),
+            "hits_checksum": int((hits_one.astype(np.uint64) * (np.arange(len(hits_one), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1)),
             "db_open_s": open_s,
         }
         if world == 1 and not args.no_cpu:
@@ -287,9 +416,13 @@ def main():
                 synth.write_bed(bed, synth.HG38, ichr, qs, qe)
             extra = ["-v", str(args.v)] if mode == "v" else []
             line["cpu_baseline"] = cpu_baseline(igd_path, bed, Q, int(hits_one.sum()), extra=extra)
+        if world == 1 and not args.no_extra:
+            line["extra_configs"] = extra_configs(db, dev, stream, args, box)
         print(json.dumps(line), flush=True)
+    del job
     db.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

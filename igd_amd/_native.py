@@ -87,7 +87,8 @@ class CoreDb(C.Structure):
                 ("cName", C.POINTER(C.c_char_p)), ("fileName", C.POINTER(C.c_char_p)),
                 ("fileNr", i32p), ("fileMd", C.POINTER(C.c_double)),
                 ("nTileTotal", C.c_int64), ("nRecords", C.c_int64), ("dataOff", C.c_int64),
-                ("dict", i32p), ("dictCap", C.c_int32), ("dev", C.c_void_p)]
+                ("dict", i32p), ("dictCap", C.c_int32), ("dev", C.c_void_p),
+                ("ndev", C.c_int32), ("devs", C.c_void_p * 16)]
 
 
 class CoreQueries(C.Structure):
@@ -97,6 +98,13 @@ class CoreQueries(C.Structure):
 
 IGD_HIP_RULE_NEST = 0
 IGD_HIP_RULE_FLAT = 1
+class HipTraffic(C.Structure):
+    _fields_ = [("units", C.c_int64), ("records", C.c_int64), ("record_bytes", C.c_int64), ("unit_bytes", C.c_int64),
+                ("query_bytes", C.c_int64), ("slab_bytes", C.c_int64), ("total", C.c_int64)]
+
+
+ENUM_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p)
+
 IGD_HIP_NO_VALUE_FILTER = -(2 ** 31)
 IGD_HIP_FLAG_SORTED = 1
 IGD_HIP_FLAG_BUCKET = 2
@@ -136,6 +144,12 @@ def hip():
         L.igd_hip_enumerate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.POINTER(C.POINTER(HipHit)), i64p]
         L.igd_hip_free.argtypes = [C.c_void_p]
+        L.igd_hip_enumerate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_void_p, ENUM_SINK, C.c_void_p, i64p]
+        L.igd_hip_batch_traffic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int32, C.c_int, C.c_int, C.POINTER(HipTraffic)]
+        L.igd_hip_measure_rates.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        L.igd_hip_seqpare_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.igd_hip_batch_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                           C.c_int32, C.c_int, C.POINTER(HipStats)]
         L.igd_hip_hitmap.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, i64p]
@@ -198,6 +212,7 @@ def cli():
         hip()
         L = _bind_core(_load("libigd.so"))
         L.igd_search.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.igd_engine_status.restype = C.c_int
         L.get_igdinfo.restype = C.c_void_p
         L.get_igdinfo.argtypes = [C.c_char_p]
         L.get_id.argtypes = [C.c_char_p]
@@ -226,6 +241,8 @@ def pyabi():
         L.get_overlaps.restype = None
         L.getOverlaps.argtypes = [C.c_void_p, C.c_char_p, i64p]
         L.getOverlaps.restype = C.c_int64
+        L.igd_engine_status.restype = C.c_int
+        L.igd_engine_clear.restype = None
         _py = L
     return _py
 
@@ -243,6 +260,8 @@ def rabi():
         L.igdr_search_n32.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), i32p, i32p, i32p]
         L.search_1.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32p, i32p, i64p]
         L.getOverlaps.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i64p]
+        L.igd_engine_status.restype = C.c_int
+        L.igd_engine_clear.restype = None
         _r = L
     return _r
 
@@ -260,6 +279,9 @@ def synth():
         L.igd_synth_queries.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int32, C.c_int32, C.c_int,
                                         C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.igd_synth_queries.restype = C.c_int64
+        L.igd_synth_queries_slab.argtypes = [C.c_int64, C.c_uint64, C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igd_synth_queries_slab.restype = C.c_int64
         L.igd_synth_write_bed.argtypes = [C.c_char_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.igd_synth_contig_name.restype = C.c_char_p
         L.igd_synth_contig_name.argtypes = [C.c_int, C.c_int]

@@ -5,7 +5,11 @@
  * its counterpart in /root/reference/src/igd_search.c / igd_base.c (lines cited at each
  * definition).  What differs is how the answer is computed: the whole tile region is put on
  * the GPU once and every call -- single query or query file -- is one batch for the engine.
- * There is no CPU search here; if no HIP device is usable the process stops with a message.
+ * There is no CPU search here.  A library must not end its host process (it may be a Python or R
+ * interpreter): if no HIP device is usable, the call prints why on stderr, returns the way the
+ * reference's silent failures return (src/igd_search.c:457,462,701-702: 0 / hits untouched) and
+ * igd_engine_status() is non-zero from then on; only `igd_search` -- the body of the command line
+ * tool -- turns that into a non-zero return value instead of printing a table of zeros.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -66,11 +70,18 @@ static int device_from_env(void)
     return e && *e ? atoi(e) : 0;
 }
 
-static void die_no_gpu(const char *where, int rc)
+static int g_fail_rc = 0;            /* code of the first engine failure of this process (0: none) */
+
+int igd_engine_status(void) { return g_fail_rc; }
+
+static void engine_failed(const char *where, int rc)
 {
-    fprintf(stderr, "igd: %s: GPU engine unavailable (code %d): %s\n"
-                    "igd: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
-    exit(EX_UNAVAILABLE);
+    if (rc == IGD_HIP_ERR_ARG || rc == IGD_HIP_ERR_NOMEM)
+        fprintf(stderr, "igd: %s: the GPU engine refused the request (code %d): %s\n", where, rc, igd_hip_last_error());
+    else
+        fprintf(stderr, "igd: %s: GPU engine unavailable (code %d): %s\n"
+                        "igd: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
+    if (!g_fail_rc) g_fail_rc = rc ? rc : IGD_HIP_ERR_DEVICE;
 }
 
 /* The engine for the current IGD, created at the first search call: this is the moment the
@@ -80,16 +91,21 @@ static igd_hip_db *engine(void)
     iGD_t *G = cur_igd();
     if (!G || !g_core) {
         fprintf(stderr, "igd: search called before get_igdinfo()\n");
-        exit(EX_SOFTWARE);
+        if (!g_fail_rc) g_fail_rc = IGD_HIP_ERR_ARG;
+        return NULL;
     }
     if (g_core->dev && igd_hip_nfiles(g_core->dev) == G->nFiles) return g_core->dev;
     g_core->nFiles = G->nFiles;          /* hits[] is sized from the TSV (:923-925) */
     double t0 = now_s();
     /* the path is preferred when known (pipelined pread + upload); fP serves callers that only
-     * opened the stream themselves */
-    int rc = g_core_path ? igdc_attach_path(g_core, g_core_path, device_from_env())
+     * opened the stream themselves.  IGD_DEVICES=0,1,..: the database goes to every listed GPU and
+     * query files are searched in contiguous slabs, one per device (igdc_search_multi) */
+    int devs[IGDC_MAX_DEVICES];
+    const int nd = g_core_path ? igdc_devices_from_env(devs, IGDC_MAX_DEVICES) : 0;
+    int rc = nd > 1 ? igdc_attach_path_multi(g_core, g_core_path, devs, nd)
+           : g_core_path ? igdc_attach_path(g_core, g_core_path, nd == 1 ? devs[0] : device_from_env())
                          : igdc_attach_fp(g_core, fP, device_from_env());
-    if (rc != IGD_HIP_OK) die_no_gpu("open", rc);
+    if (rc != IGD_HIP_OK) { engine_failed("open", rc); return NULL; }
     phase("database -> GPU", &t0);
     return g_core->dev;
 }
@@ -178,9 +194,10 @@ static int32_t one_query(const char *chrm, int32_t qs, int32_t qe, int32_t v, in
     int32_t ichr = get_id(chrm);
     if (ichr < 0) return 0;                                   /* :456-457 */
     igd_hip_db *dev = engine();
+    if (!dev) return 0;
     int64_t total = 0;
     int rc = igd_hip_search(dev, &ichr, &qs, &qe, 1, v, rule, hits, &total);
-    if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+    if (rc != IGD_HIP_OK) { engine_failed("search", rc); return 0; }
     return (int32_t)total;
 }
 
@@ -214,7 +231,7 @@ static void *parse_run(void *arg)
 
 static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
 {
-    if (!g_core || !cur_igd()) { engine(); }
+    if (!g_core || !cur_igd()) { engine(); return 0; }
     parse_job J;
     J.qFile = qFile; J.rc = -1;
     double t0 = now_s();
@@ -230,8 +247,10 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
         igd_hip_db *dev = engine();
         t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
-        int rc = igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
-        if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+        int rc = !dev ? IGD_HIP_OK
+               : g_core->ndev > 1 ? igdc_search_multi(g_core, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total)
+               : igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
+        if (rc != IGD_HIP_OK) { engine_failed("search", rc); total = 0; }
         phase("search (H2D + kernels + D2H)", &t0);
     }
     igdc_queries_free(&q);
@@ -333,9 +352,38 @@ void seqOverlaps(char *qFile, double *sm)
         ng++;
     }
     double *sums = (double *)calloc((size_t)nfiles + 1, sizeof(double));
-    if (n > 0) {
-        const int rc = igd_hip_seqpare(engine(), ichr, qs, qe, n, grp, ng, sums);
-        if (rc != IGD_HIP_OK) die_no_gpu("seqpare", rc);
+    /* The (query contig, dataset) groups are independent, so a query file beyond one engine batch (2^24
+     * queries, 2^32 overlaps; the reference has no limit) goes contig range by contig range; the engine
+     * continues the running double sums (igd_hip_seqpare_add), so the order of additions stays the reference's. */
+    igd_hip_db *dev = n > 0 ? engine() : NULL;
+    int failed = n > 0 && !dev;
+    for (int32_t g0 = 0; g0 < ng && !failed;) {
+        int64_t a0 = 0, a1;
+        while (a0 < n && grp[a0] < g0) a0++;
+        int32_t g1 = g0;
+        a1 = a0;
+        while (g1 < ng) {                                      /* as many whole contigs as fit one batch */
+            int64_t e = a1;
+            while (e < n && grp[e] == g1) e++;
+            if (g1 > g0 && e - a0 > igd_hip_max_batch()) break;
+            a1 = e; g1++;
+        }
+        for (;;) {
+            for (int64_t i = a0; i < a1; i++) grp[i] -= g0;    /* group numbers of the call start at 0 */
+            const int rc = igd_hip_seqpare_add(dev, ichr + a0, qs + a0, qe + a0, a1 - a0, grp + a0, g1 - g0, sums);
+            for (int64_t i = a0; i < a1; i++) grp[i] += g0;
+            if (rc == IGD_HIP_OK) break;
+            if (rc == IGD_HIP_ERR_ARG && g1 - g0 > 1) {          /* too many overlaps for one call: fewer contigs */
+                g1 = g0 + (g1 - g0) / 2;
+                a1 = a0;
+                while (a1 < n && grp[a1] < g1) a1++;
+                continue;
+            }
+            engine_failed("seqpare", rc);
+            failed = 1;
+            break;
+        }
+        g0 = g1;
     }
     for (int32_t m = 0; m < nfiles; m++) sm[m] = sums[m] / ((double)Nq + G->finfo[m].nr - sums[m]);   /* :446-449 */
     free(sums); free(ichr); free(qs); free(qe); free(grp);
@@ -345,28 +393,42 @@ void seqOverlaps(char *qFile, double *sm)
 
 /* ------------------------------- full enumeration (-f) -------------------------------- */
 typedef struct { char *buf; size_t n, cap; } obuf;
-static void ob_int(obuf *o, int32_t x)
-{
-    char t[12];
-    int k = 0;
-    uint32_t u = x < 0 ? 0u - (uint32_t)x : (uint32_t)x;
-    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
-    if (x < 0) o->buf[o->n++] = '-';
-    while (k) o->buf[o->n++] = t[--k];
-}
 static void ob_str(obuf *o, const char *s, size_t L) { memcpy(o->buf + o->n, s, L); o->n += L; }
 
 /* Prints what get_overlaps_f1/_f0 print for each query of the batch, in order
- * ("Query %s, %i, %i: \n" at :548, one "%i\t %i\t %i\t %s\n" per overlap at :577,:610).  The text
- * (35 bytes per overlap: > 1 GB for 10^6 queries) is formatted by several threads, each into its own
- * buffer for a contiguous range of queries, and written out in order. */
+ * ("Query %s, %i, %i: \n" at :548, one "%i\t %i\t %i\t %s\n" per overlap at :577,:610).  The engine
+ * streams the overlaps in chunks of contiguous query ranges (igd_hip_enumerate_stream); the text of a
+ * chunk (35 bytes per overlap: > 1 GB for 10^6 queries) is formatted by several threads, each into its
+ * own buffer for a contiguous range of queries, and written out in order -- while the next chunk is
+ * being filled on the GPU and copied over PCIe. */
 typedef struct {
     const igdc_queries *q; char **names; const iGD_t *G; const size_t *flen;
     int64_t q0;                       /* first query of the engine call this block belongs to   */
-    const int64_t *qoff; const igd_hip_hit *hit;
+    const int64_t *qoff; const igd_hip_hit *hit;   /* hit[h - hbase] = overlap h of the call    */
+    int64_t hbase;
     int64_t i0, i1;                   /* queries [i0, i1) of that call                           */
     obuf o;
 } fmt_job;
+
+static const char DIGIT2[201] =
+    "00010203040506070809101112131415161718192021222324252627282930313233343536373839"
+    "40414243444546474849505152535455565758596061626364656667686970717273747576777879"
+    "8081828384858687888990919293949596979899";
+static inline void ob_uint(obuf *o, uint32_t u)
+{
+    char t[12];
+    int k = 12;
+    while (u >= 100) { const uint32_t r = u % 100; u /= 100; k -= 2; memcpy(t + k, DIGIT2 + 2 * r, 2); }
+    if (u >= 10) { k -= 2; memcpy(t + k, DIGIT2 + 2 * u, 2); }
+    else t[--k] = (char)('0' + u);
+    memcpy(o->buf + o->n, t + k, (size_t)(12 - k));
+    o->n += (size_t)(12 - k);
+}
+static inline void ob_int(obuf *o, int32_t x)
+{
+    if (x < 0) { o->buf[o->n++] = '-'; ob_uint(o, 0u - (uint32_t)x); }
+    else ob_uint(o, (uint32_t)x);
+}
 
 static void *fmt_run(void *arg)
 {
@@ -382,72 +444,90 @@ static void *fmt_run(void *arg)
         ob_str(o, nm, strlen(nm));
         ob_str(o, ", ", 2); ob_int(o, qs); ob_str(o, ", ", 2); ob_int(o, qe);
         ob_str(o, ": \n", 3);
-        int32_t k = 0;
-        for (int64_t h = J->qoff[i]; h < J->qoff[i + 1]; h++, k++) {
-            const int32_t f = J->hit[h].idx;
-            ob_int(o, k); ob_str(o, "\t ", 2); ob_int(o, J->hit[h].start); ob_str(o, "\t ", 2);
-            ob_int(o, J->hit[h].end); ob_str(o, "\t ", 2); ob_str(o, G->finfo[f].fileName, J->flen[f]); o->buf[o->n++] = '\n';
+        uint32_t k = 0;
+        const igd_hip_hit *h = J->hit + (J->qoff[i] - J->hbase), *he = J->hit + (J->qoff[i + 1] - J->hbase);
+        for (; h < he; h++, k++) {
+            const int32_t f = h->idx;
+            ob_uint(o, k); ob_str(o, "\t ", 2); ob_int(o, h->start); ob_str(o, "\t ", 2);
+            ob_int(o, h->end); ob_str(o, "\t ", 2); ob_str(o, G->finfo[f].fileName, J->flen[f]); o->buf[o->n++] = '\n';
         }
     }
     return NULL;
+}
+
+typedef struct {
+    const igdc_queries *q; char **names; const iGD_t *G; const size_t *flen; size_t maxL;
+    int64_t q0; int nt;
+} print_ctx;
+
+/* igd_hip_enum_sink: one chunk = queries [b0,b1) of the call, its overlaps in pinned memory */
+static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, const igd_hip_hit *hit)
+{
+    print_ctx *P = (print_ctx *)ctx;
+    const int nt = P->nt;
+    fmt_job job[64];
+    pthread_t th[64];
+    int started[64];
+    int used = 0;
+    int64_t i0 = b0;
+    for (int t = 0; t < nt && i0 < b1; t++) {                    /* equal shares of the chunk's overlaps (+queries) */
+        int64_t i1 = b1;
+        if (t + 1 < nt) {
+            const int64_t want = qoff[b0] + b0 + (qoff[b1] - qoff[b0] + (b1 - b0)) * (t + 1) / nt;
+            int64_t lo = i0, hi = b1;                            /* largest i1 with qoff[i1] + i1 <= want */
+            while (lo < hi) {
+                const int64_t mid = lo + (hi - lo + 1) / 2;
+                if (qoff[mid] + mid <= want) lo = mid; else hi = mid - 1;
+            }
+            i1 = lo > i0 ? lo : i0 + 1;
+        }
+        fmt_job *J = &job[used];
+        J->q = P->q; J->names = P->names; J->G = P->G; J->flen = P->flen; J->q0 = P->q0; J->qoff = qoff; J->hit = hit;
+        J->hbase = qoff[b0];
+        J->i0 = i0; J->i1 = i1;
+        J->o.n = 0;
+        J->o.cap = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + P->maxL) + 64;
+        J->o.buf = (char *)malloc(J->o.cap);
+        if (!J->o.buf) { for (int k = 0; k < used; k++) { if (started[k]) pthread_join(th[k], NULL); free(job[k].o.buf); } return 1; }
+        /* a thread that cannot be started is simply run here */
+        started[used] = used > 0 && pthread_create(&th[used], NULL, fmt_run, J) == 0;
+        if (used > 0 && !started[used]) fmt_run(J);
+        used++;
+        i0 = i1;
+    }
+    if (used > 0) fmt_run(&job[0]);
+    for (int t = 0; t < used; t++) {
+        if (started[t]) pthread_join(th[t], NULL);
+        if (job[t].o.n) fwrite(job[t].o.buf, 1, job[t].o.n, stdout);
+        free(job[t].o.buf);
+    }
+    return 0;
 }
 
 static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 {
     if (q->n == 0) return 0;
     igd_hip_db *dev = engine();
+    if (!dev) return 0;
     iGD_t *G = cur_igd();
     int64_t *qoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->n + 1));
-    igd_hip_hit *hit = NULL;
     int64_t total = 0, grand = 0;
     size_t *flen = (size_t *)malloc(sizeof(size_t) * (size_t)(G->nFiles + 1));
     size_t maxL = 0;
     for (int32_t f = 0; f < G->nFiles; f++) { flen[f] = strlen(G->finfo[f].fileName); if (flen[f] > maxL) maxL = flen[f]; }
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     const char *ev = getenv("IGD_PRINT_THREADS");
-    int nt = ev && atoi(ev) > 0 ? atoi(ev) : (ncpu > 16 ? 16 : (ncpu < 1 ? 1 : (int)ncpu));
+    int nt = ev && atoi(ev) > 0 ? atoi(ev) : (ncpu > 32 ? 32 : (ncpu < 1 ? 1 : (int)ncpu));
     if (nt > 64) nt = 64;
-    const int64_t step = igd_hip_max_batch(), blockHits = (int64_t)4 << 20;
+    const int64_t step = igd_hip_max_batch();
     fflush(stdout);
+    print_ctx P;
+    P.q = q; P.names = names; P.G = G; P.flen = flen; P.maxL = maxL; P.nt = nt;
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
-        int rc = igd_hip_enumerate(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, &hit, &total);
-        if (rc != IGD_HIP_OK) die_no_gpu("enumerate", rc);
-        for (int64_t b0 = 0; b0 < m;) {                          /* blocks of ~4 M overlaps (or 1 M queries) */
-            int64_t b1 = b0 + 1;
-            while (b1 < m && qoff[b1 + 1] - qoff[b0] <= blockHits && b1 - b0 < (1 << 20)) b1++;
-            fmt_job job[64];
-            pthread_t th[64];
-            int used = 0;
-            int64_t i0 = b0;
-            for (int t = 0; t < nt && i0 < b1; t++) {            /* equal shares of the block's overlaps (+queries) */
-                int64_t i1 = b1;
-                if (t + 1 < nt) {
-                    const int64_t want = qoff[b0] + (qoff[b1] - qoff[b0] + (b1 - b0)) * (t + 1) / nt;
-                    i1 = i0;
-                    while (i1 < b1 && qoff[i1 + 1] + (i1 + 1 - b0) <= want) i1++;
-                    if (i1 == i0) i1 = i0 + 1;
-                }
-                fmt_job *J = &job[used];
-                J->q = q; J->names = names; J->G = G; J->flen = flen; J->q0 = q0; J->qoff = qoff; J->hit = hit;
-                J->i0 = i0; J->i1 = i1;
-                J->o.n = 0;
-                J->o.cap = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + maxL) + 64;
-                J->o.buf = (char *)malloc(J->o.cap);
-                if (used > 0) pthread_create(&th[used], NULL, fmt_run, J);
-                used++;
-                i0 = i1;
-            }
-            fmt_run(&job[0]);
-            for (int t = 0; t < used; t++) {
-                if (t > 0) pthread_join(th[t], NULL);
-                if (job[t].o.n) fwrite(job[t].o.buf, 1, job[t].o.n, stdout);
-                free(job[t].o.buf);
-            }
-            b0 = b1;
-        }
-        igd_hip_free(hit);
-        hit = NULL;
+        P.q0 = q0;
+        int rc = igd_hip_enumerate_stream(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, print_chunk, &P, &total);
+        if (rc != IGD_HIP_OK) { engine_failed("enumerate", rc); break; }
         grand += total;
     }
     free(flen);
@@ -457,7 +537,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 
 static int64_t file_enumerate(const char *qFile)
 {
-    if (!g_core || !cur_igd()) engine();
+    if (!g_core || !cur_igd()) { engine(); return 0; }
     igdc_lines *r = igdc_lines_open(qFile);
     if (!r) return 0;
     igdc_queries q;
@@ -508,11 +588,12 @@ int32_t get_overlaps_f0(char *chrm, int32_t qs, int32_t qe) { return one_enumera
 static int64_t hit_map(uint32_t **hitmap, int use_v, int32_t v)
 {
     igd_hip_db *dev = engine();
+    if (!dev) return 0;
     const int32_t n = cur_igd()->nFiles;
     uint32_t *flat = (uint32_t *)calloc((size_t)n * (size_t)n + 1, sizeof(uint32_t));
     int64_t total = 0;
     int rc = igd_hip_hitmap(dev, use_v, v, flat, &total);
-    if (rc != IGD_HIP_OK) die_no_gpu("hitmap", rc);
+    if (rc != IGD_HIP_OK) { engine_failed("hitmap", rc); free(flat); return 0; }
     for (int32_t a = 0; a < n; a++)
         for (int32_t b = 0; b < n; b++) hitmap[a][b] += flat[(size_t)a * (size_t)n + (size_t)b];
     free(flat);
@@ -538,7 +619,8 @@ static int usage_search(void)
             "    -m                         dataset x dataset hit map, written to -o <name> (default Hitsmap)\n"
             "    -c                         accepted, no effect\n"
             "    -s                         Seqpare similarity of the query file with every dataset\n"
-            "  environment: IGD_DEVICE=<n> selects the GPU (default 0)\n");
+            "  environment: IGD_DEVICE=<n> selects the GPU (default 0); IGD_DEVICES=0,1,.. searches a query file on\n"
+            "               several GPUs (database replicated, contiguous query slabs, per-dataset counts summed)\n");
     return EX_OK;
 }
 
@@ -609,10 +691,10 @@ int igd_search(int argc, char **argv)                                        /* 
     if (full) {                                                               /* :975-995 */
         if (mode == 1) {
             int64_t total = IGD->gType == 0 ? getOverlaps_f0(qfName) : getOverlaps_f1(qfName);
-            printf("Total overlaps: %lld\n", (long long)total);
+            if (!g_fail_rc) printf("Total overlaps: %lld\n", (long long)total);
         } else if (mode == 2) {
             int64_t total = IGD->gType == 0 ? get_overlaps_f0(chrm, qs, qe) : get_overlaps_f1(chrm, qs, qe);
-            printf("Total overlaps: %lld\n", (long long)total);
+            if (!g_fail_rc) printf("Total overlaps: %lld\n", (long long)total);
         } else {
             printf("Not supported -f option\n");
             return EX_OK;
@@ -621,20 +703,20 @@ int igd_search(int argc, char **argv)                                        /* 
         if (IGD->gType == 0) getOverlaps0(qfName, hits);
         else if (v > 0) getOverlaps_v(qfName, hits, v);
         else getOverlaps(qfName, hits);
-        printf("index\t number of regions\t number of hits\t File_name\n");
+        if (!g_fail_rc) printf("index\t number of regions\t number of hits\t File_name\n");
         int64_t total = 0;
-        for (int32_t i = 0; i < nfiles; i++) {
+        for (int32_t i = 0; i < nfiles && !g_fail_rc; i++) {
             if (hits[i] > 0)
                 printf("%i\t%i\t%lld\t%s\n", i, IGD->finfo[i].nr, (long long)hits[i], IGD->finfo[i].fileName);
             total += hits[i];
         }
-        printf("Total: %lld\n", (long long)total);
+        if (!g_fail_rc) printf("Total: %lld\n", (long long)total);
     } else if (mode == 2) {                                                   /* :1041-1053 */
         if (IGD->gType == 0) get_overlaps0(chrm, qs, qe, hits);
         else if (v > 0) get_overlaps_v(chrm, qs, qe, v, hits);
         else get_overlaps(chrm, qs, qe, hits);
-        printf("index\t number of regions\t number of hits\t File_name\n");
-        for (int32_t i = 0; i < nfiles; i++)
+        if (!g_fail_rc) printf("index\t number of regions\t number of hits\t File_name\n");
+        for (int32_t i = 0; i < nfiles && !g_fail_rc; i++)
             printf("%i\t%i\t%lld\t%s\n", i, IGD->finfo[i].nr, (long long)hits[i], IGD->finfo[i].fileName);
     } else if (mode == 0) {                                                   /* :996-1022 */
         if (IGD->gType != 1) {
@@ -644,8 +726,9 @@ int igd_search(int argc, char **argv)                                        /* 
             for (int32_t i = 0; i < nfiles; i++) hitmap[i] = (uint32_t *)calloc((size_t)nfiles + 1, sizeof(uint32_t));
             if (v > 0) getMap_v(hitmap, v); else getMap(hitmap);
             if (strlen(out) < 2) strcpy(out, "Hitsmap");
-            FILE *fo = fopen(out, "w");
-            if (!fo) printf("Can't open file %s\n", out);
+            FILE *fo = g_fail_rc ? NULL : fopen(out, "w");
+            if (g_fail_rc) ;                                /* no matrix of zeros after an engine failure */
+            else if (!fo) printf("Can't open file %s\n", out);
             else {
                 static char obuf[1 << 20];
                 setvbuf(fo, obuf, _IOFBF, sizeof obuf);
@@ -664,8 +747,8 @@ int igd_search(int argc, char **argv)                                        /* 
         else {
             double *sm = (double *)malloc(sizeof(double) * (size_t)(nfiles + 1));
             seqOverlaps(qfName, sm);
-            printf("index\t number of regions\t similarity\t dataset name\n");
-            for (int32_t i = 0; i < nfiles; i++)
+            if (!g_fail_rc) printf("index\t number of regions\t similarity\t dataset name\n");
+            for (int32_t i = 0; i < nfiles && !g_fail_rc; i++)
                 printf("%i\t%i\t%10.6f\t%s\n", i, IGD->finfo[i].nr, sm[i], IGD->finfo[i].fileName);
             free(sm);
         }
@@ -687,7 +770,9 @@ int igd_search(int argc, char **argv)                                        /* 
     free(hits);
     if (g_core) { igdc_close(g_core); g_core = NULL; g_core_of = NULL; hc = NULL; }
     free(g_core_path); g_core_path = NULL;
-    return EX_OK;
+    /* the reference's exit code is always 0; an engine failure (message already on stderr) is the one
+     * thing this tool reports through it, instead of printing a table of zeros */
+    return g_fail_rc ? EX_UNAVAILABLE : EX_OK;
 }
 
 /* ---- create_igd*, src/igd_create.h:10-14 --------------------------------------------------- */
@@ -703,7 +788,7 @@ static void create_with(char *iPath, char *oPath, char *igdName, int mode)
     const int rc = igdc_create(&o);
     if (rc < 0) {
         fprintf(stderr, "igd create: no usable GPU (%d): %s\n", rc, igd_hip_last_error());
-        exit(EX_UNAVAILABLE);
+        if (!g_fail_rc) g_fail_rc = rc;
     }
 }
 void create_igd(char *iPath, char *oPath, char *igdName) { create_with(iPath, oPath, igdName, IGDC_CREATE_GLOB); }

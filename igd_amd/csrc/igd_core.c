@@ -7,6 +7,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <limits.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -159,6 +160,7 @@ int igdc_load_index(igdc_db *db, const char *tsv_path)
 void igdc_close(igdc_db *db)
 {
     if (!db) return;
+    for (int k = 1; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);   /* devs[0] == dev */
     if (db->dev) igd_hip_close(db->dev);
     if (db->cName)
         for (int32_t c = 0; c < db->nCtg; c++) free(db->cName[c]);
@@ -178,8 +180,12 @@ static int attach_records(igdc_db *db, const void *records, int fd, int device)
     d.nbp = db->nbp; d.gType = db->gType; d.nCtg = db->nCtg; d.nFiles = db->nFiles;
     d.nTile = db->nTile; d.nCnt = db->nCntFlat; d.records = records; d.nRecords = db->nRecords;
     d.fd = fd; d.fd_offset = db->dataOff;
+    for (int k = 1; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);
+    db->ndev = 0;
     if (db->dev) { igd_hip_close(db->dev); db->dev = NULL; }
-    return igd_hip_open(&d, device, &db->dev);
+    const int rc = igd_hip_open(&d, device, &db->dev);
+    if (rc == IGD_HIP_OK) { db->devs[0] = db->dev; db->ndev = 1; }
+    return rc;
 }
 
 /* the engine preads the tile region itself, staged through pinned buffers (no mmap faults) */
@@ -208,6 +214,115 @@ int igdc_attach_fp(igdc_db *db, FILE *fp, int device)
     if (keep >= 0) fseek(fp, keep, SEEK_SET);
     int rc = ok ? attach_records(db, buf, -1, device) : IGD_HIP_ERR_ARG;
     free(buf);
+    return rc;
+}
+
+/* ---- multi-GPU in one process ----------------------------------------------------------- */
+void igd_hip_set_error_(const char *msg);      /* libigd_hip.so: sets the calling thread's igd_hip_last_error() text */
+int igdc_devices_from_env(int *devices, int max)
+{
+    const char *e = getenv("IGD_DEVICES");
+    int n = 0;
+    while (e && *e && n < max) {
+        char *end = NULL;
+        long d = strtol(e, &end, 10);
+        if (end == e) break;
+        devices[n++] = (int)d;
+        e = end;
+        while (*e == ',' || *e == ' ') e++;
+    }
+    return n;
+}
+
+typedef struct { igdc_db *db; const char *path; int device; igd_hip_db *out; int rc; char err[256]; } attach_job;
+static void *attach_run(void *arg)
+{
+    attach_job *J = (attach_job *)arg;
+    igdc_db tmp = *J->db;                       /* header tables are shared read-only; only .dev differs */
+    tmp.dev = NULL;
+    J->rc = igdc_attach_path(&tmp, J->path, J->device);
+    J->out = tmp.dev;
+    if (J->rc != IGD_HIP_OK) snprintf(J->err, sizeof J->err, "%s", igd_hip_last_error());   /* thread-local text */
+    return NULL;
+}
+
+int igdc_attach_path_multi(igdc_db *db, const char *igd_path, const int *devices, int n)
+{
+    if (n < 1 || n > IGDC_MAX_DEVICES) return IGD_HIP_ERR_ARG;
+    for (int k = 0; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);
+    db->ndev = 0; db->dev = NULL;
+    attach_job job[IGDC_MAX_DEVICES];
+    pthread_t th[IGDC_MAX_DEVICES];
+    int started[IGDC_MAX_DEVICES];
+    for (int k = 0; k < n; k++) {
+        job[k].db = db; job[k].path = igd_path; job[k].device = devices[k]; job[k].out = NULL; job[k].rc = IGD_HIP_ERR_DEVICE; job[k].err[0] = 0;
+        started[k] = k > 0 && pthread_create(&th[k], NULL, attach_run, &job[k]) == 0;
+        if (k > 0 && !started[k]) attach_run(&job[k]);
+    }
+    attach_run(&job[0]);
+    int rc = IGD_HIP_OK;
+    for (int k = 0; k < n; k++) {
+        if (started[k]) pthread_join(th[k], NULL);
+        if (job[k].rc != IGD_HIP_OK && rc == IGD_HIP_OK) { rc = job[k].rc; igd_hip_set_error_(job[k].err); }
+    }
+    if (rc != IGD_HIP_OK) {
+        for (int k = 0; k < n; k++) if (job[k].out) igd_hip_close(job[k].out);
+        return rc;
+    }
+    for (int k = 0; k < n; k++) db->devs[k] = job[k].out;
+    db->ndev = n;
+    db->dev = db->devs[0];
+    return IGD_HIP_OK;
+}
+
+typedef struct {
+    igd_hip_db *dev; const int32_t *ichr, *qs, *qe; int64_t n; int32_t v; int rule, flags;
+    int64_t *hits, total; int rc; char err[256];
+} slab_job;
+static void *slab_run(void *arg)
+{
+    slab_job *J = (slab_job *)arg;
+    J->rc = igd_hip_search_ex(J->dev, J->ichr, J->qs, J->qe, J->n, J->v, J->rule, J->flags, J->hits, &J->total);
+    if (J->rc != IGD_HIP_OK) snprintf(J->err, sizeof J->err, "%s", igd_hip_last_error());
+    return NULL;
+}
+
+int igdc_search_multi(igdc_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                      int32_t v, int rule, int flags, int64_t *hits, int64_t *total)
+{
+    const int n = db->ndev;
+    if (n < 1) return IGD_HIP_ERR_ARG;
+    if (n == 1 || nq < n) return igd_hip_search_ex(db->devs[0], ichr, qs, qe, nq, v, rule, flags, hits, total);
+    slab_job job[IGDC_MAX_DEVICES];
+    pthread_t th[IGDC_MAX_DEVICES];
+    int started[IGDC_MAX_DEVICES];
+    const int32_t nf = db->nFiles;
+    int64_t *part = (int64_t *)calloc((size_t)n * (size_t)(nf + 1), sizeof(int64_t));
+    if (!part) return IGD_HIP_ERR_NOMEM;
+    const int64_t base = nq / n, rem = nq % n;              /* the slab rule of igd_amd/dist.py shard_bounds */
+    for (int r = 0; r < n; r++) {
+        const int64_t lo = r * base + (r < rem ? r : rem), m = base + (r < rem ? 1 : 0);
+        slab_job *J = &job[r];
+        J->dev = db->devs[r]; J->ichr = ichr + lo; J->qs = qs + lo; J->qe = qe + lo; J->n = m;
+        J->v = v; J->rule = rule; J->flags = flags; J->hits = part + (size_t)r * (size_t)(nf + 1); J->total = 0;
+        J->rc = IGD_HIP_OK; J->err[0] = 0;
+        started[r] = r > 0 && pthread_create(&th[r], NULL, slab_run, J) == 0;
+        if (r > 0 && !started[r]) slab_run(J);
+    }
+    slab_run(&job[0]);
+    int rc = IGD_HIP_OK;
+    int64_t tot = 0;
+    for (int r = 0; r < n; r++) {
+        if (started[r]) pthread_join(th[r], NULL);
+        if (job[r].rc != IGD_HIP_OK && rc == IGD_HIP_OK) { rc = job[r].rc; igd_hip_set_error_(job[r].err); }
+        tot += job[r].total;
+    }
+    if (rc == IGD_HIP_OK) {                                  /* the one exchange of the path: sum of the n vectors */
+        for (int r = 0; r < n; r++)
+            for (int32_t f = 0; f < nf; f++) hits[f] += part[(size_t)r * (size_t)(nf + 1) + (size_t)f];
+        if (total) *total = tot;
+    }
+    free(part);
     return rc;
 }
 

@@ -23,6 +23,7 @@
 extern "C" {
 #endif
 
+#define IGDC_MAX_DEVICES 16
 typedef struct igdc_db {
     int32_t nbp, gType, nCtg, nFiles;
     int32_t *nTile;          /* [nCtg]                                                  */
@@ -38,6 +39,9 @@ typedef struct igdc_db {
     int32_t *dict;           /* open-addressing contig dictionary                        */
     int32_t  dictCap;
     igd_hip_db *dev;         /* the database resident on the GPU (NULL until attached)   */
+    /* multi-GPU: the same database resident on further devices; dev == devs[0] */
+    int32_t     ndev;
+    igd_hip_db *devs[IGDC_MAX_DEVICES];
 } igdc_db;
 
 /* header tables of an .igd (no tile data is read) */
@@ -52,6 +56,19 @@ int32_t  igdc_get_id(const igdc_db *db, const char *chrm);
  * already open stream (the CLI flavour's global fP).  Returns IGD_HIP_OK or an IGD_HIP_ERR_*. */
 int igdc_attach_path(igdc_db *db, const char *igd_path, int device);
 int igdc_attach_fp(igdc_db *db, FILE *fp, int device);
+/* Multi-GPU, one process driving several devices: the database is replicated on
+ * devices[0..n) (uploaded by n host threads at once; the same device may be listed twice), and
+ * igdc_search_multi gives device r the r-th CONTIGUOUS slab of the batch (one host thread per
+ * device), then adds the n per-device vectors of nFiles counts into hits[] -- the reference keeps one
+ * hits[] for all queries and prints it once (src/igd_search.c:925,1032-1039); a sum of non-negative
+ * integers, so any partition of the queries gives the identical vector.  In this single process the
+ * "all-reduce" of the multi-process path (igd_amd/dist.py, RCCL) is that host-side add of n x 8*nFiles
+ * bytes.  "IGD_DEVICES=0,1,.." selects the devices for the command line tool. */
+int igdc_attach_path_multi(igdc_db *db, const char *igd_path, const int *devices, int n);
+int igdc_search_multi(igdc_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                      int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
+/* "0,1,2" -> devices[]; returns the count (0 when the variable is unset or empty) */
+int igdc_devices_from_env(int *devices, int max);
 
 /* BED line -> (contig, start, end).  Mutates `line`.  require_chr=1 is the CLI rule
  * (name starts with "chr", shorter than 40, end > 0: src/igd_base.c:69); require_chr=0 is

@@ -18,8 +18,7 @@
 //         before it straight from the caller's arrays (a merge join: both sides stream);
 //      b. any other order: every (query, visited tile) pair is grouped by tile id without global
 //         atomics (k_split_local -> k_split_totals -> k_split_fine: LDS counting in two levels);
-//         these kernels return at once when (a) holds.  (`-f` keeps the atomic counting sort
-//         k_count_pairs -> 2-kernel scan -> k_scatter_pairs, which also carries the query id.)
+//         these kernels return at once when (a) holds.
 //      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
 //   2. scan:   igd_scan_tiles -- one wavefront owns one <=320-record chunk ("unit") of one tile
 //      at a time.  It loads the unit's records once, coalesced, into 5 register slots (record
@@ -37,7 +36,7 @@
 //      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].  The same
 //      launch walks, on the exact arrays, the few queries the scan leaves out (more than
 //      IGD_SHORT_TILES tiles long, or needing exact starts: see k_pack_units).
-//   `-f` (igd_enum_tiles) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays;
+//   `-f` (igd_enum_queries: query-major, streamed out in chunks) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays;
 //   Seqpare `-s` (igd_hip_seqpare) = the `-f` kernel emitting similarities + radix sorts into the
 //   greedy order (igd_sortscan.hpp) + a wave-per-group matching kernel (k_seq_greedy).
 // No MFMA anywhere: this is integer compare + count, bound by HBM / VALU issue, not by math.
@@ -178,7 +177,7 @@ struct igd_hip_db {
     char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
     size_t arenaSize, arenaUsed;
     int32_t epoch;                // batch counter: device-side flags are compared against it
-    int32_t promised;             // epoch of the last batch launched under IGD_HIP_FLAG_SORTED (0: none)
+    int32_t promised;             // != 0: a batch was launched under IGD_HIP_FLAG_SORTED since the last igd_hip_sync
     // per-batch workspace
     int32_t *d_pairCnt, *d_pairPos, *d_blockSums;
     void *d_pairs;                // int2[cap*K] (or int4 for the enumerate path)
@@ -190,6 +189,13 @@ struct igd_hip_db {
     u64 *d_slab;
     int grid, ldsBytes;
     bool ldsHits;
+    // `-f` streaming workspace (created by the first enumeration, kept)
+    int64_t *d_qcount, *d_qoff, *d_enumBsum;
+    int64_t enumQCap, enumChunkCap;          // capacity in queries / overlaps per chunk buffer
+    igd_hip_hit *d_enumOut[2], *h_enumPin[2];
+    bool enumPinned;
+    hipStream_t copyStream;
+    hipEvent_t evFill[2], evCopy[2];
     // host-API staging
     int32_t *d_qc, *d_qs, *d_qe;
     int64_t qcap;
@@ -268,7 +274,8 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 
 // Control words shared by the kernels of one batch (int32 ctl[16]):
 //   ctl[1] = epoch of the last batch whose queries were NOT ordered by tile
-//   ctl[2] = epoch of the last batch that broke a caller's IGD_HIP_FLAG_SORTED promise
+//   ctl[2] = epoch of a batch that broke a caller's IGD_HIP_FLAG_SORTED promise since the last igd_hip_sync
+//            (written by k_query_bounds, cleared by igd_hip_sync: no broken batch goes unreported)
 //   ctl[4 + (epoch & 1)] = entries of the bucket path's exact-walk list (k_count_pairs)
 //   ctl[6 + (epoch & 1)] = entries of the merge-join path's exact-walk list (k_query_bounds)
 //   ctl[8 + (epoch & 1)] = gap-fill budget spent by k_query_bounds (units of 256 tiles)
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       int packed, int32_t *__restrict__ firstQ,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
-                                                      int32_t *__restrict__ qw)
+                                                      int32_t *__restrict__ qw, int promised)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST
@@ -323,7 +330,10 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
         const int c = ichr[i], s0 = qs[i];
         const int k = tile_key(db, c, s0);
         const int prev = i ? tile_key(db, ichr[i - 1], qs[i - 1]) : -1;
-        if (k < prev) ctl[CTL_UNSORTED] = epoch;
+        if (k < prev) {
+            ctl[CTL_UNSORTED] = epoch;
+            if (promised) ctl[CTL_BROKEN] = epoch;          // sticky until the next igd_hip_sync (any promised batch since)
+        }
         lo = prev + 1; hi = k;
         // The scan kernel's view of the query: (global number of its first tile) << 4 | min(n2 - n1, 15),
         // -1 when it visits nothing (unknown contig, tile out of range) -- so that the scan does not
@@ -367,7 +377,10 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
             if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
             spent = __builtin_amdgcn_readfirstlane(spent);
             if (spent > (db.nT >> 8) + 16) {
-                if (lane == 0) ctl[CTL_UNSORTED] = epoch;
+                if (lane == 0) {
+                    ctl[CTL_UNSORTED] = epoch;
+                    if (promised) ctl[CTL_BROKEN] = epoch;
+                }
                 continue;
             }
         }
@@ -685,9 +698,8 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan_apply(int32_t *__restri
     }
 }
 
-// step 3: scatter (qs,qe[,q]) of every pair to its tile's slot range.  After this kernel
-// pairPos[t] is the END of tile t's range.  WITH_Q: the enumerate path also needs the query id.
-template <bool WITH_Q>
+// step 3: scatter (qs,qe) of every pair to its tile's slot range.  After this kernel
+// pairPos[t] is the END of tile t's range.
 __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
                                 const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                 int nq, int rule, int packed, int32_t *__restrict__ pairPos,
@@ -703,8 +715,7 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
     for (int k = 0; k < ntl; k++) {
         if (db.tileCnt[gt0 + k] > 0) {
             int p = atomicAdd(&pairPos[gt0 + k], 1);
-            if (WITH_Q) ((int4 *)pairs)[p] = make_int4(s, e, i, k);
-            else ((int2 *)pairs)[p] = make_int2(s, e);
+            ((int2 *)pairs)[p] = make_int2(s, e);
         }
     }
 }
@@ -1296,13 +1307,12 @@ __global__ __launch_bounds__(256) void k_sum_hits(const u64 *__restrict__ hits, 
 }
 
 // ------------------------------------------------------------------------------------------
-// `-f` enumeration.  Same bucketing (pairs carry the query id q and k = tile - n1); the tile
-// is the unit (a wave walks its chunks from the LAST to the first so that record indices come
-// out descending, as the reverse scans at src/igd_search.c:575-579 and :608-612 emit them).
-//   pass COUNT: pcount[q*K + k] = hits of pair (q, tile n1+k)
-//   host/scan : qoff = exclusive scan over q of sum_k pcount
-//   pass FILL : record i of pair (q,k) goes to out[qoff[q] + sum_{k'<k} pcount[q*K+k'] + rank]
-// Long queries: one wave per query, tiles ascending, same two passes with a running offset.
+// `-f` enumeration (get_overlaps_f1/_f0, src/igd_search.c:537-620,114-200).  A wave walks the tiles
+// of its query in ascending order and each tile from its LAST 64 records to the first, so that
+// record indices come out descending, as the reverse scans at :575-579 and :608-612 emit them.
+//   pass COUNT: qcount[q] = overlaps of query q
+//   scan      : qoff = exclusive scan of qcount
+//   pass FILL : the rank-th overlap of query q goes to out[qoff[q] + rank]
 // SEQ (Seqpare, src/igd_search.c:253-352): the record's place is taken by what seq_overlaps stores for it:
 // start <- idx_g (index of the record inside its tile), end <- the bits of the float similarity
 // sm = st / (qlen + rlen - st), computed in single precision in the reference's order of operations.
@@ -1314,111 +1324,63 @@ __device__ __forceinline__ int seq_similarity_bits(int qs, int qe, int s, int e)
     return __float_as_int(__fdiv_rn(st, __fsub_rn(__fadd_rn(qlen, rlen), st)));
 }
 
+// Query-major: one wave per query, so that a contiguous range of queries is a contiguous range of the
+// output -- which is what lets the host side stream the result out in chunks while later chunks are
+// still being produced (the path is bound by the 16 bytes per overlap that cross PCIe, not by these
+// kernels).  No grouping step at all: with queries in any order a tile's records are simply re-read from
+// L2 / HBM (2.2 KB per (query, tile) pair; < 1 ms per 10^6 queries either way).
+//   COUNT (FILL = false): qcount[q] = overlaps of query q            (all its tiles)
+//   FILL                : out[qoff[q] - base0 + rank] = the overlaps of queries [qa, qb), reference order
 template <bool FILL, bool SEQ = false>
-__global__ __launch_bounds__(IGD_WG) void igd_enum_tiles(
-    DbView db, const int32_t *__restrict__ pairCnt, const int32_t *__restrict__ pairPos,
-    const int4 *__restrict__ pairs, const int2 *__restrict__ longList,
-    const int32_t *__restrict__ ctl, int epoch, const int32_t *__restrict__ q_ichr,
-    const int32_t *__restrict__ q_qs, const int32_t *__restrict__ q_qe,
-    int32_t *__restrict__ pcount /* [nq*K] */, int64_t *__restrict__ qlong /* [nq] long totals */,
-    const int64_t *__restrict__ qoff, igd_hip_hit *__restrict__ out)
+__global__ __launch_bounds__(256) void igd_enum_queries(
+    DbView db, const int32_t *__restrict__ q_ichr, const int32_t *__restrict__ q_qs,
+    const int32_t *__restrict__ q_qe, int qa, int qb, int64_t *__restrict__ qcount,
+    const int64_t *__restrict__ qoff, int64_t base0, igd_hip_hit *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int wavesPerWG = IGD_WG / IGD_WAVE;
-    const int gwave = blockIdx.x * wavesPerWG + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * wavesPerWG;
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
     const u64 above = (lane == 63) ? 0ull : (~0ull << (lane + 1));   // lanes with a higher record index
 
-    for (int t = gwave; t < db.nT; t += nwaves) {
-        const int np = __builtin_amdgcn_readfirstlane(pairCnt[t]);
-        if (np == 0) continue;
-        const int pend = __builtin_amdgcn_readfirstlane(pairPos[t]);
-        const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
-        const int bd = __builtin_amdgcn_readfirstlane(db.tileBd[t]);
-        const int64_t toff = db.tileOff[t];
-        for (int p = pend - np; p < pend; p++) {
-            const int4 pr = pairs[p];                     // wave-uniform address
-            const int qs = pr.x, qe = pr.y, q = pr.z, k = pr.w;
-            const int lob = (qs >= bd) ? INT_MIN : bd;
-            int64_t base = 0;
-            if (FILL) {
-                base = qoff[q];
-                for (int kk = 0; kk < k; kk++) base += pcount[(size_t)q * IGD_SHORT_TILES + kk];
-            }
-            int cnt = 0;
-            // records from the end of the tile towards the front, 64 at a time
-            for (int hi = tcnt; hi > 0; hi -= IGD_WAVE) {
-                const int i = hi - IGD_WAVE + lane;       // lane 63 = highest index of this step
-                const bool ok = i >= 0;
-                const int s = ok ? db.start[toff + i] : INT_MAX;
-                const int e = ok ? db.end[toff + i] : INT_MIN;
-                const bool hit = (s < qe) & (s >= lob) & (e > qs);
-                const u64 m = __ballot(hit);
-                if (FILL && hit) {
-                    igd_hip_hit h;
-                    h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
-                    if (SEQ) { h.start = i; h.end = seq_similarity_bits(qs, qe, s, e); }
-                    out[base + cnt + __popcll(m & above)] = h;
-                }
-                cnt += __popcll(m);
-                // all starts in this step are below lob => so is everything before it
-                const int smax = __builtin_amdgcn_readlane(s, 63);
-                if (smax < lob) break;
-            }
-            if (!FILL && lane == 0) pcount[(size_t)q * IGD_SHORT_TILES + k] = cnt;
-        }
-    }
-
-    const int nLong = __builtin_amdgcn_readfirstlane(ctl[CTL_NLONG + (epoch & 1)]);
-    for (int li = gwave; li < nLong; li += nwaves) {
-        const int q = __builtin_amdgcn_readfirstlane(longList[li].x);
+    for (int q = qa + gwave; q < qb; q += nwaves) {
         const int qs = __builtin_amdgcn_readfirstlane(q_qs[q]);
         const int qe = __builtin_amdgcn_readfirstlane(q_qe[q]);
         const int cc = __builtin_amdgcn_readfirstlane(q_ichr[q]);
-        const int n1 = tile_of(db, qs);
-        int n2 = tile_of(db, (int)((unsigned)qe - 1u));
-        const int mT = db.ctgNTile[cc] - 1;
-        if (n2 > mT) n2 = mT;
-        const int tb = db.ctgBase[cc];
         int64_t cnt = 0;
-        const int64_t base = FILL ? qoff[q] : 0;
-        for (int j = n1; j <= n2; j++) {
-            const int t = tb + j;
-            const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
-            if (tcnt == 0) continue;
-            const int lob = (j == n1) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
-            const int64_t toff = db.tileOff[t];
-            for (int hi = tcnt; hi > 0; hi -= IGD_WAVE) {
-                const int i = hi - IGD_WAVE + lane;
-                const bool ok = i >= 0;
-                const int s = ok ? db.start[toff + i] : INT_MAX;
-                const int e = ok ? db.end[toff + i] : INT_MIN;
-                const bool hit = (s < qe) & (s >= lob) & (e > qs);
-                const u64 m = __ballot(hit);
-                if (FILL && hit) {
-                    igd_hip_hit h;
-                    h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
-                    if (SEQ) { h.start = i; h.end = seq_similarity_bits(qs, qe, s, e); }
-                    out[base + cnt + __popcll(m & above)] = h;
+        int gt0, ntl;
+        if (query_span(db, cc, qs, qe, IGD_HIP_RULE_NEST, gt0, ntl)) {
+            gt0 = __builtin_amdgcn_readfirstlane(gt0);
+            ntl = __builtin_amdgcn_readfirstlane(ntl);
+            const int64_t base = FILL ? qoff[q] - base0 : 0;
+            for (int k = 0; k < ntl; k++) {
+                const int t = gt0 + k;
+                const int tcnt = __builtin_amdgcn_readfirstlane(db.tileCnt[t]);
+                if (tcnt == 0) continue;
+                const int lob = (k == 0) ? INT_MIN : __builtin_amdgcn_readfirstlane(db.tileBd[t]);
+                const int64_t toff = db.tileOff[t];
+                // records from the end of the tile towards the front, 64 at a time
+                for (int hi = tcnt; hi > 0; hi -= IGD_WAVE) {
+                    const int i = hi - IGD_WAVE + lane;           // lane 63 = highest index of this step
+                    const bool ok = i >= 0;
+                    const int s = ok ? db.start[toff + i] : INT_MAX;
+                    const int e = ok ? db.end[toff + i] : INT_MIN;
+                    const bool hit = (s < qe) & (s >= lob) & (e > qs);
+                    const u64 m = __ballot(hit);
+                    if (FILL && hit) {
+                        igd_hip_hit h;
+                        h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
+                        if (SEQ) { h.start = i; h.end = seq_similarity_bits(qs, qe, s, e); }
+                        out[base + cnt + __popcll(m & above)] = h;
+                    }
+                    cnt += __popcll(m);
+                    // all starts in this step are below lob => so is everything before it
+                    const int smax = __builtin_amdgcn_readlane(s, 63);
+                    if (smax < lob) break;
                 }
-                cnt += __popcll(m);
-                const int smax = __builtin_amdgcn_readlane(s, 63);
-                if (smax < lob) break;
             }
         }
-        if (!FILL && lane == 0) qlong[q] = cnt;
+        if (!FILL && lane == 0) qcount[q] = cnt;
     }
-}
-
-// per-query totals -> qcount (int64) ; the scan to qoff is done by k_scan64 below
-__global__ void k_enum_qcount(const int32_t *__restrict__ pcount, const int64_t *__restrict__ qlong,
-                              int nq, int64_t *__restrict__ qcount)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nq) return;
-    int64_t s = qlong[i];
-    for (int k = 0; k < IGD_SHORT_TILES; k++) s += pcount[(size_t)i * IGD_SHORT_TILES + k];
-    qcount[i] = s;
 }
 
 // exclusive scan of int64 per-query counts -> qoff[0..n] (two kernels, like the tile scan)
@@ -1643,6 +1605,16 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
+    {
+        void *es[] = {db->d_qcount, db->d_qoff, db->d_enumBsum, db->d_enumOut[0], db->d_enumOut[1]};
+        for (void *p : es) if (p) (void)hipFree(p);
+        for (int k = 0; k < 2; k++) {
+            if (db->h_enumPin[k]) (void)hipHostFree(db->h_enumPin[k]);
+            if (db->evFill[k]) (void)hipEventDestroy(db->evFill[k]);
+            if (db->evCopy[k]) (void)hipEventDestroy(db->evCopy[k]);
+        }
+        if (db->copyStream) (void)hipStreamDestroy(db->copyStream);
+    }
     for (hipEvent_t e : db->ev) (void)hipEventDestroy(e);
     if (db->stream) (void)hipStreamDestroy(db->stream);
     delete db;
@@ -1722,8 +1694,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     for (int c = 0; c < d->nCtg; c++) nT += d->nTile[c];
     bool jfits = true;
     for (int c = 0; c < d->nCtg; c++) jfits = jfits && d->nTile[c] < (1 << 27);
-    if (nT > INT_MAX - 1 || !jfits) {
-        snprintf(g_err, sizeof g_err, "igd_hip_open: too many tiles");
+    // the merge join packs (global tile number << 4 | span) into one int32 per query (k_query_bounds):
+    // the TOTAL number of tiles has to stay below 2^27, not just every contig's
+    if (nT >= (1 << 27) || !jfits) {
+        snprintf(g_err, sizeof g_err, "igd_hip_open: too many tiles (%lld; the engine's limit is 2^27-1)", (long long)nT);
         delete db;
         return IGD_HIP_ERR_ARG;
     }
@@ -2028,7 +2002,6 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
 // The bucket step (count -> scan -> scatter).  gate != 0: every kernel returns at once unless
 // k_query_bounds marked this batch unsorted (ctl[CTL_UNSORTED] == gate).  Leaves the pair
 // counts in d_pairN, the range ends in d_pairPos, and d_pairCnt zeroed again.
-template <bool WITH_Q>
 static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
                          int nq, int rule, int gate, int packed, hipStream_t st, u64 *zeroHits = nullptr,
                          u64 *zeroTotal = nullptr)
@@ -2042,7 +2015,7 @@ static int launch_bucket(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d
     k_scan_block_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_ctl, gate);
     k_scan_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_pairCnt, nT, db->d_blockSums, db->d_pairPos, db->d_pairN,
                                                 db->d_ctl, gate);
-    k_scatter_pairs<WITH_Q><<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairPos, db->d_pairs,
+    k_scatter_pairs<<<qb, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->d_pairPos, db->d_pairs,
                                                 db->d_ctl, gate);
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
@@ -2115,14 +2088,14 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const int gridQ = (int)(((nq > db->nFiles ? nq : db->nFiles) + 255) / 256);
     if (mode != 2)
         k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw);
+                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, mode == 1 ? 1 : 0);
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
         if (db->spShift >= 0 && !oldBucket)
             rc = launch_split(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                               mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         else
-            rc = launch_bucket<false>(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+            rc = launch_bucket(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                                       mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         if (rc != IGD_HIP_OK) return rc;
     }
@@ -2174,13 +2147,16 @@ extern "C" int igd_hip_sync(igd_hip_db *db, void *stream)
     HIPCHK(hipGetLastError());
     if (db->promised) {
         // a batch ran under IGD_HIP_FLAG_SORTED: the device recorded whether the promise held
+        // -- stickily: ANY promised batch since the last sync that was found unordered is reported
         int32_t ctl[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpy(ctl, db->d_ctl, sizeof ctl, hipMemcpyDeviceToHost));
-        const bool broken = ctl[CTL_UNSORTED] == db->promised;
+        const bool broken = ctl[CTL_BROKEN] != 0;
         db->promised = 0;
         if (broken) {
+            const int32_t zero = 0;
+            HIPCHK(hipMemcpy(db->d_ctl + CTL_BROKEN, &zero, 4, hipMemcpyHostToDevice));
             snprintf(g_err, sizeof g_err, "igd_hip: queries passed with IGD_HIP_FLAG_SORTED were not ordered by "
-                     "(contig, start); that batch added nothing to hits");
+                     "(contig, start); such a batch added nothing to hits");
             return IGD_HIP_ERR_UNSORTED;
         }
     }
@@ -2257,6 +2233,168 @@ extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int3
     return IGD_HIP_OK;
 }
 
+// `-f` on the host side.  The path is bound by the 16 bytes per overlap that cross PCIe (and, in the
+// command line tool, by turning them into text), so the result is produced in CHUNKS of contiguous
+// query ranges and streamed: while chunk k's device->host copy runs on the copy stream into one of
+// two pinned buffers, chunk k+1 is being filled on the compute stream and the caller's sink is
+// formatting chunk k-1.  Every buffer is part of a persistent workspace (no allocation per call).
+//   COUNT pass over the whole batch -> qcount -> scan -> qoff (device + host)
+//   chunks: the longest query range whose overlaps fit one buffer
+//   per chunk: FILL [qa,qb) -> d_enumOut[k&1] -> async D2H -> pinned h_enumPin[k&1] (or the final array) -> sink
+static int ensure_enum_workspace(igd_hip_db *db, int64_t nq, int64_t chunkHits, bool needPinned)
+{
+    int rc;
+    if (nq > db->enumQCap) {
+        HIPCHK(hipDeviceSynchronize());
+        void *ps[] = {db->d_qcount, db->d_qoff, db->d_enumBsum};
+        for (void *q : ps) if (q) (void)hipFree(q);
+        db->d_qcount = db->d_qoff = db->d_enumBsum = nullptr;
+        db->enumQCap = 0;
+        if ((rc = dalloc(&db->d_qcount, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_qoff, (size_t)nq + 1, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_enumBsum, (size_t)(nq / IGD_SCAN_TILE + 2), nullptr)) != IGD_HIP_OK) return rc;
+        db->enumQCap = nq;
+    }
+    if (!db->copyStream) {
+        HIPCHK(hipStreamCreateWithFlags(&db->copyStream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIPCHK(hipEventCreateWithFlags(&db->evFill[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&db->evCopy[k], hipEventDisableTiming));
+        }
+    }
+    if (chunkHits > db->enumChunkCap) {
+        HIPCHK(hipDeviceSynchronize());
+        for (int k = 0; k < 2; k++) {
+            if (db->d_enumOut[k]) (void)hipFree(db->d_enumOut[k]);
+            if (db->h_enumPin[k]) (void)hipHostFree(db->h_enumPin[k]);
+            db->d_enumOut[k] = nullptr; db->h_enumPin[k] = nullptr;
+        }
+        db->enumChunkCap = 0; db->enumPinned = false;
+        for (int k = 0; k < 2; k++)
+            if ((rc = dalloc(&db->d_enumOut[k], (size_t)chunkHits, nullptr)) != IGD_HIP_OK) return rc;
+        db->enumChunkCap = chunkHits;
+    }
+    if (needPinned && !db->enumPinned) {
+        for (int k = 0; k < 2; k++)
+            if (hipHostMalloc((void **)&db->h_enumPin[k], (size_t)db->enumChunkCap * sizeof(igd_hip_hit), hipHostMallocDefault) != hipSuccess) {
+                snprintf(g_err, sizeof g_err, "igd_hip_enumerate: pinned host allocation failed");
+                return IGD_HIP_ERR_NOMEM;
+            }
+        db->enumPinned = true;
+    }
+    return IGD_HIP_OK;
+}
+
+#define IGD_ENUM_CHUNK_HITS ((int64_t)4 << 20)     // 64 MiB of igd_hip_hit per chunk buffer
+
+// whole != nullptr: the chunks are copied straight to their place in `whole` (pinned, qoff[nq] records);
+// otherwise every chunk is handed to `sink` from one of the two pinned chunk buffers.
+static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                          int64_t *qoff, bool wantWhole, igd_hip_hit **wholeOut, igd_hip_enum_sink sink, void *ctx, int64_t *total)
+{
+    const char *tenv = getenv("IGD_TIMING");
+    const bool tim = tenv && *tenv && *tenv != '0';
+    double t0 = wall_s();
+#define ENUM_PHASE(name) do { if (tim) { double t_ = wall_s(); fprintf(stderr, "[igd timing]   enumerate: %-24s %8.2f ms\n", name, 1e3 * (t_ - t0)); t0 = t_; } } while (0)
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = db->stream;
+    int rc = ensure_qstage(db, nq);
+    if (rc != IGD_HIP_OK) return rc;
+    int64_t chunkHits = IGD_ENUM_CHUNK_HITS;
+    if (const char *ce = getenv("IGD_ENUM_CHUNK_HITS")) { if (atoll(ce) > 0) chunkHits = atoll(ce); }   // tests: many small chunks
+    rc = ensure_enum_workspace(db, nq, db->enumChunkCap > chunkHits ? db->enumChunkCap : chunkHits, !wantWhole);
+    if (rc != IGD_HIP_OK) return rc;
+    ENUM_PHASE("workspace");
+    HIPCHK(hipMemcpyAsync(db->d_qc, ichr, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(db->d_qs, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    const int egrid = db->grid * 4;                        // 256-thread workgroups: 8 per CU
+    igd_enum_queries<false><<<egrid, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, 0, (int)nq, db->d_qcount, nullptr, 0, nullptr);
+    {
+        const int sb = (int)((nq + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE);
+        k_scan64_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_qcount, (int)nq, db->d_enumBsum);
+        k_scan64_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(db->d_qcount, (int)nq, db->d_enumBsum, db->d_qoff);
+    }
+    HIPCHK(hipMemcpyAsync(qoff, db->d_qoff, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    ENUM_PHASE("H2D + count + scan + qoff");
+    const int64_t tot = qoff[nq];
+    if (total) *total = tot;
+    if (tot == 0) return IGD_HIP_OK;
+    int64_t maxq = 0;
+    for (int64_t i = 0; i < nq; i++) if (qoff[i + 1] - qoff[i] > maxq) maxq = qoff[i + 1] - qoff[i];
+    if (maxq > db->enumChunkCap) {                         // one query larger than a chunk buffer: grow them
+        rc = ensure_enum_workspace(db, nq, maxq, !wantWhole);
+        if (rc != IGD_HIP_OK) return rc;
+    }
+    igd_hip_hit *whole = nullptr;
+    if (wantWhole) {
+        size_t got = 0;
+        size_t *hdr = (size_t *)pinned_take((size_t)tot * sizeof(igd_hip_hit), &got);
+        if (!hdr) { snprintf(g_err, sizeof g_err, "igd_hip_enumerate: pinned host allocation failed"); return IGD_HIP_ERR_NOMEM; }
+        hdr[0] = got;
+        whole = (igd_hip_hit *)((char *)hdr + 64);
+        ENUM_PHASE("pinned result buffer");
+    }
+    static const bool zeroCopy = getenv("IGD_ENUM_ZEROCOPY") != nullptr;   // A/B: the fill kernel stores straight into pinned host memory
+    const int64_t cap = db->enumChunkCap;
+    int64_t qa = 0, prevA = 0, prevB = 0;
+    int k = 0;
+    hipError_t e = hipSuccess;
+    int sinkRc = 0;
+    while (qa < nq && e == hipSuccess && sinkRc == 0) {
+        int64_t qb = qa + 1;                               // longest range [qa,qb) whose overlaps fit the buffer
+        {
+            int64_t lo = qa + 1, hi = nq;                  // qoff is non-decreasing: bisect
+            while (lo < hi) {
+                const int64_t mid = lo + (hi - lo + 1) / 2;
+                if (qoff[mid] - qoff[qa] <= cap) lo = mid; else hi = mid - 1;
+            }
+            qb = lo;
+        }
+        const int64_t nh = qoff[qb] - qoff[qa];
+        const int b = k & 1;
+        if (nh > 0) {
+            igd_hip_hit *hostDst = whole ? whole + qoff[qa] : db->h_enumPin[b];
+            if (k >= 2) e = hipStreamWaitEvent(st, db->evCopy[b], 0);          // the buffer's previous copy is done
+            if (e != hipSuccess) break;
+            igd_enum_queries<true><<<egrid, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, (int)qa, (int)qb, nullptr,
+                                                          db->d_qoff, qoff[qa], zeroCopy ? hostDst : db->d_enumOut[b]);
+            e = hipEventRecord(db->evFill[b], st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(db->copyStream, db->evFill[b], 0);
+            if (e == hipSuccess && !zeroCopy)
+                e = hipMemcpyAsync(hostDst, db->d_enumOut[b], (size_t)nh * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, db->copyStream);
+            if (e == hipSuccess) e = hipEventRecord(db->evCopy[b], db->copyStream);
+            if (e != hipSuccess) break;
+        }
+        if (sink && k >= 1 && prevB > prevA) {            // hand out the previous chunk while this one is produced
+            if (qoff[prevB] > qoff[prevA]) e = hipEventSynchronize(db->evCopy[(k - 1) & 1]);
+            if (e == hipSuccess) sinkRc = sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
+        }
+        prevA = qa; prevB = qb;
+        qa = qb;
+        if (nh > 0 || sink) k++;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(db->copyStream);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess && sink && sinkRc == 0 && prevB > prevA) sinkRc = sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
+    ENUM_PHASE("fill + D2H (+ sink)");
+#undef ENUM_PHASE
+    if (e != hipSuccess) {
+        if (whole) igd_hip_free(whole);
+        set_err("enumerate fill", e, __FILE__, __LINE__);
+        return IGD_HIP_ERR_DEVICE;
+    }
+    if (sinkRc != 0) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: the sink stopped the enumeration (%d)", sinkRc);
+        return IGD_HIP_ERR_ARG;
+    }
+    if (wholeOut) *wholeOut = whole;
+    return IGD_HIP_OK;
+}
+
 extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                                  int64_t nq, int64_t *qoff, igd_hip_hit **out, int64_t *total)
 {
@@ -2268,66 +2406,21 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
     if (total) *total = 0;
     for (int64_t i = 0; i <= nq; i++) qoff[i] = 0;
     if (nq == 0 || db->nT == 0) return IGD_HIP_OK;
-    HIPCHK(hipSetDevice(db->device));
-    hipStream_t st = db->stream;
-    int rc = ensure_qstage(db, nq);
-    if (rc != IGD_HIP_OK) return rc;
-    rc = ensure_workspace(db, nq, 16);
-    if (rc != IGD_HIP_OK) return rc;
-    int32_t *d_pcount = nullptr;
-    int64_t *d_qlong = nullptr, *d_qcount = nullptr, *d_qoff = nullptr, *d_bsum = nullptr;
-    igd_hip_hit *d_out = nullptr;
-    auto cleanup = [&]() {
-        if (d_pcount) (void)hipFree(d_pcount);
-        if (d_qlong) (void)hipFree(d_qlong);
-        if (d_qcount) (void)hipFree(d_qcount);
-        if (d_qoff) (void)hipFree(d_qoff);
-        if (d_bsum) (void)hipFree(d_bsum);
-        if (d_out) (void)hipFree(d_out);
-    };
-#define EH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; } } while (0)
-    if ((rc = dalloc(&d_pcount, (size_t)nq * IGD_SHORT_TILES, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-    if ((rc = dalloc(&d_qlong, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-    if ((rc = dalloc(&d_qcount, (size_t)nq, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-    if ((rc = dalloc(&d_qoff, (size_t)nq + 1, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-    if ((rc = dalloc(&d_bsum, (size_t)(nq / IGD_SCAN_TILE + 2), nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-    EH(hipMemcpyAsync(db->d_qc, ichr, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    EH(hipMemcpyAsync(db->d_qs, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    EH(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    EH(hipMemsetAsync(d_pcount, 0, (size_t)nq * IGD_SHORT_TILES * 4, st));
-    EH(hipMemsetAsync(d_qlong, 0, (size_t)nq * 8, st));
-    db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
-    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, 0, 0, st);
-    if (rc != IGD_HIP_OK) { cleanup(); return rc; }
-    igd_enum_tiles<false><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
-        db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
-    k_enum_qcount<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_pcount, d_qlong, (int)nq, d_qcount);
-    {
-        const int sb = (int)((nq + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE);
-        k_scan64_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(d_qcount, (int)nq, d_bsum);
-        k_scan64_apply<<<sb, IGD_SCAN_BLOCK, 0, st>>>(d_qcount, (int)nq, d_bsum, d_qoff);
+    return enumerate_core(db, ichr, qs, qe, nq, qoff, true, out, nullptr, nullptr, total);
+}
+
+extern "C" int igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                                        int64_t nq, int64_t *qoff, igd_hip_enum_sink sink, void *ctx, int64_t *total)
+{
+    if (!db || !qoff || !sink || nq < 0 || nq > IGD_MAX_BATCH || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: bad argument (batch limit %lld)", (long long)IGD_MAX_BATCH);
+        return IGD_HIP_ERR_ARG;
     }
-    EH(hipMemcpyAsync(qoff, d_qoff, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, st));
-    EH(hipStreamSynchronize(st));
-    int64_t tot = qoff[nq];
-    if (total) *total = tot;
-    if (tot > 0) {
-        if ((rc = dalloc(&d_out, (size_t)tot, nullptr)) != IGD_HIP_OK) { cleanup(); return rc; }
-        igd_enum_tiles<true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
-            db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_out);
-        size_t got = 0;
-        size_t *hdr = (size_t *)pinned_take((size_t)tot * sizeof(igd_hip_hit), &got);
-        if (!hdr) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_enumerate: pinned host allocation failed"); return IGD_HIP_ERR_NOMEM; }
-        hdr[0] = got;
-        igd_hip_hit *h = (igd_hip_hit *)((char *)hdr + 64);
-        hipError_t e = hipMemcpyAsync(h, d_out, (size_t)tot * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { igd_hip_free(h); set_err("enumerate fill", e, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; }
-        *out = h;
-    }
-#undef EH
-    cleanup();
-    return IGD_HIP_OK;
+    if (total) *total = 0;
+    for (int64_t i = 0; i <= nq; i++) qoff[i] = 0;
+    if (nq == 0) return IGD_HIP_OK;
+    if (db->nT == 0) return sink(ctx, 0, nq, qoff, nullptr) == 0 ? IGD_HIP_OK : IGD_HIP_ERR_ARG;
+    return enumerate_core(db, ichr, qs, qe, nq, qoff, false, nullptr, sink, ctx, total);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2476,7 +2569,7 @@ __global__ void k_seq_accumulate(const float *__restrict__ sel, const int32_t *_
 {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= nFiles) return;
-    double acc = 0.0;
+    double acc = sums[m];                                     // 0, or the running sum of the earlier contigs (igd_hip_seqpare_add)
     for (int32_t c = 0; c < nGroups; c++) {
         const int64_t g = (int64_t)c * nFiles + m;
         const int64_t o = goff[g];
@@ -2486,8 +2579,8 @@ __global__ void k_seq_accumulate(const float *__restrict__ sel, const int32_t *_
     sums[m] = acc;
 }
 
-extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
-                               const int32_t *qgroup, int32_t nGroups, double *sums)
+static int seqpare_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                        const int32_t *qgroup, int32_t nGroups, double *sums, bool carry)
 {
     if (!db || !sums || nq < 0 || nq > IGD_MAX_BATCH || nGroups < 0 || (nq > 0 && (!ichr || !qs || !qe || !qgroup)) ||
         (int64_t)nGroups * db->nFiles >= 0x7fffffffLL) {
@@ -2498,17 +2591,15 @@ extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_
         snprintf(g_err, sizeof g_err, "igd_hip_seqpare: needs a gType-1 database (seq_overlaps reads 16-byte records)");
         return IGD_HIP_ERR_ARG;
     }
-    for (int32_t m = 0; m < db->nFiles; m++) sums[m] = 0.0;
+    if (!carry) for (int32_t m = 0; m < db->nFiles; m++) sums[m] = 0.0;
     if (nq == 0 || db->nT == 0 || nGroups == 0 || db->nFiles == 0) return IGD_HIP_OK;
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = db->stream;
     int rc = ensure_qstage(db, nq);
     if (rc != IGD_HIP_OK) return rc;
-    rc = ensure_workspace(db, nq, 16);
-    if (rc != IGD_HIP_OK) return rc;
     const int64_t nG = (int64_t)nGroups * db->nFiles;
-    int32_t *d_pcount = nullptr, *d_qgrp = nullptr, *d_nsel = nullptr, *x_rows = nullptr;
-    int64_t *d_qlong = nullptr, *d_qcount = nullptr, *d_qoff = nullptr, *d_bsum = nullptr, *d_goff = nullptr, *d_dig = nullptr,
+    int32_t *d_qgrp = nullptr, *d_nsel = nullptr, *x_rows = nullptr;
+    int64_t *d_qcount = nullptr, *d_qoff = nullptr, *d_bsum = nullptr, *d_goff = nullptr, *d_dig = nullptr,
             *d_sums = nullptr, *d_tot = nullptr;
     unsigned long long *x_cols = nullptr;
     uint32_t *kA = nullptr, *vA = nullptr, *kB = nullptr, *vB = nullptr, *d_gcnt = nullptr, *d_hist = nullptr;
@@ -2518,27 +2609,20 @@ extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_
     igd_hip_hit *d_ent = nullptr;
     uint32_t *h_gcnt = nullptr;
     auto cleanup = [&]() {
-        void *ps[] = { d_pcount, d_qgrp, d_nsel, x_rows, d_qlong, d_qcount, d_qoff, d_bsum, d_goff, d_dig, d_sums,
+        void *ps[] = { d_qgrp, d_nsel, x_rows, d_qcount, d_qoff, d_bsum, d_goff, d_dig, d_sums,
                        d_tot, x_cols, kA, vA, kB, vB, d_gcnt, d_hist, d_sel, d_out, d_next, d_ent };
         for (void *p : ps) if (p) (void)hipFree(p);
         free(h_gcnt);
     };
 #define EH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); cleanup(); return IGD_HIP_ERR_DEVICE; } } while (0)
 #define DA(p, n) do { if ((rc = dalloc(&(p), (size_t)(n), nullptr)) != IGD_HIP_OK) { cleanup(); return rc; } } while (0)
-    DA(d_pcount, nq * IGD_SHORT_TILES); DA(d_qlong, nq); DA(d_qcount, nq); DA(d_qoff, nq + 1);
+    DA(d_qcount, nq); DA(d_qoff, nq + 1);
     DA(d_bsum, nq / IGD_SCAN_TILE + 2); DA(d_qgrp, nq);
     EH(hipMemcpyAsync(db->d_qc, ichr, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemcpyAsync(db->d_qs, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemcpyAsync(db->d_qe, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
     EH(hipMemcpyAsync(d_qgrp, qgroup, (size_t)nq * 4, hipMemcpyHostToDevice, st));
-    EH(hipMemsetAsync(d_pcount, 0, (size_t)nq * IGD_SHORT_TILES * 4, st));
-    EH(hipMemsetAsync(d_qlong, 0, (size_t)nq * 8, st));
-    db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
-    rc = launch_bucket<true>(db, db->d_qc, db->d_qs, db->d_qe, (int)nq, IGD_HIP_RULE_NEST, 0, 0, st);
-    if (rc != IGD_HIP_OK) { cleanup(); return rc; }
-    igd_enum_tiles<false, true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
-        db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, nullptr, nullptr);
-    k_enum_qcount<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_pcount, d_qlong, (int)nq, d_qcount);
+    igd_enum_queries<false, true><<<db->grid * 4, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, 0, (int)nq, d_qcount, nullptr, 0, nullptr);
     {
         const int sb = (int)((nq + IGD_SCAN_TILE - 1) / IGD_SCAN_TILE);
         k_scan64_sums<<<sb, IGD_SCAN_BLOCK, 0, st>>>(d_qcount, (int)nq, d_bsum);
@@ -2550,8 +2634,7 @@ extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_
     if (E == 0) { cleanup(); return IGD_HIP_OK; }
     if (E >= 0xffffffffLL) { cleanup(); snprintf(g_err, sizeof g_err, "igd_hip_seqpare: %lld overlaps exceed one batch", (long long)E); return IGD_HIP_ERR_ARG; }
     DA(d_ent, E);
-    igd_enum_tiles<true, true><<<db->grid, IGD_WG, 0, st>>>(db->v, db->d_pairN, db->d_pairPos, (const int4 *)db->d_pairs,
-        db->d_long, db->d_ctl, db->epoch, db->d_qc, db->d_qs, db->d_qe, d_pcount, d_qlong, d_qoff, d_ent);
+    igd_enum_queries<true, true><<<db->grid * 4, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, 0, (int)nq, nullptr, d_qoff, 0, d_ent);
     // order the entries: stable radix sort by similarity (descending), then by group (query contig * nFiles +
     // dataset) -> inside a group: similarity descending, ties in the reference's scan order
     DA(kA, E); DA(vA, E); DA(kB, E); DA(vB, E); DA(d_gcnt, nG + 1); DA(d_goff, nG + 1); DA(d_tot, 8);
@@ -2582,6 +2665,8 @@ extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_
     }
     DA(d_sel, E); DA(d_nsel, nG); DA(d_next, 16); DA(d_out, db->nFiles);
     EH(hipMemsetAsync(d_next, 0, 4, st));
+    if (carry) EH(hipMemcpyAsync(d_out, sums, (size_t)db->nFiles * 8, hipMemcpyHostToDevice, st));   // the running sums continue
+    else EH(hipMemsetAsync(d_out, 0, (size_t)db->nFiles * 8, st));
     {
         SeqArgs a;
         a.ent = d_ent; a.vals = vA; a.goff = d_goff; a.q_qs = db->d_qs; a.sel = d_sel; a.nsel = d_nsel;
@@ -2598,6 +2683,17 @@ extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_
 #undef DA
     cleanup();
     return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                               const int32_t *qgroup, int32_t nGroups, double *sums)
+{
+    return seqpare_core(db, ichr, qs, qe, nq, qgroup, nGroups, sums, false);
+}
+extern "C" int igd_hip_seqpare_add(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                                   const int32_t *qgroup, int32_t nGroups, double *sums)
+{
+    return seqpare_core(db, ichr, qs, qe, nq, qgroup, nGroups, sums, true);
 }
 
 extern "C" int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total)
@@ -2676,6 +2772,158 @@ extern "C" int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const 
     if (e != hipSuccess) { set_err("batch_stats", e, __FILE__, __LINE__); return IGD_HIP_ERR_DEVICE; }
     out->queries = (int64_t)acc[0]; out->pairs = (int64_t)acc[1];
     out->S = (int64_t)acc[2]; out->B = (int64_t)acc[3]; out->H = tot;
+    return IGD_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// instrumentation: compulsory traffic of the scan kernel for one batch (include/igd_hip.h)
+__global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, const int32_t *__restrict__ pairN,
+                               int sortedPath, u64 *__restrict__ acc /* units, records, pairs */)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 nu = 0, nr = 0, np = 0;
+    if (u < db.nUnits) {
+        const Unit un = db.units[u];
+        if (un.n > 0) {
+            if (sortedPath) {       // exactly the test of issue_unit: the candidate range of the unit's tile is not empty
+                const int lj = UNIT_J(un);
+                const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+                if (firstQ[un.tile + 1] > firstQ[un.tile - lb]) { nu = 1; nr = (u64)un.n; }
+            } else if (pairN[un.tile] > 0) {
+                nu = 1; nr = (u64)un.n;
+                if (UNIT_FLAGS(un) & 1) np = (u64)pairN[un.tile];
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nu += __shfl_down(nu, o); nr += __shfl_down(nr, o); np += __shfl_down(np, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nu) atomicAdd(&acc[0], nu);
+        if (nr) atomicAdd(&acc[1], nr);
+        if (np) atomicAdd(&acc[2], np);
+    }
+}
+
+extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
+                                     int64_t nq, int32_t v, int rule, int flags, igd_hip_traffic *out)
+{
+    if (!db || !out || nq < 0 || nq > IGD_MAX_BATCH) return IGD_HIP_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    if (nq == 0 || db->nT == 0 || db->nFiles == 0) return IGD_HIP_OK;
+    HIPCHK(hipSetDevice(db->device));
+    u64 *d_acc = nullptr;
+    int64_t *d_h = nullptr;
+    int rc;
+    if ((rc = dalloc(&d_acc, 4, nullptr)) != IGD_HIP_OK) return rc;
+    if ((rc = dalloc(&d_h, (size_t)db->nFiles + 1, nullptr)) != IGD_HIP_OK) { (void)hipFree(d_acc); return rc; }
+    hipStream_t st = db->stream;
+    (void)hipMemsetAsync(d_acc, 0, 32, st);
+    (void)hipMemsetAsync(d_h, 0, ((size_t)db->nFiles + 1) * 8, st);
+    const bool saved = db->evOn;
+    db->evOn = false;
+    rc = igd_hip_search_dev(db, d_ichr, d_qs, d_qe, nq, v, rule, flags & ~IGD_HIP_FLAG_ZERO_FIRST, d_h, nullptr, st);
+    db->evOn = saved;
+    int32_t ctl[4] = {0, 0, 0, 0};
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(ctl, db->d_ctl, sizeof ctl, hipMemcpyDeviceToHost);
+    if (rc == IGD_HIP_OK && e == hipSuccess) {
+        const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
+        const bool sortedPath = mode == 1 || (mode == 0 && ctl[CTL_UNSORTED] != db->epoch);
+        k_unit_traffic<<<(db->nUnits + 255) / 256, 256, 0, st>>>(db->v, db->d_firstQ, db->d_pairN, sortedPath ? 1 : 0, d_acc);
+        u64 acc[4] = {0, 0, 0, 0};
+        e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(acc, d_acc, 32, hipMemcpyDeviceToHost);
+        const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);
+        const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
+        const int recB = packed ? (useV ? 8 : 6) : (useV ? 16 : 12);
+        out->units = (int64_t)acc[0];
+        out->records = (int64_t)acc[1];
+        out->record_bytes = (int64_t)acc[1] * recB;
+        out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
+        out->query_bytes = sortedPath ? 12ll * nq : 8ll * (int64_t)acc[2];
+        out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * 8 : 8ll * db->nFiles;
+        out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;
+    }
+    (void)hipFree(d_acc); (void)hipFree(d_h);
+    (void)igd_hip_sync(db, st);                            // consumes a promise made for this measurement batch
+    if (rc != IGD_HIP_OK) return rc;
+    if (e != hipSuccess) { set_err("batch_traffic", e, __FILE__, __LINE__); return IGD_HIP_ERR_DEVICE; }
+    return IGD_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// instrumentation: what the memory system of THIS box gives simple streaming kernels (bench.py quotes
+// it next to the roofline): a float4 copy (the guide's 6.29 TB/s measurement), a float4 read-only sum,
+// pinned D2H / H2D copies.
+__global__ __launch_bounds__(256) void k_copy16(const float4 *__restrict__ in, float4 *__restrict__ outp, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {          // four independent 16-byte loads in flight per lane
+        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        outp[i] = a; outp[i + stride] = b; outp[i + 2 * stride] = c; outp[i + 3 * stride] = d;
+    }
+    for (; i < n; i += stride) outp[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_read16(const float4 *__restrict__ in, size_t n, float *__restrict__ sink)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        acc += a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    }
+    for (; i < n; i += stride) { const float4 a = in[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 123.456f) *sink = acc;                       // never true for the zero-filled buffer; keeps the loads
+}
+
+extern "C" int igd_hip_measure_rates(int device, double rates[4])
+{
+    if (!rates) return IGD_HIP_ERR_ARG;
+    for (int k = 0; k < 4; k++) rates[k] = 0.0;
+    HIPCHK(hipSetDevice(device));
+    const size_t bytes = (size_t)1 << 30, n16 = bytes / 16, hb = (size_t)256 << 20;
+    float4 *a = nullptr, *b = nullptr;
+    float *sink = nullptr;
+    void *h = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e = hipMalloc((void **)&a, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&b, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&sink, 16);
+    if (e == hipSuccess) e = hipHostMalloc(&h, hb, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0, bytes, st);
+    if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, st);
+    if (e == hipSuccess) memset(h, 0, hb);
+    const int grid = 256 * 16, reps = 10;
+    for (int which = 0; which < 4 && e == hipSuccess; which++) {
+        float best = 1e30f;
+        for (int r = 0; r < reps + 2 && e == hipSuccess; r++) {
+            e = hipEventRecord(e0, st);
+            if (which == 0) k_copy16<<<grid, 256, 0, st>>>(a, b, n16);
+            else if (which == 1) k_read16<<<grid, 256, 0, st>>>(a, n16, sink);
+            else if (which == 2) { if (e == hipSuccess) e = hipMemcpyAsync(h, a, hb, hipMemcpyDeviceToHost, st); }
+            else { if (e == hipSuccess) e = hipMemcpyAsync(a, h, hb, hipMemcpyHostToDevice, st); }
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (r >= 2 && ms < best) best = ms;
+        }
+        const double moved = which == 0 ? 2.0 * (double)bytes : which == 1 ? (double)bytes : (double)hb;
+        if (e == hipSuccess && best > 0.f) rates[which] = moved / ((double)best * 1e-3) / 1e9;
+    }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (sink) (void)hipFree(sink);
+    if (h) (void)hipHostFree(h);
+    if (e != hipSuccess) { set_err("measure_rates", e, __FILE__, __LINE__); return IGD_HIP_ERR_DEVICE; }
     return IGD_HIP_OK;
 }
 

@@ -21,11 +21,17 @@ static int device_from_env(void)
     return e && *e ? atoi(e) : 0;
 }
 
-static void die_no_gpu(const char *where, int rc)
+/* A library must not end the interpreter that loaded it: an engine failure is reported on stderr,
+ * the call returns like the reference's silent failures (hits untouched) and igd_engine_status() keeps
+ * the code -- the Python shim (igd_amd/igd_py.py) turns it into an exception. */
+static int g_fail_rc = 0;
+int igd_engine_status(void) { return g_fail_rc; }
+void igd_engine_clear(void) { g_fail_rc = 0; }
+static void engine_failed(const char *where, int rc)
 {
     fprintf(stderr, "igd_py: %s: GPU engine unavailable (code %d): %s\n"
                     "igd_py: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
-    exit(EX_UNAVAILABLE);
+    g_fail_rc = rc ? rc : IGD_HIP_ERR_DEVICE;
 }
 
 iGD_t *iGD_init(void)
@@ -51,7 +57,7 @@ void open_iGD(iGD_t *iGD, char *igdFile)
     if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
     free(tsv);
     int rc = igdc_attach_path(core, igdFile, device_from_env());
-    if (rc != IGD_HIP_OK) { igdc_close(core); die_no_gpu("open_iGD", rc); }
+    if (rc != IGD_HIP_OK) { igdc_close(core); engine_failed("open_iGD", rc); return; }
     iGD->core = core;
 }
 
@@ -64,8 +70,14 @@ void close_iGD(iGD_t *iGD)
 
 void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_size)
 {
-    (void)iGD;
-    size_t lo = strlen(oPath), li = strlen(iPath);
+    /* the reference appends "/", "*" or "/" "*" to the CALLER's buffers (src_py/igd_create.c:22-31) --
+     * which its own Cython wrapper hands over as immutable Python bytes objects; copies are extended here */
+    const size_t lo = strlen(oPath), li = strlen(iPath);
+    char *oBuf = (char *)malloc(lo + 4), *iBuf = (char *)malloc(li + 4);
+    if (!oBuf || !iBuf) { free(oBuf); free(iBuf); return; }
+    memcpy(oBuf, oPath, lo + 1);
+    memcpy(iBuf, iPath, li + 1);
+    oPath = oBuf; iPath = iBuf;
     if (lo && oPath[lo - 1] != '/') strcat(oPath, "/");
     if (li && iPath[li - 1] == '/') strcat(iPath, "*");
     else if (li && iPath[li - 1] != '*') strcat(iPath, "/*");
@@ -75,7 +87,7 @@ void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_si
     struct stat st;
     if (stat(probe, &st) == 0) {
         printf("The igd database file %s exists!\n", probe);
-        free(probe);
+        free(probe); free(oBuf); free(iBuf);
         return;
     }
     igdc_create_opts o;
@@ -85,9 +97,9 @@ void create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_si
     const char *dv = getenv("IGD_DEVICE");
     o.device = dv ? atoi(dv) : 0;
     const int rc = igdc_create(&o);
-    if (rc < 0) die_no_gpu("create_iGD", rc);
+    if (rc < 0) engine_failed("create_iGD", rc);
     if (rc == 0 && iGD) open_iGD(iGD, probe);                              /* src_py/igd_create.c:140-141 */
-    free(probe);
+    free(probe); free(oBuf); free(iBuf);
 }
 
 void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
@@ -97,7 +109,7 @@ void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
     if (ichr < 0) return;
     int rc = igd_hip_search(iGD->core->dev, &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
                             IGD_HIP_RULE_NEST, hits, NULL);
-    if (rc != IGD_HIP_OK) die_no_gpu("get_overlaps", rc);
+    if (rc != IGD_HIP_OK) engine_failed("get_overlaps", rc);
 }
 
 int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
@@ -108,7 +120,7 @@ int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
     if (q.n > 0) {
         int rc = igd_hip_search_ex(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
                                    IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
-        if (rc != IGD_HIP_OK) die_no_gpu("getOverlaps", rc);
+        if (rc != IGD_HIP_OK) { engine_failed("getOverlaps", rc); igdc_queries_free(&q); return 0; }
     }
     igdc_queries_free(&q);
     int64_t nols = 0;

@@ -21,11 +21,17 @@ static int device_from_env(void)
     return e && *e ? atoi(e) : 0;
 }
 
-static void die_no_gpu(const char *where, int rc)
+/* A library must not end the R session that loaded it: an engine failure is reported on stderr, the
+ * call returns like the reference's silent failures (hits untouched, NULL handle) and
+ * igd_engine_status() keeps the code; the .Call entry points raise it as an R error (Rf_error). */
+static int g_fail_rc = 0;
+int igd_engine_status(void) { return g_fail_rc; }
+void igd_engine_clear(void) { g_fail_rc = 0; }
+static void engine_failed(const char *where, int rc)
 {
     fprintf(stderr, "IGDr: %s: GPU engine unavailable (code %d): %s\n"
                     "IGDr: this build has no CPU search path.\n", where, rc, igd_hip_last_error());
-    exit(EX_UNAVAILABLE);
+    g_fail_rc = rc ? rc : IGD_HIP_ERR_DEVICE;
 }
 
 iGD_t *open_iGD(char *igdFile)
@@ -39,7 +45,7 @@ iGD_t *open_iGD(char *igdFile)
     if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
     free(tsv);
     int rc = igdc_attach_path(core, igdFile, device_from_env());
-    if (rc != IGD_HIP_OK) { igdc_close(core); die_no_gpu("open_iGD", rc); }
+    if (rc != IGD_HIP_OK) { igdc_close(core); engine_failed("open_iGD", rc); return NULL; }
     iGD_t *h = (iGD_t *)calloc(1, sizeof *h);
     h->core = core;
     h->path = strdup(igdFile);
@@ -66,7 +72,7 @@ void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
     if (ichr < 0) return;
     int rc = igd_hip_search(iGD->core->dev, &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
                             IGD_HIP_RULE_NEST, hits, NULL);
-    if (rc != IGD_HIP_OK) die_no_gpu("get_overlaps", rc);
+    if (rc != IGD_HIP_OK) engine_failed("get_overlaps", rc);
 }
 
 void igdr_search_n32(iGD_t *iGD, int32_t n, const char *const *chrm, const int32_t *qs,
@@ -84,7 +90,7 @@ void igdr_search_n32(iGD_t *iGD, int32_t n, const char *const *chrm, const int32
     if (q.n > 0) {
         int rc = igd_hip_search(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
                                 IGD_HIP_RULE_NEST, h64, NULL);
-        if (rc != IGD_HIP_OK) die_no_gpu("search", rc);
+        if (rc != IGD_HIP_OK) { engine_failed("search", rc); memset(h64, 0, sizeof(int64_t) * (size_t)nf); }
     }
     for (int32_t f = 0; f < nf; f++) hits[f] = (int32_t)((int64_t)hits[f] + h64[f]);
     free(h64);
@@ -114,7 +120,7 @@ void getOverlaps(char **igdFile, char **qFile, int64_t *hits)
         if (q.n > 0) {
             int rc = igd_hip_search_ex(h->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
                                        IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
-            if (rc != IGD_HIP_OK) die_no_gpu("getOverlaps", rc);
+            if (rc != IGD_HIP_OK) engine_failed("getOverlaps", rc);
         }
         igdc_queries_free(&q);
     }
@@ -146,7 +152,7 @@ static void create_common(char **iPath, char **oPath, char **igdName, int *binsi
         const char *dv = getenv("IGD_DEVICE");
         o.device = dv ? atoi(dv) : 0;
         const int rc = igdc_create(&o);
-        if (rc < 0) die_no_gpu("create_iGD", rc);
+        if (rc < 0) engine_failed("create_iGD", rc);
     }
     free(probe); free(in); free(out);
 }
@@ -178,6 +184,7 @@ static void igdr_finalizer(SEXP igdr) { (void)iGD_free(igdr); }
 SEXP iGD_new(SEXP igd_file)
 {
     iGD_t *h = open_iGD((char *)CHAR(STRING_ELT(igd_file, 0)));
+    if (h == NULL && g_fail_rc) { g_fail_rc = 0; error("IGDr: GPU engine unavailable: %s", igd_hip_last_error()); }
     SEXP igdr, klass, obj;
     PROTECT(igdr = R_MakeExternalPtr(h, R_NilValue, R_NilValue));
     R_RegisterCFinalizer(igdr, igdr_finalizer);
@@ -196,6 +203,7 @@ SEXP search_1r(SEXP igdr, SEXP qchrm, SEXP qs, SEXP qe)
     memset(INTEGER(hits), 0, (size_t)h->core->nFiles * sizeof(int));
     get_overlaps32(h, (char *)CHAR(STRING_ELT(qchrm, 0)), INTEGER(qs)[0], INTEGER(qe)[0], INTEGER(hits));
     UNPROTECT(1);
+    if (g_fail_rc) { g_fail_rc = 0; error("IGDr: GPU engine failure: %s", igd_hip_last_error()); }
     return hits;
 }
 
@@ -211,6 +219,7 @@ SEXP search_nr(SEXP igdr, SEXP n, SEXP qchrm, SEXP qs, SEXP qe)
     igdr_search_n32(h, m, names, INTEGER(qs), INTEGER(qe), INTEGER(hits));
     free(names);
     UNPROTECT(1);
+    if (g_fail_rc) { g_fail_rc = 0; error("IGDr: GPU engine failure: %s", igd_hip_last_error()); }
     return hits;
 }
 

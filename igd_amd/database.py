@@ -149,6 +149,27 @@ class Database:
             rec = np.zeros((0, 4), np.int32)
         return qoff, rec
 
+    def enumerate_stream(self, ichr, qs, qe, on_chunk=None):
+        """`-f`, streamed (igd_hip_enumerate_stream): on_chunk(q0, q1, qoff, rec) is called per chunk with
+        rec = int32[n,4] VIEW of the pinned chunk buffer (valid during the call only).  Returns (qoff, total)."""
+        ichr, qs, qe = _i32(ichr), _i32(qs), _i32(qe)
+        nq = len(qs)
+        qoff = np.zeros(nq + 1, np.int64)
+        total = C.c_int64(0)
+
+        def sink(ctx, q0, q1, qoff_p, hits_p):
+            if on_chunk is not None:
+                n = int(qoff[q1] - qoff[q0])
+                rec = (np.ctypeslib.as_array(C.cast(hits_p, N.i32p), shape=(n * 4,)).reshape(n, 4)
+                       if n else np.zeros((0, 4), np.int32))
+                on_chunk(int(q0), int(q1), qoff, rec)
+            return 0
+
+        cb = N.ENUM_SINK(sink)
+        _chk(self._H.igd_hip_enumerate_stream(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq,
+                                              qoff.ctypes.data, cb, None, C.byref(total)), "igd_hip_enumerate_stream")
+        return qoff, total.value
+
     def hitmap(self, v=0):
         """`-m`: (uint32[nfiles,nfiles], pairs); v>0 keeps records with value > v (getMap_v)."""
         m = np.zeros((self.nfiles, self.nfiles), np.uint32)
@@ -177,6 +198,14 @@ class Database:
              "igd_hip_batch_stats")
         return dict(queries=st.queries, pairs=st.pairs, S=st.S, B=st.B, H=st.H)
 
+    def batch_traffic(self, d_ichr, d_qs, d_qe, nq, v=0, flags=0):
+        """Compulsory HBM bytes of the scan kernel for this batch (igd_hip_batch_traffic)."""
+        rule, vf = self.cli_dispatch(self.gtype, v)
+        t = N.HipTraffic()
+        _chk(self._H.igd_hip_batch_traffic(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, int(flags), C.byref(t)),
+             "igd_hip_batch_traffic")
+        return {k: getattr(t, k) for k, _ in N.HipTraffic._fields_}
+
     def algorithmic_bytes(self, stats, nq, mode="hits"):
         """bytes one launch has to touch, by the reference's own work terms."""
         b = 4 * stats["S"] + 4 * stats["H"] + 4 * stats["B"] + 16 * stats["pairs"] + 12 * nq + 8 * self.nfiles
@@ -193,3 +222,10 @@ class Database:
         n, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
         _chk(self._H.igd_hip_profile_end(self.dev, C.byref(n), C.byref(a), C.byref(b)), "igd_hip_profile_end")
         return dict(launches=n.value, scan_ms=a.value, pipeline_ms=b.value)
+
+
+def measure_rates(device=0):
+    """GB/s of this box, measured now: HBM float4 copy (read+write), HBM float4 read, pinned D2H, pinned H2D."""
+    r = (C.c_double * 4)()
+    _chk(N.hip().igd_hip_measure_rates(int(device), r), "igd_hip_measure_rates")
+    return {"hbm_copy_GBps": r[0], "hbm_read_GBps": r[1], "d2h_GBps": r[2], "h2d_GBps": r[3]}

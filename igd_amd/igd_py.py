@@ -7,10 +7,21 @@ import numpy as np
 from . import _native as N
 
 
+class IgdEngineError(RuntimeError):
+    """The GPU engine behind libigd_py.so could not be used (the library itself only reports it)."""
+
+
 class igd_py:
     def __init__(self):
         self._L = N.pyabi()
         self._h = self._L.iGD_init()
+
+    def _check(self, what):
+        rc = self._L.igd_engine_status()
+        if rc:
+            self._L.igd_engine_clear()
+            raise IgdEngineError("%s: GPU engine failure (code %d): %s -- there is no CPU search path"
+                                 % (what, rc, N.hip().igd_hip_last_error().decode()))
 
     def __del__(self):
         try:
@@ -25,19 +36,22 @@ class igd_py:
 
     def create(self, iPath, oPath, igdName, bin_size):
         import ctypes as C
-        # the C side appends "/" and "*" in place (src_py/igd_create.c:22-31): give it room
-        i = C.create_string_buffer(str.encode(iPath), len(iPath) + 8)
-        o = C.create_string_buffer(str.encode(oPath), len(oPath) + 8)
-        self._L.create_iGD(self._h, i, o, str.encode(igdName), int(bin_size))
+        # exactly what the reference's .pyx passes: immutable bytes objects (the C side copies them)
+        self._L.create_iGD(self._h, str.encode(iPath), str.encode(oPath), str.encode(igdName), int(bin_size))
+        self._check("create")
 
     def open(self, igdFile):
         self._L.open_iGD(self._h, str.encode(igdFile))
+        self._check("open")
 
     def search_1(self, chrm, qs, qe, hits):
         assert hits.dtype == np.int64 and hits.flags["C_CONTIGUOUS"] and hits.ndim == 1
         self._L.get_overlaps(self._h, str.encode(chrm), int(qs), int(qe),
                              hits.ctypes.data_as(N.i64p))
+        self._check("search_1")
 
     def search_n(self, qFile, hits):
         assert hits.dtype == np.int64 and hits.flags["C_CONTIGUOUS"] and hits.ndim == 1
-        return self._L.getOverlaps(self._h, str.encode(qFile), hits.ctypes.data_as(N.i64p))
+        n = self._L.getOverlaps(self._h, str.encode(qFile), hits.ctypes.data_as(N.i64p))
+        self._check("search_n")
+        return n

@@ -33,6 +33,20 @@ def make_queries(n, seed=7, genome=HG38, min_len=100, max_len=1999, sorted_=True
     return ichr, qs, qe
 
 
+def make_queries_slab(n_total, lo, hi, seed=7, genome=HG38, min_len=100, max_len=1999):
+    """Queries [lo, hi) of make_queries(n_total, seed, sorted_=True) without building the rest (config 4:
+    rank r of N takes slab r of ONE position-sorted set of N x 1.25e7 queries)."""
+    m = int(hi) - int(lo)
+    ichr = np.empty(m, np.int32)
+    qs = np.empty(m, np.int32)
+    qe = np.empty(m, np.int32)
+    got = N.synth().igd_synth_queries_slab(int(n_total), seed, genome, min_len, max_len, int(lo), int(hi),
+                                           ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data)
+    if got != m:
+        raise RuntimeError("igd_synth_queries_slab failed")
+    return ichr, qs, qe
+
+
 def write_bed(path, genome, ichr, qs, qe):
     ichr, qs, qe = (np.ascontiguousarray(a, np.int32) for a in (ichr, qs, qe))
     if N.synth().igd_synth_write_bed(path.encode(), genome, len(qs), ichr.ctypes.data, qs.ctypes.data,

@@ -133,6 +133,18 @@ int  igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs,
                        int64_t *total);
 void igd_hip_free(void *p);
 
+/* The same enumeration, STREAMED: the overlaps are produced in chunks of contiguous query ranges
+ * (<= 64 MiB of records each, a whole query never split) and each chunk is handed to `sink` from
+ * pinned host memory while the next chunks are being filled and copied -- the caller (the command
+ * line tool's formatter, getOverlaps_f1 src/igd_search.c:721-744) works on chunk k while chunk k+1
+ * crosses PCIe.  qoff[0..nq] is complete before the first sink call; a chunk covers queries [q0,q1),
+ * `hits` points at overlap number qoff[q0] (so overlap h of the batch is hits[h - qoff[q0]]) and is
+ * only valid during the call.  Chunks arrive in order and together cover [0,nq) exactly once, also
+ * the queries without overlaps.  A non-zero return of the sink stops the enumeration.  Blocking. */
+typedef int (*igd_hip_enum_sink)(void *ctx, int64_t q0, int64_t q1, const int64_t *qoff, const igd_hip_hit *hits);
+int  igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                              int64_t nq, int64_t *qoff, igd_hip_enum_sink sink, void *ctx, int64_t *total);
+
 /* `-m`: dataset x dataset hit map, getMap src/igd_search.c:772-826 (use_v = 0) and getMap_v
  * :829-886 (use_v = 1: both records need value > v, strictly).  hitmap is nFiles x nFiles uint32,
  * row-major, caller-allocated, ADDED to; *total (may be NULL) receives the number of pairs.
@@ -147,6 +159,10 @@ int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64
  * finishes with sm = sums/(Nq + nr - sums) (:446-449).  gType-1 databases; one batch; blocking. */
 int igd_hip_seqpare(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
                     const int32_t *qgroup, int32_t nGroups, double *sums);
+/* The same for a query file beyond one batch: the contigs of the file are passed range by range, in
+ * order; sums[] is NOT cleared but continued, so the additions happen in the reference's order. */
+int igd_hip_seqpare_add(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                        const int32_t *qgroup, int32_t nGroups, double *sums);
 
 /* `igd create`: intervals -> the tile region of an .igd, on the GPU.
  * Replaces igd_add (src/igd_base.c:118-169: replicate into tiles start/nbp..(end-1)/nbp),
@@ -181,6 +197,26 @@ void igd_hip_created_free(igd_hip_created *c);
 int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
                         const int32_t *d_qe, int64_t nq, int32_t v, int rule,
                         igd_hip_stats *out);
+/* COMPULSORY traffic of the dominant kernel for one batch: the bytes igd_scan_tiles cannot avoid moving
+ * through HBM when every visited unit's records are read exactly once -- the denominator-free part of
+ * a roofline fraction that stays <= 1 (the algorithmic bytes above price the REFERENCE's re-reads).
+ * Runs the batch once (grouping as `flags` say) into scratch counters and then counts, on the device,
+ * the units the scan kernel visited.  Blocking. */
+typedef struct {
+    int64_t units;          /* units (<= 320-record chunks of a tile) with at least one candidate query     */
+    int64_t records;        /* records in them                                                            */
+    int64_t record_bytes;   /* records x bytes per record of the image read (6 / 8 compact, 12 / 16 exact) */
+    int64_t unit_bytes;     /* 32-byte descriptors of ALL units + the per-tile query ranges read            */
+    int64_t query_bytes;    /* 12 B (ichr/qs/qe ... the merge join reads qw,qs,qe) + 4 B qw per query, once */
+    int64_t slab_bytes;     /* the workgroups' private counter rows written at the end of the kernel       */
+    int64_t total;          /* sum of the four                                                            */
+} igd_hip_traffic;
+int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
+                          int64_t nq, int32_t v, int rule, int flags, igd_hip_traffic *out);
+/* What this box's memory system delivers to simple streaming kernels, measured now (GB/s, 1e9):
+ * rates[0] float4 copy kernel, read+write bytes (the guide's 6.29 TB/s figure is this measurement);
+ * rates[1] float4 read-only kernel; rates[2] pinned device->host copy; rates[3] pinned host->device. */
+int igd_hip_measure_rates(int device, double rates[4]);
 /* HIP-event timing of the launches made by igd_hip_search_dev on their own stream:
  * begin() arms up to max_launches slots, end() waits and returns the number of launches
  * seen plus the average duration (ms) of the dominant scan kernel and of the whole

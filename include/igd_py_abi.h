@@ -26,11 +26,19 @@ iGD_t  *iGD_init(void);                                   /* src_py/igd_base.c:3
 int32_t get_nFiles(iGD_t *iGD);
 void    open_iGD(iGD_t *iGD, char *igdFile);              /* src_py/igd_base.c:161-222 */
 void    close_iGD(iGD_t *iGD);                            /* src_py/igd_base.c:350-366 */
-/* src_py/igd_create.c:18-143; appends "/" and "*" into the caller's buffers like the
- * reference does (:22-31), so iPath/oPath need room for 2 more characters */
+/* src_py/igd_create.c:18-143.  The reference appends "/" and "*" to the CALLER's buffers (:22-31),
+ * which the Cython wrapper passes as immutable bytes objects; here the paths are copied first and
+ * iPath/oPath are only read */
 void    create_iGD(iGD_t *iGD, char *iPath, char *oPath, char *igdName, int tile_size);
 void    get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits);  /* src_py/igd_search.c:25-102 */
 int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits);                          /* src_py/igd_search.c:104-128 */
+
+/* Not in the reference.  This library never ends the interpreter: when the GPU engine cannot be used
+ * the failing call says why on stderr and returns like the reference's silent failures (handle left
+ * closed / hits[] untouched / 0); igd_engine_status() returns the engine's code of the last such
+ * failure (0: none; igd_hip_last_error() has the text), igd_engine_clear() resets it. */
+int  igd_engine_status(void);
+void igd_engine_clear(void);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,13 @@ void seqOverlaps(char *qFile, double *sm);                                      
 /* `igd search <db.igd> [-q file | -r chr s e | -m] [-v N] [-f] [-o name] [-c]`        :889-1079 */
 int igd_search(int argc, char **argv);
 
+/* Not in the reference.  The library never ends the host process: when the GPU engine cannot be used
+ * (no device, out of memory, a batch beyond its limits) the failing call says why on stderr and returns
+ * like the reference's silent failures (0 / hits[] untouched, src/igd_search.c:457,462,701-702);
+ * this returns the engine's code of the FIRST such failure (0: none).  igd_search() returns non-zero
+ * instead of printing a table of zeros. */
+int igd_engine_status(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,13 @@ SEXP get_binLen(SEXP igdr, SEXP ichr, SEXP bin);
 SEXP get_binData(SEXP igdr, SEXP ichr, SEXP bin);
 #endif
 
+/* Not in the reference.  This library never ends the R session: when the GPU engine cannot be used the
+ * failing call says why on stderr and returns like the reference's silent failures (NULL handle /
+ * hits untouched); the .Call entry points raise an R error instead.  igd_engine_status(): the engine's
+ * code of the last such failure (0: none), igd_engine_clear() resets it. */
+int  igd_engine_status(void);
+void igd_engine_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,3 +55,37 @@ def test_two_rank_allreduce_equals_unsharded(tmp_path):
     want, _ = o.search(ichr, qs, qe, 0)
     for r in range(2):
         np.testing.assert_array_equal(np.load(os.path.join(str(tmp_path), "r%d.npy" % r)), want)
+
+
+def test_bench_spawns_its_ranks_before_touching_the_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` without WORLD_SIZE starts 2 child processes with the torchrun environment and
+    never imports torch / igd_amd in the parent (checked by running spawn_ranks against a stub child)."""
+    import importlib
+    import bench
+    importlib.reload(bench)
+    stub = tmp_path / "stub.py"
+    stub.write_text("import os, sys\n"
+                    "open(os.path.join(%r, 'r' + os.environ['RANK']), 'w').write(' '.join([os.environ['WORLD_SIZE'], "
+                    "os.environ['LOCAL_RANK'], os.environ['MASTER_ADDR'], os.environ['MASTER_PORT']] + sys.argv[1:]))\n"
+                    "sys.exit(3 if os.environ['RANK'] == '1' else 0)\n" % str(tmp_path))
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    mods = set(sys.modules)
+    rc = bench.spawn_ranks(2, ["--gpus", "2", "--steps", "4"])
+    assert rc == 3                                          # the worst child exit code is the parent's
+    assert not ({"torch", "igd_amd._native"} & (set(sys.modules) - mods))
+    got = [open(os.path.join(str(tmp_path), "r%d" % r)).read().split() for r in range(2)]
+    assert got[0][0] == got[1][0] == "2" and [g[1] for g in got] == ["0", "1"]
+    assert got[0][2] == "127.0.0.1" and got[0][3] == got[1][3] and got[0][4:] == ["--gpus", "2", "--steps", "4"]
+
+
+def test_slab_generator_equals_slices_of_the_sorted_set():
+    """config 4's per-rank slabs are slices of ONE sorted set (igd_synth_queries_slab == make_queries[lo:hi])"""
+    from igd_amd import synth
+    from igd_amd.dist import shard_bounds
+    n = 300000
+    whole = synth.make_queries(n, seed=7, genome=synth.HG38, sorted_=True)
+    for world in (2, 3, 8):
+        for r in range(world):
+            lo, hi = shard_bounds(n, world, r)
+            part = synth.make_queries_slab(n, lo, hi, seed=7, genome=synth.HG38)
+            assert all(np.array_equal(a[lo:hi], b) for a, b in zip(whole, part)), (world, r)

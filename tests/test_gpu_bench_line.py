@@ -32,8 +32,61 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         r = j["roofline"]
         assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["achieved"] > 0
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and "traffic" in r
+        # the fraction prices the kernel time against bytes computed IN THE RUN, and is a fraction
+        assert 0 < r["frac"] <= 1.0 and r["bytes_per_launch"] == r["bytes_breakdown"]["total"] > 0
+        assert abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+        assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
+        x = j["extra_configs"]
+        assert len(x) == 4 and not any("error" in e for e in x), x
+        assert all(e["value"] > 0 for e in x) and x[3]["roofline"]["bound"] == "pcie-d2h" and x[3]["overlaps"] > 0
         c = j["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
         assert c["totals_match_gpu"] is True
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _two_rank_expected(d, files, per_file, q):
+    """hits of the whole 2 x q position-sorted set through Database.search on one GPU"""
+    import numpy as np
+    from igd_amd import Database, synth
+    db = Database(os.path.join(d, "rm%dx%d.igd" % (files, per_file)))
+    ichr, qs, qe = synth.make_queries(2 * q, seed=7, genome=synth.HG38, sorted_=True)
+    hits, total = db.search(ichr, qs, qe)
+    db.close()
+    w = (hits.astype(np.uint64) * (np.arange(len(hits), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1)
+    return int(total), int(w)
+
+
+@pytest.mark.parametrize("launcher", ["self-spawn", "torchrun"])
+def test_bench_two_ranks_config4_slabs_and_allreduce(launcher):
+    """N > 1: `bench.py --gpus 2` starts two ranks (by itself, or under torch.distributed.run as the driver does),
+    each takes its contiguous slab of ONE sorted query set, and the all-reduced hits[] equals the unsharded search.
+    Both ranks share GPU 0 here (IGD_BENCH_ONE_GPU) and the collective runs over gloo -- the box has one GPU."""
+    d = short_tmpdir("igb")
+    try:
+        files, per_file, q = 40, 3000, 15000
+        env = dict(os.environ, IGD_BENCH_ONE_GPU="1", IGD_DIST_BACKEND="gloo")
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", str(files), "--per-file", str(per_file),
+                "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d]
+        if launcher == "self-spawn":
+            cmd = [sys.executable] + tail
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300)] + tail
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, p.stdout.decode()[-800:]
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
+        assert "config 4" in j["config"]["workload"] and "all-reduce" in j["config"]["collective"]
+        assert j["config"]["queries_per_gpu"] == q and j["config"]["queries_per_step_all_gpus"] == 2 * q
+        assert abs(j["value"] - 2 * q * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
+        assert 0 < j["roofline"]["frac"] <= 1.0
+        total, chk = _two_rank_expected(d, files, per_file, q)
+        assert j["hits_per_step_total"] == total and j["hits_checksum"] == chk
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -86,6 +86,64 @@ def test_enumeration_histogram_equals_counts(big):
     o.close()
 
 
+def test_config5_enumeration_of_all_queries_streamed_equals_counts_and_whole_array(big):
+    """BASELINE config 5 at its stated size: -f on ALL 10^6 queries.  The streamed chunks (igd_hip_enumerate_stream)
+    cover every query once, in order; their histogram over dataset index is the counted hits[] vector; and
+    the concatenation equals what the one-array API (igd_hip_enumerate) returns."""
+    db, path, (ichr, qs, qe) = big
+    hits, tot = db.search(ichr, qs, qe)
+    hist = np.zeros(db.nfiles, np.int64)
+    seen = {"q": 0, "n": 0, "chunks": 0, "crc": 0}
+
+    def on_chunk(q0, q1, qoff, rec):
+        assert q0 == seen["q"] and q1 > q0 and len(rec) == qoff[q1] - qoff[q0] and qoff[q0] == seen["n"]
+        hist[:] += np.bincount(rec[:, 1], minlength=db.nfiles)
+        np.testing.assert_array_equal(rec[:, 0], np.repeat(np.arange(q0, q1), np.diff(qoff[q0:q1 + 1])))
+        assert (rec[:, 2] < qe[rec[:, 0]]).all() and (rec[:, 3] > qs[rec[:, 0]]).all()
+        seen["crc"] = (seen["crc"] * 31 + int(rec.astype(np.int64).sum())) & 0xFFFFFFFFFFFF
+        seen["q"], seen["n"], seen["chunks"] = q1, seen["n"] + len(rec), seen["chunks"] + 1
+
+    qoff, total = db.enumerate_stream(ichr, qs, qe, on_chunk)
+    assert seen["q"] == Q and seen["n"] == total == tot == qoff[-1] and seen["chunks"] >= 5
+    np.testing.assert_array_equal(hist, hits)
+    qoff2, rec = db.enumerate(ichr, qs, qe)
+    np.testing.assert_array_equal(qoff2, qoff)
+    crc, qa, nch = 0, 0, 0
+    while qa < Q:                                   # same chunking rule: longest query range within 4 Mi overlaps
+        qb = max(qa + 1, int(np.searchsorted(qoff, qoff[qa] + (4 << 20), side="right")) - 1)
+        crc = (crc * 31 + int(rec[qoff[qa]:qoff[qb]].astype(np.int64).sum())) & 0xFFFFFFFFFFFF
+        qa, nch = qb, nch + 1
+    assert nch == seen["chunks"] and crc == seen["crc"]
+
+
+def test_config5_cli_f_on_all_queries_is_byte_identical_to_the_reference(big):
+    """`bin/igd search db -q 10^6.bed -f` (1.2 GB of text, streamed chunk by chunk) against the real reference
+    binary's stdout: same bytes (md5 + length), when oracle/_ref/igd travelled; otherwise against the oracle CLI."""
+    import hashlib
+    from helpers import ORACLE_BIN
+    from igd_amd import synth
+    db, path, (ichr, qs, qe) = big
+    bed = os.path.join(DIR, "t_q.bed")
+    if not os.path.exists(bed):
+        synth.write_bed(bed, synth.HG38, ichr, qs, qe)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def digest(exe):
+        p = subprocess.Popen([exe, "search", path, "-q", bed, "-f"], stdout=subprocess.PIPE)
+        h, n = hashlib.md5(), 0
+        while True:
+            b = p.stdout.read(1 << 24)
+            if not b:
+                break
+            h.update(b)
+            n += len(b)
+        assert p.wait() == 0
+        return h.hexdigest(), n
+    mine = digest(os.path.join(root, "bin", "igd"))
+    theirs = digest(REF_BIN if have_ref() else ORACLE_BIN)
+    assert mine == theirs and mine[1] > 1e9
+
+
 def test_work_statistics_equal_oracle(big):
     import torch
     db, path, (ichr, qs, qe) = big

@@ -203,6 +203,51 @@ def test_compact_image_edges(nbp_log, wide_values, workdir):
         orc.close()
 
 
+def test_a_broken_promise_among_several_async_batches_is_not_lost(workdir):
+    """Several IGD_HIP_FLAG_SORTED batches enqueued before ONE igd_hip_sync (what bench.py does): if ANY of
+    them was unordered the sync reports it -- also when a later batch was ordered again -- and that batch
+    added nothing; after the report the slate is clean."""
+    import torch
+    from igd_amd import Database
+    from igd_amd.database import IgdError
+    rng = random.Random(77)
+    nbp = 1 << 12
+    path, ctgs, span = _random_db(rng, workdir, "stick", nbp, 1, 9, 3, 30, 80, 20)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, [0, 1, 2], nbp, span, 4000)
+        si, ss, se = _sorted(ichr, qs, qe)
+        want = orc.search(si, ss, se, 0)[0]
+        dev = torch.device("cuda", 0)
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            good = [torch.from_numpy(x).to(dev) for x in (si, ss, se)]
+            bad = [torch.from_numpy(x).to(dev) for x in (ichr, qs, qe)]
+            hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+            for order in (("good", "bad", "good"), ("bad", "good", "good"), ("good", "good", "bad")):
+                hits.zero_()
+                stream.synchronize()
+                for which in order:
+                    t = good if which == "good" else bad
+                    db.search_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(si), hits.data_ptr(), None,
+                                  v=0, stream=stream.cuda_stream, flags=FLAG_SORTED)
+                with pytest.raises(IgdError):
+                    db.sync(stream.cuda_stream)
+                np.testing.assert_array_equal(hits.cpu().numpy(), 2 * want)     # the two ordered batches only
+                # reported once: the next sync, and a following all-ordered job, are clean
+                db.sync(stream.cuda_stream)
+                hits.zero_()
+                for _ in range(2):
+                    db.search_dev(good[0].data_ptr(), good[1].data_ptr(), good[2].data_ptr(), len(si), hits.data_ptr(), None,
+                                  v=0, stream=stream.cuda_stream, flags=FLAG_SORTED)
+                db.sync(stream.cuda_stream)
+                np.testing.assert_array_equal(hits.cpu().numpy(), 2 * want)
+    finally:
+        db.close()
+        orc.close()
+
+
 def test_blocking_api_repairs_a_wrong_order_promise(workdir):
     """igd_hip_search_ex(..., IGD_HIP_FLAG_SORTED) on UNSORTED host arrays: the device reports the
     broken promise, the call repeats the slice in auto mode -- counts are right, never doubled."""

@@ -120,6 +120,45 @@ def test_enumerate_matches_oracle(case, workdir):
         orc.close()
 
 
+@pytest.mark.parametrize("chunk_hits", [64, 1000, 50000])
+def test_streamed_enumeration_in_small_chunks_matches_oracle(chunk_hits, workdir, monkeypatch):
+    """igd_hip_enumerate_stream with chunk buffers far smaller than the result (IGD_ENUM_CHUNK_HITS): the chunks
+    tile the query range in order, a query is never split (a query larger than the buffer makes the engine grow
+    it), zero-overlap queries are covered too, and the concatenation is the oracle's enumeration; the one-array
+    API on the same handle agrees."""
+    from igd_amd import Database
+    monkeypatch.setenv("IGD_ENUM_CHUNK_HITS", str(chunk_hits))
+    rng = random.Random(4242 + chunk_hits)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[3]
+    path, ctgs, span = _random_db(rng, workdir, "es%d" % chunk_hits, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, list(range(nctg)) + [-1], nbp, span, 3000)
+        wqoff, wrec = orc.enumerate(ichr, qs, qe)
+        parts, ranges = [], []
+
+        def on_chunk(q0, q1, qoff, rec):
+            ranges.append((q0, q1))
+            parts.append(rec.copy())
+            assert len(rec) == wqoff[q1] - wqoff[q0]
+
+        gqoff, total = db.enumerate_stream(ichr, qs, qe, on_chunk)
+        np.testing.assert_array_equal(gqoff, wqoff)
+        assert total == wqoff[-1]
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(qs) and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        assert len(ranges) > 3
+        grec = np.concatenate(parts) if parts else np.zeros((0, 4), np.int32)
+        np.testing.assert_array_equal(grec[:, 1:], wrec)
+        np.testing.assert_array_equal(grec[:, 0], np.repeat(np.arange(len(qs)), np.diff(wqoff)))
+        q2, r2 = db.enumerate(ichr, qs, qe)
+        np.testing.assert_array_equal(q2, wqoff)
+        np.testing.assert_array_equal(r2, grec)
+    finally:
+        db.close()
+        orc.close()
+
+
 def test_accumulates_into_caller_hits(workdir):
     """hits is caller-zeroed and ADDED to (src/igd_search.c:491): two calls sum up."""
     from igd_amd import Database

@@ -9,6 +9,7 @@ import random
 import re
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -195,6 +196,7 @@ def _declared_functions(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     txt = re.sub(r"#ifdef IGDR_HAVE_R.*?#endif", "", txt, flags=re.S)   # .Call group needs R headers
+    txt = re.sub(r"^\s*typedef\s[^;{]*\(\s*\*[^;]*;", "", txt, flags=re.M)   # function-pointer typedefs are not functions
     names = re.findall(r"^\s*(?:[A-Za-z_][\w\s\*]*?[\s\*])([A-Za-z_]\w*)\s*\([^;{]*\)\s*;", txt, flags=re.M)
     return sorted(set(n for n in names if n not in ("defined",)))
 
@@ -235,6 +237,47 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback(N):
     # ... and the package never imports the oracle
     src = "".join(open(os.path.join(ROOT, "igd_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "igd_amd")) if f.endswith(".py"))
     assert "oracle" not in src.lower().replace("no cpu", "")
+
+
+def test_libraries_never_end_the_host_process(N):
+    """libigd.so / libigd_py.so / libigdr.so inside an interpreter (ctypes here, Cython / R in real life): an
+    unusable engine -- no GPU on this host, or IGD_DEVICE out of range on a GPU box -- must NOT exit() the
+    process: the call returns like the reference's silent failures, hits stay untouched, igd_engine_status() != 0
+    (the reference returns silently at src/igd_search.c:457,462,701-702)."""
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from igd_amd import _native as N
+from igd_amd import igd_py as P
+db, q = %r, %r
+if N.hip().igd_hip_device_count() > 0:
+    os.environ["IGD_DEVICE"] = "99"
+# handle flavour through the ctypes twin of the .pyx class: raises, interpreter alive
+h = P.igd_py()
+try:
+    h.open(db); print("NO-RAISE")
+except P.IgdEngineError as e:
+    print("py raised:", "no CPU search path" in str(e))
+hits = np.zeros(8, np.int64)
+assert h.search_n(q, hits) == 0 and not hits.any() and h.get_nFiles() == 0   # handle stayed closed
+# R flavour (.C entry points)
+R = N.rabi()
+assert R.open_iGD(db.encode()) is None and R.igd_engine_status() != 0
+hits[:] = 0
+a, b = C.c_char_p(db.encode()), C.c_char_p(q.encode())
+R.getOverlaps(C.byref(a), C.byref(b), hits.ctypes.data_as(N.i64p)); assert not hits.any()
+# CLI flavour as a library
+L = N.cli()
+g = L.get_igdinfo(db.encode()); assert g
+L.getOverlaps.argtypes = [C.c_char_p, N.i64p]; L.getOverlaps.restype = C.c_int64
+assert L.getOverlaps(q.encode(), hits.ctypes.data_as(N.i64p)) == 0 and not hits.any() and L.igd_engine_status() != 0
+print("alive")
+''' % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "edge", "db.igd"), os.path.join(GOLDEN, "edge", "q.bed"))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "py raised: True" in out and out.strip().endswith("alive"), (out, p.stderr.decode()[-1500:])
+    assert b"no CPU search path" in p.stderr
 
 
 def test_create_without_gpu_fails_loudly_and_leaves_no_database(N):

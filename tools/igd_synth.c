@@ -212,6 +212,65 @@ int64_t igd_synth_queries(int64_t n, uint64_t seed, int genome, int32_t minLen, 
     return n;
 }
 
+/* Positions [lo, hi) of the SORTED query set igd_synth_queries(n, seed, ..., sorted=1) would return,
+ * without materialising the other n - (hi - lo) queries: BASELINE config 4 gives GPU r the r-th contiguous
+ * slab of one position-sorted set of 10^8 queries.  Two generation passes (the generator is counter-based):
+ * a histogram over the top bits of the sort key finds the key range that holds the slab, the second pass
+ * keeps only queries in that range, which are then sorted exactly like the whole set (stable radix sort,
+ * generation order among equal keys).  Returns hi - lo, or -1. */
+int64_t igd_synth_queries_slab(int64_t n, uint64_t seed, int genome, int32_t minLen, int32_t maxLen,
+                               int64_t lo, int64_t hi, int32_t *ichr, int32_t *qs, int32_t *qe)
+{
+    if (lo < 0 || hi > n || lo > hi) return -1;
+    if (lo == hi) return 0;
+    genome_t g; genome_init(&g, genome);
+    const int SH = 16;                                     /* bucket = key >> 16: (contig+1) << 16 | start >> 16 */
+    const int64_t nb = ((int64_t)(g.n + 1) << 16) + 1;
+    int64_t *hist = (int64_t *)calloc((size_t)nb + 1, sizeof(int64_t));
+    if (!hist) return -1;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t b = (uint64_t)i * 4;
+        const int c = pick_contig(&g, mix64(seed, b));
+        const int32_t L = minLen + (int32_t)below(mix64(seed, b + 1), (int64_t)maxLen - minLen + 1);
+        const int64_t s = below(mix64(seed, b + 2), g.len[c] - L);
+        const uint64_t key = ((uint64_t)(uint8_t)(c + 1) << 32) | (uint32_t)s;
+        hist[key >> SH]++;
+    }
+    int64_t b0 = 0, before = 0, run = 0;                   /* first bucket that reaches position lo */
+    while (b0 < nb && run + hist[b0] <= lo) run += hist[b0++];
+    before = run;
+    int64_t b1 = b0;                                       /* last bucket needed for position hi-1 */
+    while (b1 < nb && run + hist[b1] < hi) run += hist[b1++];
+    int64_t m = 0;
+    for (int64_t b = b0; b <= b1 && b < nb; b++) m += hist[b];
+    free(hist);
+    uint64_t *key = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(m ? m : 1));
+    int32_t *end = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m ? m : 1));
+    if (!key || !end) { free(key); free(end); return -1; }
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t b = (uint64_t)i * 4;
+        const int c = pick_contig(&g, mix64(seed, b));
+        const uint64_t kc = (uint64_t)(uint8_t)(c + 1) << 32;
+        if ((int64_t)((kc | 0xFFFFFFFFull) >> SH) < b0 || (int64_t)(kc >> SH) > b1) continue;   /* contig outside the range */
+        const int32_t L = minLen + (int32_t)below(mix64(seed, b + 1), (int64_t)maxLen - minLen + 1);
+        const int64_t s = below(mix64(seed, b + 2), g.len[c] - L);
+        const uint64_t ky = kc | (uint32_t)s;
+        const int64_t bk = (int64_t)(ky >> SH);
+        if (bk < b0 || bk > b1) continue;
+        key[k] = ky; end[k] = (int32_t)(s + L); k++;
+    }
+    radix_sort_keys(key, end, k);
+    for (int64_t i = lo; i < hi; i++) {
+        const int64_t j = i - before;
+        ichr[i - lo] = (int32_t)(key[j] >> 32) - 1;
+        qs[i - lo] = (int32_t)(uint32_t)key[j];
+        qe[i - lo] = end[j];
+    }
+    free(key); free(end);
+    return hi - lo;
+}
+
 int igd_synth_write_bed(const char *path, int genome, int64_t n, const int32_t *ichr,
                         const int32_t *qs, const int32_t *qe)
 {
