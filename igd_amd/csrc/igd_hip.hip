@@ -73,7 +73,7 @@
 #ifndef IGD_REDUCE_GROUPS
 #define IGD_REDUCE_GROUPS 128
 #endif
-#define IGD_LDS_HITS_MAX_BYTES (128 * 1024)
+#define IGD_LDS_HITS_MAX_BYTES (120 * 1024)   // + 37 KiB of rank-method areas (igd_scan_sorted) stays below 160 KiB
 
 typedef unsigned long long u64;
 
@@ -83,6 +83,20 @@ typedef unsigned long long u64;
 #endif
 #ifndef IGD_EXP_NOMATCH
 #define IGD_EXP_NOMATCH 0     // measurement only: load everything, compare nothing (wrong results)
+#endif
+
+#ifndef IGD_EXP
+#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 32 time stamps
+#endif
+#ifndef IGD_OPT_PRIO
+#define IGD_OPT_PRIO 1 // igd_scan_sorted: waves lower their issue priority as they get through their share
+#endif
+#ifndef IGD_OPT_CNT32
+#define IGD_OPT_CNT32 1 // igd_scan_sorted: 32-bit LDS counters when the host can bound them
+#endif
+#if IGD_EXP & 32
+static u64 *g_stamps = nullptr;     // diagnostic build: s_memtime stamps of the last igd_scan_sorted launch
+static int g_stampWaves = 0;
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -119,18 +133,18 @@ extern "C" int64_t igd_hip_max_batch(void) { return IGD_MAX_BATCH; }
 
 // ------------------------------------------------------------------------------------------
 // device view of one database (passed to kernels by value)
-// One unit of scan work: a chunk of <= IGD_CHUNK records of one tile (32 bytes, one s_load_dwordx8).
+// One unit of scan work: a chunk of <= IGD_CHUNK records of one tile (48 bytes, three dwordx4 loads).
 // Every tile has at least one unit; an empty tile gets a placeholder with n == 0 so that the
 // long queries that START in it still have an owner in the sorted path.
-struct __attribute__((aligned(32))) Unit {
+struct __attribute__((aligned(16))) Unit {
     int64_t off;      // index of the unit's first record in the SoA arrays
     int32_t tile;     // global tile id
     int32_t n;        // records in this unit
-    int32_t mx01;     // compact image: largest e' of slot 0 | of slot 1 << 16   (k_pack_units;
     int32_t jf;       // (j << 4) | flags; j = tile index inside its contig;
                       // flag bit 0: first unit of its tile; bit k (1..3): tile j-k of the contig is EMPTY
-    int32_t mx23;     //                slots 2, 3                                    a slot is 64
-    int32_t mx45;     //                slots 4, 5                                    consecutive records)
+    uint32_t W[6];    // compact image: summary word of each 64-record slot (k_pack_units): the component-wise
+                      // maximum of the slot's record words = (65535 - smallest s') | largest e' << 16
+    int32_t pad;
 };
 #define UNIT_J(u) ((u).jf >> 4)
 #define UNIT_FLAGS(u) ((u).jf & 15)
@@ -169,7 +183,11 @@ struct igd_hip_db {
     int32_t nUnits;
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
-    int32_t *d_qw;                // [wsQueries] per-query tile word of the merge join (k_query_bounds)
+    int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
+    int32_t *d_qw1;               // [wsQueries] later-tile word (compact image only)
+    int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
+    int ldsSorted;                // dynamic LDS of igd_scan_sorted: counters + the waves' rank-method areas
+    int32_t maxTileCnt;           // records of the fullest tile
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
     int32_t *d_spBase;            // pairs per coarse bucket
@@ -281,6 +299,7 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 //   ctl[8 + (epoch & 1)] = gap-fill budget spent by k_query_bounds (units of 256 tiles)
 #define CTL_UNSORTED 1
 #define CTL_BROKEN 2
+#define CTL_NOTSTART 3   // epoch of the last batch whose queries were ordered by tile but NOT by start inside a tile
 #define CTL_NLONG 4
 #define CTL_NFIX 6
 #define CTL_BUDGET 8
@@ -304,13 +323,40 @@ __device__ __forceinline__ int tile_key(const DbView &db, int c, int qs)
     return db.ctgBase[c] + n1;
 }
 
+// The compact query word of k_pack_units' image (defined here because k_query_bounds writes it):
+//     (65536 - qe') | qs' << 16   with   qe' = min(qe - T, W) + 1,   qs' = first ? max(qs - T + 1, 1) : 1
+// A record word matches when both of its 16-bit halves are >= the query's.
+__device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int W)
+{
+    int qe2 = qe - T;
+    qe2 = (qe2 < W ? qe2 : W) + 1;                       // s' < qe2   <=> start < qe
+    int qs2 = first ? qs - T + 1 : 1;                    // e' >= qs2  <=> end > qs   (e' >= 1 always)
+    if (qs2 < 1) qs2 = 1;
+    return (int)((unsigned)(65536 - qe2) | ((unsigned)qs2 << 16));
+}
+#define IGD_NEVER 0xFFFFFFFFu     // a query word no record word can match (e' <= W <= 32768 < 65535)
+
+// What k_query_bounds leaves per query for the merge join (sorted path):
+//   compact image (packed != 0):
+//     qw0[i] = ~(query word for the query's FIRST tile), or ~IGD_NEVER = 0 when the query does not take part
+//              there (unknown contig, first tile out of range, rule NEST with an empty first tile, or the one case
+//              the image cannot express, listed as WALK_FIRST).  Stored inverted so that a bounds-checked
+//              buffer load past a tile's last query (which returns 0) reads as "never matches".
+//     qw1[i] = 0 unless the query also covers LATER tiles; then  min(qe - T0, 4W)  [bits 0..19]
+//              | min(span, 3) << 20 | (first global tile & 3) << 22 | 1 << 24:  all a later tile needs
+//              (there, qs' = 1 and qe' = min(qeRel - k W, W) + 1; k = (tile - first tile) follows from 2 bits).
+//     spill[t] = epoch for every tile t that some query covers as a later tile (k = 1..3): most units have
+//              none and never look at the queries of the tiles before theirs.
+//   exact arrays (packed == 0):
+//     qw0[i] = (global number of the first tile) << 4 | min(n2 - n1, 15), -1 when it visits nothing.
 __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
                                                       int packed, int32_t *__restrict__ firstQ,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
-                                                      int32_t *__restrict__ qw, int promised)
+                                                      int32_t *__restrict__ qw0, int32_t *__restrict__ qw1,
+                                                      int32_t *__restrict__ spill, int promised)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST
@@ -322,24 +368,25 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
-    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
+    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.  A plain
+    // (L1-cached, possibly stale) load on purpose: this is only a shortcut, and a device-scope load of ONE
+    // address by every wave of the grid queues up at a single L2 channel (128 us for 1.25e7 queries).
+    if (__builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) == epoch) return;
     int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
     int val = i;
     if (i < nq) {
         const int c = ichr[i], s0 = qs[i];
         const int k = tile_key(db, c, s0);
-        const int prev = i ? tile_key(db, ichr[i - 1], qs[i - 1]) : -1;
+        int prev = -1, prevS = INT_MIN;
+        if (i) { prevS = qs[i - 1]; prev = tile_key(db, ichr[i - 1], prevS); }
         if (k < prev) {
             ctl[CTL_UNSORTED] = epoch;
             if (promised) ctl[CTL_BROKEN] = epoch;          // sticky until the next igd_hip_sync (any promised batch since)
         }
+        // ordered by tile but not by start inside a tile: the merge join still holds, the rank method does not
+        if (k == prev && s0 < prevS) ctl[CTL_NOTSTART] = epoch;
         lo = prev + 1; hi = k;
-        // The scan kernel's view of the query: (global number of its first tile) << 4 | min(n2 - n1, 15),
-        // -1 when it visits nothing (unknown contig, tile out of range) -- so that the scan does not
-        // redo the two divisions for every unit that looks at the query.
-        int word = -1;
-        // what the scan kernel leaves to k_exact_walk
+        int w0 = packed ? 0 : -1, w1 = 0;
         if (c >= 0 && c < db.nCtg) {
             const int n1 = tile_of(db, s0);
             const int mT = db.ctgNTile[c] - 1;
@@ -348,13 +395,27 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                 int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
                 if (n2 > mT) n2 = mT;
                 const int span = n2 > n1 ? n2 - n1 : 0;
-                word = ((db.ctgBase[c] + n1) << 4) | (span < 15 ? span : 15);
+                const int g0 = db.ctgBase[c] + n1;
+                const int T0 = (int)((unsigned)n1 * (unsigned)db.nbp);
+                // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
                 if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
-                if (packed && e0 <= (int)((unsigned)n1 * (unsigned)db.nbp))
-                    fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
+                const bool needExact = packed && e0 <= T0;
+                if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
+                if (!packed) w0 = (g0 << 4) | (span < 15 ? span : 15);
+                else if (rule != IGD_HIP_RULE_NEST || db.tileCnt[g0] > 0) {   // rule NEST: an empty first tile ends the query (:468)
+                    if (!needExact) w0 = ~query_word(s0, e0, true, T0, db.nbp);
+                    if (span > 0) {
+                        const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
+                        int rel = e0 - T0;                  // > W here, since the query reaches the next tile
+                        if (rel > 4 * db.nbp) rel = 4 * db.nbp;
+                        w1 = rel | (sp << 20) | ((g0 & 3) << 22) | (1 << 24);
+                        for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
+                    }
+                }
             }
         }
-        qw[i] = word;
+        qw0[i] = w0;
+        if (packed) qw1[i] = w1;
     }
     // short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
     // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
@@ -362,8 +423,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
     // A wave that sees disorder among its own queries, or finds the batch already marked, fills
     // nothing: firstQ[] is not going to be used.
-    const bool disorder = __ballot(lo > hi + 1) != 0 ||
-                          __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+    const bool disorder = __ballot(lo > hi + 1) != 0 || ctl[CTL_UNSORTED] == epoch;
     const bool big = hi - lo >= 8;
     if (!big && !disorder) for (int t = lo; t <= hi; t++) firstQ[t] = val;
     unsigned long long m = disorder ? 0ull : __ballot(big);
@@ -742,7 +802,8 @@ __global__ void k_scatter_pairs(DbView db, const int32_t *__restrict__ ichr,
 // component-wise maximum of a slot's words, (65535 - min s') | max e' << 16, passes the query
 // test exactly when SOME word in the slot COULD pass it, so a query whose word fails against the
 // summary skips the slot.  The low half is read from the slot's first record (the tile is sorted by
-// start); the high halves are stored in the unit descriptor (mx01, mx23, mx45).
+// start); the whole summary word of every slot is kept in the unit descriptor (Unit::W), so the scan
+// kernel can prune a unit's queries before -- or without -- waiting for the unit's records.
 __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict__ unitsOut, uint32_t *__restrict__ pse,
                                                     uint16_t *__restrict__ px, uint32_t *__restrict__ pv,
                                                     int32_t *__restrict__ flag /* bit 0: a value needs > 16 bits; bit 1: malformed tile */)
@@ -754,10 +815,10 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict_
     for (int ui = gw; ui < db.nUnits; ui += nw) {
         const Unit u = unitsOut[ui];
         const int T = (int)((unsigned)UNIT_J(u) * (unsigned)db.nbp);
-        unsigned mx[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        unsigned mx[6] = {0u, 0u, 0u, 0u, 0u, 0u};        // summary words of the unit's slots
         for (int i0 = 0; i0 < u.n; i0 += IGD_WAVE) {
             const int i = i0 + lane;
-            unsigned edv = 0u;
+            unsigned edv = 0u, spv = 65535u;
             if (i < u.n) {
             const int64_t r = u.off + i;
             const int st = db.start[r], en = db.end[r];
@@ -766,6 +827,7 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict_
             if (ed > db.nbp) ed = db.nbp;
             if (ed < 1) ed = 1;
             edv = (unsigned)ed;
+            spv = sp;
             pse[r] = (65535u - sp) | ((unsigned)ed << 16);
             px[r] = (uint16_t)db.idx[r];
             if (pv) {
@@ -780,13 +842,11 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict_
                 const unsigned y = (unsigned)__shfl_xor((int)edv, o);
                 edv = y > edv ? y : edv;
             }
-            if (i0 / IGD_WAVE < 6) mx[i0 / IGD_WAVE] = edv;
+            const unsigned s0 = (unsigned)__shfl((int)spv, 0);      // the tile is sorted by start: the slot's first record has its smallest s'
+            if (i0 / IGD_WAVE < 6) mx[i0 / IGD_WAVE] = (65535u - s0) | (edv << 16);
         }
-        if (lane == 0) {
-            unitsOut[ui].mx01 = (int)(mx[0] | mx[1] << 16);
-            unitsOut[ui].mx23 = (int)(mx[2] | mx[3] << 16);
-            unitsOut[ui].mx45 = (int)(mx[4] | mx[5] << 16);
-        }
+        if (lane == 0)
+            for (int r = 0; r < 6; r++) unitsOut[ui].W[r] = mx[r];
     }
     if (wide) atomicOr(flag, wide);
 }
@@ -818,13 +878,14 @@ struct Raw {
 };
 
 // A Unit held one-per-lane in VGPRs, and its wave-uniform broadcast.
-struct UnitRegs { int32_t offLo, offHi, tile, n, mx01, jf, mx23, mx45; };
+struct UnitRegs { int32_t offLo, offHi, tile, n, jf, w[6]; };
 __device__ __forceinline__ UnitRegs load_unit_regs(const Unit *p)
 {
-    const int4 a = ((const int4 *)p)[0], b = ((const int4 *)p)[1];
+    const int4 a = ((const int4 *)p)[0], b = ((const int4 *)p)[1], c = ((const int4 *)p)[2];
     UnitRegs r;
     r.offLo = a.x; r.offHi = a.y; r.tile = a.z; r.n = a.w;
-    r.mx01 = b.x; r.jf = b.y; r.mx23 = b.z; r.mx45 = b.w;
+    r.jf = b.x; r.w[0] = b.y; r.w[1] = b.z; r.w[2] = b.w;
+    r.w[3] = c.x; r.w[4] = c.y; r.w[5] = c.z;
     return r;
 }
 
@@ -928,14 +989,6 @@ __device__ __forceinline__ void issue_unit(const DbView &db, const ScanArgs &a, 
 // No scalar-ALU work is needed per record slot, which matters: a CU has a single scalar unit.
 typedef unsigned short igd_u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int W)
-{
-    int qe2 = qe - T;
-    qe2 = (qe2 < W ? qe2 : W) + 1;                       // s' < qe2   <=> start < qe
-    int qs2 = first ? qs - T + 1 : 1;                    // e' >= qs2  <=> end > qs   (e' >= 1 always)
-    if (qs2 < 1) qs2 = 1;
-    return (int)((unsigned)(65536 - qe2) | ((unsigned)qs2 << 16));
-}
 
 // one query against the unit's slots: cnt[r] += hit   (no branches, no exec masking, no LDS)
 template <bool USE_V, bool PACKED>
@@ -1016,14 +1069,8 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
     // slot summaries (see k_pack_units): the largest word a record of the slot could have
     uint32_t W[IGD_SLOTS];
     if (PACKED) {
-        const uint32_t m01 = (uint32_t)__builtin_amdgcn_readlane(L.mx01, kk), m23 = (uint32_t)__builtin_amdgcn_readlane(L.mx23, kk),
-                       m45 = (uint32_t)__builtin_amdgcn_readlane(L.mx45, kk);
 #pragma unroll
-        for (int r = 0; r < IGD_SLOTS; r++) {
-            const uint32_t mw = r < 2 ? m01 : r < 4 ? m23 : m45;
-            const uint32_t hi = (r & 1) ? (mw & 0xFFFF0000u) : (mw << 16);
-            W[r] = ((uint32_t)__builtin_amdgcn_readlane((int)R.a[r], 0) & 0xFFFFu) | hi;   // first record of the slot: smallest s'
-        }
+        for (int r = 0; r < IGD_SLOTS; r++) W[r] = (uint32_t)__builtin_amdgcn_readlane(L.w[r], kk);
     }
     int cnt[IGD_SLOTS];
 #pragma unroll
@@ -1187,6 +1234,449 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
         u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
         for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// igd_scan_sorted: the merge join over the compact image -- the dominant kernel of a position-sorted
+// batch.  Same unit / slot / summary scheme as igd_scan_tiles above, but fed by k_query_bounds'
+// per-query words, which take everything that depends on one QUERY out of the per-unit path:
+//   * the queries whose FIRST tile is the unit's tile are read as ready-made compare words (qw0, one
+//     bounds-checked buffer load per 64 of them); nothing is computed per candidate;
+//   * the queries of the up-to-3 tiles before it are looked at only if k_query_bounds marked the tile
+//     (spill[]: some query covers it as a later tile), 29 % of the units on the benchmark;
+//   * the visiting rule (NEST: an empty first tile ends the query) is already folded into the words.
+// Two ways to count a unit's overlaps, chosen per unit:
+//   pairwise  (few queries per tile): every query that passes a slot's summary word is broadcast and
+//             compared with the slot's 64 records: v_readlane, v_pk_max_u16, v_cmp, v_addc;
+//   rank      (>= IGD_DENSE_MIN first-tile queries): O((R + Q) log) instead of O(R Q).  For queries with
+//             qs <= qe a record is missed for exactly one of two reasons -- it starts at or after the
+//             query's end (A) or ends at or before its start (B) -- so per record
+//                 hits = #queries - #{q: qe' <= s'} - #{first-tile q: qs' > e'}.
+//             A: every query bisects the unit's sorted starts (staged in LDS) for p = #{records: s' < qe'}
+//                and adds 1 to a histogram at p; a prefix sum over the records gives #{q: p_q <= i};
+//             B: the first-tile queries of a tile are consecutive in the caller's array and ordered by
+//                start, so every record bisects q_qs[] for its own end.
+//             Queries that are inverted (qe < qs) or masked out (IGD_NEVER) would be counted twice or
+//             wrongly: they are taken out of both terms and compared pairwise.
+#ifndef IGD_DENSE_MIN
+#define IGD_DENSE_MIN 32
+#endif
+
+#define IGD_WLDS_S 512                                  // u16 entries per wave: the unit's sorted s' (+ sentinels)
+#define IGD_WLDS_H 328                                  // u32 entries per wave: histogram over record positions 0..320
+#define IGD_WLDS_BYTES (IGD_WLDS_S * 2 + IGD_WLDS_H * 4)
+
+struct SortArgs {
+    const int32_t *firstQ;       // [nT+1] first query of each tile
+    const int32_t *spill;        // [nT]   == epoch: some query covers the tile as a later tile
+    const int32_t *qw0, *qw1;    // per-query words (k_query_bounds)
+    const int32_t *q_qs;         // the caller's query starts (rank method, B term)
+    const int32_t *ctl;
+    int nq, v, epoch, mode;
+    u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
+    u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
+};
+
+// A unit's descriptor and query ranges, one unit per lane (broadcast with v_readlane when its turn comes)
+struct SRegs { int32_t offLo, offHi, n /* | (tile & 3) << 16 */, jf, w[IGD_SLOTS], f0, c0, cl; };
+
+struct Raw2 {
+    uint32_t a[IGD_SLOTS];       // s' | e' << 16 (inverted s', see k_pack_units)
+    int32_t x[IGD_SLOTS];        // idx (| value << 16)
+    int32_t q;                   // first 64 first-tile words (already un-inverted)
+    int32_t c0, cl, f0, nn;      // wave-uniform (SGPRs): the unit's query ranges and n | (tile & 3) << 16, kept from the issue
+};
+
+// Branch-free on purpose (see issue_unit): the same number of loads whatever the unit looks like, so that
+// the compiler counts them (s_waitcnt vmcnt(N)) and the next unit's loads stay in flight during a compare.
+// A unit nobody asks about (or kk past the wave's last unit) gets descriptors of size 0: no memory access.
+// Descriptors: the hardware range check covers voffset + soffset + immediate, so every array keeps ONE base for the
+// whole kernel (loop-invariant SGPRs) and a unit only moves soffset (= its first byte) and num_records (= its end):
+// two scalar instructions per array instead of a 64-bit address computation.  BIG = the image is beyond the 4 GiB a
+// 32-bit soffset reaches (> 2^30 records): per-unit base addresses, as igd_scan_tiles does.
+template <bool USE_V, bool BIG>
+__device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, const SRegs &L, int kk, bool valid, int lane, Raw2 &R)
+{
+    const int kq = kk & 63;
+    int c0 = __builtin_amdgcn_readlane(L.c0, kq), cl = __builtin_amdgcn_readlane(L.cl, kq);
+    if (!valid) { c0 = 0; cl = 0; }
+    const int f0 = __builtin_amdgcn_readlane(L.f0, kq);
+    const int nn = (c0 | cl) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
+    const int n = nn & 0xFFFF;
+    R.c0 = c0; R.cl = cl; R.f0 = f0; R.nn = nn;
+    const unsigned offLo = (unsigned)__builtin_amdgcn_readlane(L.offLo, kq);
+    const int vo4 = lane * 4, vo2 = lane * 2;
+    if (BIG) {
+        const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(L.offHi, kq) << 32) | offLo);
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pse + off), 0, n * 4, 0x00020000);
+        if (USE_V) {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + off), 0, n * 4, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4, r * 256, 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + off), 0, n * 2, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2, r * 128, 0);
+            }
+        }
+    } else {
+        const int end = (int)offLo + n;                   // < 2^30 records: byte offsets fit 32 bits
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, (int)((unsigned)end * 4u), 0x00020000);
+        if (USE_V) {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, (int)((unsigned)end * 4u), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, (int)((unsigned)end * 2u), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, (int)(offLo * 2u), 0);
+            }
+        }
+    }
+    // the first 64 first-tile words (no memory access when there are none); the later-tile words of the 29 % of the
+    // units that have any are loaded when their turn comes
+    const int b0 = c0 < IGD_WAVE ? c0 : IGD_WAVE;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, (f0 + b0) * 4, 0x00020000);
+    R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, vo4, f0 * 4, 0);             // past the last query: ~0 = IGD_NEVER
+}
+
+// The queries of one batch of <= 64 candidates (word `P0` per lane, IGD_NEVER where there is none) against the
+// unit: per slot, the summary word picks the queries that can hit it at all (one compare for all 64), and only
+// those are broadcast and compared.  cnt[r] += hit; no exec masking, no LDS.
+__device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS], const uint32_t (&W)[IGD_SLOTS], int P0)
+{
+    igd_u16x2 qv;
+    __builtin_memcpy(&qv, &P0, 4);
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        igd_u16x2 wv;
+        __builtin_memcpy(&wv, &W[r], 4);
+        const igd_u16x2 mw = __builtin_elementwise_max(wv, qv);
+        uint32_t mww;
+        __builtin_memcpy(&mww, &mw, 4);
+        unsigned long long m = __ballot(mww == W[r]);
+#if IGD_EXP & 2
+        asm volatile("" ::"v"(R.a[r]), "s"(m));
+        m = 0;
+#endif
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= ~(1ull << src);                         // s_bitset0_b64
+            const int q = __builtin_amdgcn_readlane(P0, src);
+            igd_u16x2 rec, qw;
+            __builtin_memcpy(&rec, &R.a[r], 4);
+            __builtin_memcpy(&qw, &q, 4);
+            const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);   // v_pk_max_u16
+            uint32_t mxw;
+            __builtin_memcpy(&mxw, &mx, 4);
+            cnt[r] += mxw == R.a[r] ? 1 : 0;             // both halves already >= the query's
+        }
+    }
+}
+
+// later-tile candidate word qw1 -> compare word for this tile (IGD_NEVER when the query does not reach it)
+__device__ __forceinline__ int later_word(const DbView &db, int q1, int g3, bool &covers)
+{
+    const int k = (g3 - ((q1 >> 22) & 3)) & 3;           // tiles between the query's first tile and this one (1..3)
+    covers = ((q1 >> 24) & 1) && k != 0 && ((q1 >> 20) & 3) >= k;
+    int rel = (q1 & 0xFFFFF) - __mul24(k, db.nbp);       // qe - T for this tile
+    rel = (rel < db.nbp ? rel : db.nbp) + 1;             // qe'
+    return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: row_shr 1,2,4,8, then row_bcast 15 and 31)
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// #{entries of the wave's sorted s' array that are < key}: 9 dependent LDS reads; entries past the unit's
+// records hold 65535 (> every key), so no bounds are needed
+__device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key)
+{
+    int pos = 0;
+#pragma unroll
+    for (int step = 256; step > 0; step >>= 1) pos += ((int)sl[pos + step - 1] < key) ? step : 0;
+    return pos;
+}
+
+template <bool USE_V, bool CNT32>
+__device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
+                                          u64 *hits, unsigned short *sl, unsigned int *hist, bool rankOK)
+{
+    const int c0 = R.c0, cl = R.cl;
+    if ((c0 | cl) == 0) return;                          // nobody asks about this unit
+    const int nn = R.nn;
+    const int un = nn & 0xFFFF, g3 = nn >> 16;
+    if (un == 0) return;                                 // placeholder of an empty tile
+    const int f0 = R.f0;
+    uint32_t W[IGD_SLOTS];
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) W[r] = (uint32_t)__builtin_amdgcn_readlane(L.w[r], kk);
+    int cnt[IGD_SLOTS];
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) cnt[r] = 0;
+    int nLater = 0;                                      // covering queries for which this is NOT the first tile
+    bool keep[IGD_SLOTS];                                // record passes the value filter (USE_V)
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        keep[r] = true;
+        if (USE_V) {
+            keep[r] = (R.x[r] >> 16) >= a.v;             // arithmetic shift: the signed 16-bit value
+            R.x[r] &= 0xFFFF;
+        }
+    }
+#if IGD_EXP & 4
+    {
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) asm volatile("" ::"v"(R.a[r]), "v"(R.x[r]));
+        asm volatile("" ::"v"(R.q));
+        return;
+    }
+#endif
+    if (!(rankOK && c0 >= IGD_DENSE_MIN)) {
+        // ---- pairwise ---------------------------------------------------------------------------
+        if (USE_V) {
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) if (!keep[r]) R.a[r] = 0u;    // the word nothing matches
+        }
+        for (int p = 0; p < c0; p += IGD_WAVE) {
+            int w = R.q;
+            if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
+            match_words(R, cnt, W, w);
+        }
+        for (int p = 0; p < cl; p += IGD_WAVE) {
+            const int q1 = (p + lane < cl) ? a.qw1[f0 - cl + p + lane] : 0;
+            bool covers;
+            const int w = later_word(db, q1, g3, covers);
+            nLater += __popcll(__ballot(covers));
+            match_words(R, cnt, W, w);
+        }
+        // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
+        // query, none of which may count them (the reference's tS skip, :510-511)
+        if (nLater != 0) {
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+        }
+    } else {
+        // ---- rank ---------------------------------------------------------------------------------
+        // a first-tile query misses the record at the front (term B) iff  qs > key,  key = e' + T - 1
+        const int Tm1 = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp) - 1;
+#define RANK_KEY(r) ((int)(R.a[r] >> 16) + Tm1)
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++)
+            sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
+        // term B first, with cnt[] as the bisection's position: #{first-tile q: qs > key} = c0 - #{qs <= key};
+        // q_qs[f0 .. f0+c0) is ordered (CTL_NOTSTART says when it is not)
+        {
+            int top = 1;
+            while (top <= c0) top <<= 1;                 // c0 < 2^31
+            for (int step = top >> 1; step > 0; step >>= 1) {
+                int vq[IGD_SLOTS];
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int at = cnt[r] + step - 1;
+                    vq[r] = at < c0 ? a.q_qs[f0 + at] : INT_MAX;
+                }
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] += vq[r] <= RANK_KEY(r) ? step : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0;   // = -(term B)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int nFirst = 0;
+        for (int p = 0; p < c0; p += IGD_WAVE) {
+            int w = R.q;
+            if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
+            const bool there = p + lane < c0;
+            const int qe2 = 65536 - (w & 0xFFFF), qs2 = (int)((unsigned)w >> 16);
+            const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;
+            const int pos = lds_lower_bound(sl, qe2);
+            if (good) atomicAdd(&hist[pos], 1u);
+            nFirst += __popcll(__ballot(good));
+            // the exceptions: in the range (so the bisection of q_qs[] above counted them) but not in the sums
+            unsigned long long x = __ballot(there && !good);
+            if (x) {
+                const int qsx = there ? a.q_qs[f0 + p + lane] : 0;
+                while (x) {
+                    const int src = __builtin_ctzll(x);
+                    x &= ~(1ull << src);
+                    const int s_ = __builtin_amdgcn_readlane(qsx, src), wq = __builtin_amdgcn_readlane(w, src);
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        igd_u16x2 rec, qw;
+                        __builtin_memcpy(&rec, &R.a[r], 4);
+                        __builtin_memcpy(&qw, &wq, 4);
+                        const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);
+                        uint32_t mxw;
+                        __builtin_memcpy(&mxw, &mx, 4);
+                        cnt[r] += (s_ > RANK_KEY(r) ? 1 : 0) + (mxw == R.a[r] ? 1 : 0);   // undo term B; an inverted query's own hits
+                    }
+                }
+            }
+        }
+        for (int p = 0; p < cl; p += IGD_WAVE) {
+            const int q1 = (p + lane < cl) ? a.qw1[f0 - cl + p + lane] : 0;
+            bool covers;
+            const int w = later_word(db, q1, g3, covers);
+            const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
+            if (covers) atomicAdd(&hist[pos], 1u);
+            nLater += __popcll(__ballot(covers));
+        }
+#undef RANK_KEY
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // term A: #{q: p_q <= i} = inclusive prefix sum of the histogram over the record positions
+        int carry = 0;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const int h = (int)hist[r * IGD_WAVE + lane];
+            hist[r * IGD_WAVE + lane] = 0u;
+            const int inc = wave_inclusive_sum(h);
+            const bool prefix = (R.a[r] & 0xFFFFu) == 0xFFFFu;   // starts before the tile: later-tile queries do not count it
+            cnt[r] += nFirst + (prefix ? 0 : nLater) - (carry + inc);
+            carry += __builtin_amdgcn_readlane(inc, 63);
+            if (r * IGD_WAVE + lane >= un || !keep[r]) cnt[r] = 0;   // no record here / fails the value filter
+        }
+        if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;  // p = 320: queries beyond every record of a full unit
+    }
+    // CNT32 (the host has bounded every counter of a launch below 2^32): one 32-bit LDS atomic per slot, for all
+    // lanes -- a lane without hits adds 0 (lanes past the unit: to counter 0), which costs LDS lanes but none of the
+    // compare / exec-mask instructions that skipping them would.  Otherwise: one 64-bit LDS (or global) atomic per
+    // record that was hit.
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) {
+        const int c = cnt[r];
+#if IGD_EXP & 1
+        asm volatile("" ::"v"(c), "v"(R.x[r]));
+        continue;
+#endif
+        if (CNT32) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)c);
+        else if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
+    }
+}
+
+// CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
+// reach 2^32); BIG: more than 2^30 records (see s_issue).
+template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG>
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, SortArgs a)
+{
+    if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;   // not ordered: the bucket path's batch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t hitBytes = LDS_HITS ? (((size_t)db.nFiles * (CNT32 ? 4 : 8) + 15) & ~(size_t)15) : 0;
+    u64 *hits = LDS_HITS ? (u64 *)smem : a.out;
+    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * IGD_WLDS_BYTES);
+    unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
+    for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
+    for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
+    if (LDS_HITS) {
+        if (CNT32) for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) ((unsigned int *)hits)[f] = 0u;
+        else for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
+        __syncthreads();
+    }
+    const bool rankOK = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NOTSTART]) != a.epoch;
+    const int wavesPerWG = IGD_WG / IGD_WAVE;
+    const int gwave = blockIdx.x * wavesPerWG + wid;
+    const int nwaves = gridDim.x * wavesPerWG;
+    Raw2 A, B;
+#if IGD_EXP & 32
+    const u64 t_start = __builtin_amdgcn_s_memtime();
+    u64 t_desc = 0, t_first = 0;
+#endif
+    // Issue slots go to the OLDEST wave of a SIMD first: left alone, the eight waves of a SIMD finish their equal
+    // shares one after the other (the first in 63 % of the last one's time, measured) and the SIMD runs ever emptier
+    // towards the end.  Every wave therefore lowers its own priority as it gets through its share -- a wave that is
+    // behind outranks one that is ahead -- and they finish together.
+    const int myUnits = (db.nUnits - gwave + nwaves - 1) / nwaves;
+    const int quarter = (myUnits + 3) >> 2;
+    int prioAt = quarter, prioLevel = 3, done = 0;
+#if IGD_OPT_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+
+    for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
+        SRegs L;
+        L.offLo = L.offHi = L.n = L.jf = L.f0 = L.c0 = L.cl = 0;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = 0;
+        {
+            const long long mi = (long long)ub + (long long)lane * nwaves;
+            if (mi < db.nUnits) {
+                const UnitRegs u = load_unit_regs(db.units + mi);
+                L.offLo = u.offLo; L.offHi = u.offHi; L.jf = u.jf;
+                L.n = u.n | ((u.tile & 3) << 16);
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = u.w[r];
+                if (u.n > 0) {
+                    const int lj = u.jf >> 4;
+                    const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+                    L.f0 = a.firstQ[u.tile];
+                    L.c0 = a.firstQ[u.tile + 1] - L.f0;
+                    if (a.spill[u.tile] == a.epoch) L.cl = L.f0 - a.firstQ[u.tile - lb];
+                }
+            }
+        }
+        int cntU = (int)(((long long)db.nUnits - ub + nwaves - 1) / nwaves);
+        if (cntU > IGD_WAVE) cntU = IGD_WAVE;
+#if IGD_EXP & 32
+        if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.cl)); t_desc = __builtin_amdgcn_s_memtime(); }
+#endif
+        s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
+        for (int kk = 0; kk < cntU; kk += 2) {
+            s_issue<USE_V, BIG>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
+#if IGD_EXP & 32
+            if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
+#endif
+            s_compute<USE_V, CNT32>(db, a, L, kk, lane, A, hits, sl, hist, rankOK);
+            s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32>(db, a, L, kk + 1, lane, B, hits, sl, hist, rankOK);
+#if IGD_OPT_PRIO
+            done += 2;
+            if (done >= prioAt) {
+                prioAt += quarter;
+                prioLevel--;
+                if (prioLevel == 2) __builtin_amdgcn_s_setprio(2);
+                else if (prioLevel == 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+        }
+    }
+#if IGD_EXP & 32
+    const u64 t_loop = __builtin_amdgcn_s_memtime();
+#endif
+    if (LDS_HITS) {
+        __syncthreads();
+        u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
+        if (CNT32) for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = (u64)((unsigned int *)hits)[f];
+        else for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
+    }
+#if IGD_EXP & 32
+    if (a.stamps && lane == 0) {
+        u64 *o = a.stamps + (size_t)gwave * 5;
+        o[0] = t_start; o[1] = t_desc; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1594,13 +2084,22 @@ static int dalloc(T **p, size_t n, int64_t *acct)
 extern "C" void igd_hip_close(igd_hip_db *db)
 {
     if (!db) return;
+#if IGD_EXP & 32
+    if (g_stamps) {
+        std::vector<u64> h((size_t)g_stampWaves * 5);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE *f = fopen("gpurun_out/stamps.bin", "wb");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
     if (t_arenaOwner == db) t_arenaOwner = nullptr;
     (void)hipSetDevice(db->device);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_qw1, db->d_spill,
                     db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
@@ -1717,6 +2216,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             for (int j = 0; j < d->nTile[c]; j++, t++) {
                 int32_t cnt = d->nCnt[t];
                 if (cnt < 0) cnt = 0;
+                if (cnt > db->maxTileCnt) db->maxTileCnt = cnt;
                 tileOff[t] = off;
                 tileCnt[t] = cnt;
                 // tile start coordinate; computed with wrap like `bd` at src/igd_search.c:496,529
@@ -1726,7 +2226,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                     u.off = off + r0;
                     u.tile = (int32_t)t;
                     u.n = cnt - r0 < IGD_CHUNK ? cnt - r0 : IGD_CHUNK;
-                    u.mx01 = u.mx23 = u.mx45 = 0;
+                    for (int r = 0; r < 6; r++) u.W[r] = 0;
+                    u.pad = 0;
                     int fl = r0 == 0 ? 1 : 0;
                     for (int k = 1; k < IGD_SHORT_TILES && k <= j; k++)
                         if (d->nCnt[t - k] <= 0) fl |= 1 << k;
@@ -1759,10 +2260,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         if (cus <= 0) cus = 256;
         db->ldsBytes = (int)((size_t)d->nFiles * 8);
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
+        db->ldsSorted = (db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0) + (IGD_WG / IGD_WAVE) * IGD_WLDS_BYTES;
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
         if (db->ldsHits && db->ldsBytes > 0) {
-            int fit = (160 * 1024) / (db->ldsBytes + 256);
+            int fit = (160 * 1024) / (db->ldsSorted + 256);
             if (fit < 1) fit = 1;
             if (fit < perCU) perCU = fit;
         }
@@ -1770,7 +2272,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 64 * ((size_t)nT + 2) + sizeof(Unit) * units.size() +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 72 * ((size_t)nT + 2) + sizeof(Unit) * units.size() +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -1790,6 +2292,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_spill, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_pairPos, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_blockSums, (size_t)(nT / IGD_SCAN_TILE + 2), acct));
@@ -1892,6 +2395,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
     }
     TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
+    TRYHIP(hipMemset(db->d_spill, 0, ((size_t)nT + 2) * 4));
     TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
 
     // launch geometry of the scan kernel: computed above (db->grid, db->ldsBytes, db->ldsHits)
@@ -1905,6 +2409,12 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             for (const void *fn : fns)
                 TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
         }
+    }
+    if (db->ldsSorted > 64 * 1024) {
+        const void *sfn[] = {(const void *)igd_scan_sorted<false, true, false, false>, (const void *)igd_scan_sorted<true, true, false, false>,
+                             (const void *)igd_scan_sorted<false, true, true, false>, (const void *)igd_scan_sorted<true, true, true, false>,
+                             (const void *)igd_scan_sorted<false, true, false, true>, (const void *)igd_scan_sorted<true, true, false, true>};
+        for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
     }
 #undef TRY
 #undef TRYHIP
@@ -1964,10 +2474,12 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
         HIPCHK(hipDeviceSynchronize());
         if (db->d_fix) (void)hipFree(db->d_fix);
         if (db->d_qw) (void)hipFree(db->d_qw);
-        db->d_fix = nullptr; db->d_qw = nullptr;
+        if (db->d_qw1) (void)hipFree(db->d_qw1);
+        db->d_fix = nullptr; db->d_qw = nullptr; db->d_qw1 = nullptr;
         db->wsQueries = 0;
         if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
-        if ((rc = dalloc(&db->d_qw, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_qw, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_qw1, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
         db->wsQueries = nq;
     }
     if (pairBytes == 0 || (nq <= db->wsBucket && pairBytes <= db->pairBytes)) return IGD_HIP_OK;
@@ -2041,6 +2553,29 @@ template <bool USE_V, bool LDS_HITS, bool PACKED>
 static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
 {
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
+    if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
+        SortArgs sa;
+        sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.qw1 = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
+        sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out;
+        sa.stamps = nullptr;
+#if IGD_EXP & 32
+        {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
+            static u64 *d_st = nullptr;
+            if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)db->grid * (IGD_WG / IGD_WAVE) * 5 * 8);
+            sa.stamps = d_st;
+            g_stamps = d_st; g_stampWaves = db->grid * (IGD_WG / IGD_WAVE);
+        }
+#endif
+        // 32-bit workgroup counters when nothing can reach 2^32: a record is counted at most once per candidate query of
+        // its unit, a query is a candidate in <= IGD_SHORT_TILES tiles, i.e. in <= 4 * (units per tile) units of <= 320 records
+        const int64_t unitsPerTile = (db->maxTileCnt + IGD_CHUNK - 1) / IGD_CHUNK;
+        const bool cnt32 = IGD_OPT_CNT32 && LDS_HITS && (int64_t)a.nq * IGD_SHORT_TILES * (unitsPerTile > 0 ? unitsPerTile : 1) * IGD_CHUNK < (1ll << 32);
+        const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
+        const size_t ldsS = (size_t)db->ldsSorted;
+        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
+        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
+        else igd_scan_sorted<USE_V, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
+    } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
 }
@@ -2078,7 +2613,11 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
     const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
     const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
-    db->epoch = db->epoch >= 0x3fffffff ? 1 : db->epoch + 1;
+    if (db->epoch >= 0x3fffffff) {                       // the epoch stamps start over
+        HIPCHK(hipMemsetAsync(db->d_spill, 0, ((size_t)db->nT + 2) * 4, st));
+        db->epoch = 0;
+    }
+    db->epoch++;
     int slot = -1;
     if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
@@ -2088,7 +2627,8 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const int gridQ = (int)(((nq > db->nFiles ? nq : db->nFiles) + 255) / 256);
     if (mode != 2)
         k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, mode == 1 ? 1 : 0);
+                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill,
+                                              mode == 1 ? 1 : 0);
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
         if (db->spShift >= 0 && !oldBucket)
@@ -2778,28 +3318,41 @@ extern "C" int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const 
 // ------------------------------------------------------------------------------------------
 // instrumentation: compulsory traffic of the scan kernel for one batch (include/igd_hip.h)
 __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, const int32_t *__restrict__ pairN,
-                               int sortedPath, u64 *__restrict__ acc /* units, records, pairs */)
+                               const int32_t *__restrict__ spill, int epoch, int path /* 0 bucket, 1 merge join exact, 2 merge join compact */,
+                               int rankOK, u64 *__restrict__ acc /* units, records, pairs | later-range queries, queries of rank-method tiles */)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    u64 nu = 0, nr = 0, np = 0;
+    u64 nu = 0, nr = 0, np = 0, nd = 0;
     if (u < db.nUnits) {
         const Unit un = db.units[u];
         if (un.n > 0) {
-            if (sortedPath) {       // exactly the test of issue_unit: the candidate range of the unit's tile is not empty
-                const int lj = UNIT_J(un);
-                const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+            const int lj = UNIT_J(un);
+            const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+            const bool firstUnit = UNIT_FLAGS(un) & 1;
+            if (path == 1) {        // exactly the test of issue_unit: the candidate range of the unit's tile is not empty
                 if (firstQ[un.tile + 1] > firstQ[un.tile - lb]) { nu = 1; nr = (u64)un.n; }
+            } else if (path == 2) { // exactly the test of s_issue: first-tile queries, or a marked tile with earlier queries
+                const int f0 = firstQ[un.tile], c0 = firstQ[un.tile + 1] - f0;
+                const int cl = spill[un.tile] == epoch ? f0 - firstQ[un.tile - lb] : 0;
+                if (c0 | cl) { nu = 1; nr = (u64)un.n; }
+                if (firstUnit) {
+                    if (cl) np = (u64)(f0 - firstQ[un.tile - (lb ? 1 : 0)]);   // the previous tile's queries: read as later candidates
+                    if (rankOK && c0 >= IGD_DENSE_MIN) nd = (u64)c0;
+                }
             } else if (pairN[un.tile] > 0) {
                 nu = 1; nr = (u64)un.n;
-                if (UNIT_FLAGS(un) & 1) np = (u64)pairN[un.tile];
+                if (firstUnit) np = (u64)pairN[un.tile];
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { nu += __shfl_down(nu, o); nr += __shfl_down(nr, o); np += __shfl_down(np, o); }
+    for (int o = 32; o > 0; o >>= 1) {
+        nu += __shfl_down(nu, o); nr += __shfl_down(nr, o); np += __shfl_down(np, o); nd += __shfl_down(nd, o);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (nu) atomicAdd(&acc[0], nu);
         if (nr) atomicAdd(&acc[1], nr);
         if (np) atomicAdd(&acc[2], np);
+        if (nd) atomicAdd(&acc[3], nd);
     }
 }
 
@@ -2828,18 +3381,23 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
     if (rc == IGD_HIP_OK && e == hipSuccess) {
         const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
         const bool sortedPath = mode == 1 || (mode == 0 && ctl[CTL_UNSORTED] != db->epoch);
-        k_unit_traffic<<<(db->nUnits + 255) / 256, 256, 0, st>>>(db->v, db->d_firstQ, db->d_pairN, sortedPath ? 1 : 0, d_acc);
+        const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);
+        const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
+        const int path = !sortedPath ? 0 : packed ? 2 : 1;
+        k_unit_traffic<<<(db->nUnits + 255) / 256, 256, 0, st>>>(db->v, db->d_firstQ, db->d_pairN, db->d_spill, db->epoch, path,
+                                                               ctl[CTL_NOTSTART] != db->epoch ? 1 : 0, d_acc);
         u64 acc[4] = {0, 0, 0, 0};
         e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipMemcpy(acc, d_acc, 32, hipMemcpyDeviceToHost);
-        const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);
-        const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
         const int recB = packed ? (useV ? 8 : 6) : (useV ? 16 : 12);
         out->units = (int64_t)acc[0];
         out->records = (int64_t)acc[1];
         out->record_bytes = (int64_t)acc[1] * recB;
-        out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
-        out->query_bytes = sortedPath ? 12ll * nq : 8ll * (int64_t)acc[2];
+        out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (path == 2 ? 8ll * (db->nT + 1) : sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
+        // merge join, compact image: one 4-byte word per query (qw0), the later-tile words (qw1) of the queries in front of a
+        // marked tile, the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe; bucket path: 8 B per pair
+        out->query_bytes = path == 2 ? 4ll * nq + 4ll * (int64_t)acc[2] + 4ll * (int64_t)acc[3]
+                         : path == 1 ? 12ll * nq : 8ll * (int64_t)acc[2];
         out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * 8 : 8ll * db->nFiles;
         out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;
     }

@@ -206,8 +206,8 @@ typedef struct {
     int64_t units;          /* units (<= 320-record chunks of a tile) with at least one candidate query     */
     int64_t records;        /* records in them                                                            */
     int64_t record_bytes;   /* records x bytes per record of the image read (6 / 8 compact, 12 / 16 exact) */
-    int64_t unit_bytes;     /* 32-byte descriptors of ALL units + the per-tile query ranges read            */
-    int64_t query_bytes;    /* 12 B (ichr/qs/qe ... the merge join reads qw,qs,qe) + 4 B qw per query, once */
+    int64_t unit_bytes;     /* 48-byte descriptors of ALL units + the per-tile query ranges / marks read     */
+    int64_t query_bytes;    /* per-query words the kernel reads, each once (4 B/query in the compact merge join) */
     int64_t slab_bytes;     /* the workgroups' private counter rows written at the end of the kernel       */
     int64_t total;          /* sum of the four                                                            */
 } igd_hip_traffic;
