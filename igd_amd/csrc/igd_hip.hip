@@ -188,6 +188,8 @@ struct igd_hip_db {
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
     int ldsSorted;                // dynamic LDS of igd_scan_sorted: counters + the waves' rank-method areas
     int32_t maxTileCnt;           // records of the fullest tile
+    int sbCap;                    // igd_scan_sorted, rank method: query starts of one tile a wave keeps in LDS
+    int32_t *d_blockLast;         // [wsQueries / 64 + 2] per 64 queries: last tile covered as a later tile
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
     int32_t *d_spBase;            // pairs per coarse bucket
@@ -335,6 +337,7 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
     return (int)((unsigned)(65536 - qe2) | ((unsigned)qs2 << 16));
 }
 #define IGD_NEVER 0xFFFFFFFFu     // a query word no record word can match (e' <= W <= 32768 < 65535)
+#define QB_CTG 1024               // contigs whose tile tables k_query_bounds keeps in LDS
 
 // What k_query_bounds leaves per query for the merge join (sorted path):
 //   compact image (packed != 0):
@@ -347,8 +350,13 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 //              (there, qs' = 1 and qe' = min(qeRel - k W, W) + 1; k = (tile - first tile) follows from 2 bits).
 //     spill[t] = epoch for every tile t that some query covers as a later tile (k = 1..3): most units have
 //              none and never look at the queries of the tiles before theirs.
+//     blockLast[i / 64] = the last tile any of the 64 queries covers as a later tile (-1: none): a unit that does
+//              look back skips the 64-query blocks that end before its tile.
 //   exact arrays (packed == 0):
 //     qw0[i] = (global number of the first tile) << 4 | min(n2 - n1, 15), -1 when it visits nothing.
+// VEC queries per thread (4: the three query arrays are read, and the word arrays written, as dwordx4 -- a quarter of
+// the memory instructions and four independent chains per thread; 1: arrays that are not 16-byte aligned).
+template <int VEC>
 __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
@@ -356,12 +364,22 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ qw1,
-                                                      int32_t *__restrict__ spill, int promised)
+                                                      int32_t *__restrict__ spill, int32_t *__restrict__ blockLast, int promised)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zeroHits && i < db.nFiles) zeroHits[i] = 0;        // IGD_HIP_FLAG_ZERO_FIRST
-    if (zeroTotal && i == 0) *zeroTotal = 0;
-    if (i == 0) {                                           // next batch's list counters
+    // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
+    __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
+    const bool ldsTab = db.nCtg <= QB_CTG;
+    if (ldsTab) {
+        for (int c = threadIdx.x; c < db.nCtg; c += blockDim.x) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
+        __syncthreads();
+    }
+#define QB_BASE(c) (ldsTab ? sBase[c] : db.ctgBase[c])
+#define QB_NTILE(c) (ldsTab ? sNTile[c] : db.ctgNTile[c])
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i0 = t * VEC;
+    if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * blockDim.x) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
+    if (zeroTotal && t == 0) *zeroTotal = 0;
+    if (t == 0) {                                           // next batch's list counters
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
@@ -369,87 +387,129 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
     // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.  A plain
-    // (L1-cached, possibly stale) load on purpose: this is only a shortcut, and a device-scope load of ONE
-    // address by every wave of the grid queues up at a single L2 channel (128 us for 1.25e7 queries).
+    // (L1-cached, possibly stale) load: this is only a shortcut.
     if (__builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) == epoch) return;
-    int lo = 0, hi = -1;                                    // this thread fills firstQ[lo..hi] = val
-    int val = i;
-    if (i < nq) {
-        const int c = ichr[i], s0 = qs[i];
-        const int k = tile_key(db, c, s0);
-        int prev = -1, prevS = INT_MIN;
-        if (i) { prevS = qs[i - 1]; prev = tile_key(db, ichr[i - 1], prevS); }
-        if (k < prev) {
-            ctl[CTL_UNSORTED] = epoch;
-            if (promised) ctl[CTL_BROKEN] = epoch;          // sticky until the next igd_hip_sync (any promised batch since)
+    int qc[VEC], qs_[VEC], qe_[VEC];
+    if (VEC == 4) {
+        int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
+        if (i0 + 3 < nq) {
+            c4 = *(const int4 *)(ichr + i0); s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
+        } else {
+            if (i0 < nq) { c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
+            if (i0 + 1 < nq) { c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
+            if (i0 + 2 < nq) { c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
         }
-        // ordered by tile but not by start inside a tile: the merge join still holds, the rank method does not
-        if (k == prev && s0 < prevS) ctl[CTL_NOTSTART] = epoch;
-        lo = prev + 1; hi = k;
-        int w0 = packed ? 0 : -1, w1 = 0;
-        if (c >= 0 && c < db.nCtg) {
-            const int n1 = tile_of(db, s0);
-            const int mT = db.ctgNTile[c] - 1;
-            if (n1 >= 0 && n1 <= mT) {
-                const int e0 = qe[i];
+        qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
+        qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
+        qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
+    } else if (i0 < nq) { qc[0] = ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
+    // predecessor of the thread's first query
+    int pc = -1, ps = INT_MIN, prevKey = -1;
+    if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; prevKey = tile_key(db, pc, ps); }
+    int w0v[VEC], w1v[VEC];
+    int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
+    bool unordered = false;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        const int i = i0 + v;
+        int lo = 0, hi = -1;                                // this query fills firstQ[lo..hi] = i
+        w0v[v] = packed ? 0 : -1; w1v[v] = 0;
+        if (i < nq) {
+            const int c = qc[v], s0 = qs_[v];
+            const bool cOk = c >= 0 && c < db.nCtg;
+            const int cBase = cOk ? QB_BASE(c) : 0, cMT = cOk ? QB_NTILE(c) - 1 : 0;
+            const int n1r = tile_of(db, s0);
+            // key(i): global number of the first tile, clamped into the contig (tile_key)
+            const int n1c = n1r < 0 ? 0 : (n1r > cMT ? cMT : n1r);
+            const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cBase + n1c);
+            if (k < prevKey) {
+                ctl[CTL_UNSORTED] = epoch;
+                if (promised) ctl[CTL_BROKEN] = epoch;      // sticky until the next igd_hip_sync (any promised batch since)
+                unordered = true;
+            }
+            // ordered by tile but not by start inside a tile: the merge join still holds, the rank method does not
+            if (k == prevKey && s0 < ps) ctl[CTL_NOTSTART] = epoch;
+            lo = prevKey + 1; hi = k;
+            if (cOk && n1r >= 0 && n1r <= cMT) {
+                const int n1 = n1r, e0 = qe_[v];
                 int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
-                if (n2 > mT) n2 = mT;
+                if (n2 > cMT) n2 = cMT;
                 const int span = n2 > n1 ? n2 - n1 : 0;
-                const int g0 = db.ctgBase[c] + n1;
+                const int g0 = cBase + n1;
                 const int T0 = (int)((unsigned)n1 * (unsigned)db.nbp);
                 // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
                 if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
                 const bool needExact = packed && e0 <= T0;
                 if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
-                if (!packed) w0 = (g0 << 4) | (span < 15 ? span : 15);
-                else if (rule != IGD_HIP_RULE_NEST || db.tileCnt[g0] > 0) {   // rule NEST: an empty first tile ends the query (:468)
-                    if (!needExact) w0 = ~query_word(s0, e0, true, T0, db.nbp);
+                if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
+                else {
+                    // rule NEST (an empty first tile ends the query, :468) needs no look-up here: the first tile's own
+                    // units have records by definition, and for the later tiles the scan knows from the unit's flags
+                    // which of the tiles before it are empty
+                    if (!needExact) w0v[v] = ~query_word(s0, e0, true, T0, db.nbp);
                     if (span > 0) {
                         const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
                         int rel = e0 - T0;                  // > W here, since the query reaches the next tile
                         if (rel > 4 * db.nbp) rel = 4 * db.nbp;
-                        w1 = rel | (sp << 20) | ((g0 & 3) << 22) | (1 << 24);
+                        w1v[v] = rel | (sp << 20) | ((g0 & 3) << 22) | (1 << 24);
                         for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
+                        if (g0 + sp > lastTile) lastTile = g0 + sp;
                     }
                 }
             }
+            prevKey = k; ps = s0;
         }
-        qw0[i] = w0;
-        if (packed) qw1[i] = w1;
-    }
-    // short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
-    // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
-    // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
-    // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
-    // A wave that sees disorder among its own queries, or finds the batch already marked, fills
-    // nothing: firstQ[] is not going to be used.
-    const bool disorder = __ballot(lo > hi + 1) != 0 || ctl[CTL_UNSORTED] == epoch;
-    const bool big = hi - lo >= 8;
-    if (!big && !disorder) for (int t = lo; t <= hi; t++) firstQ[t] = val;
-    unsigned long long m = disorder ? 0ull : __ballot(big);
-    while (m) {
-        const int src = __builtin_ctzll(m);
-        m &= m - 1;
-        const int l2 = __builtin_amdgcn_readlane(lo, src), h2 = __builtin_amdgcn_readlane(hi, src);
-        const int v2 = __builtin_amdgcn_readlane(val, src);
-        if (h2 - l2 >= 256) {
-            int spent = 0;
-            if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
-            spent = __builtin_amdgcn_readfirstlane(spent);
-            if (spent > (db.nT >> 8) + 16) {
-                if (lane == 0) {
-                    ctl[CTL_UNSORTED] = epoch;
-                    if (promised) ctl[CTL_BROKEN] = epoch;
+        // firstQ: short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
+        // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
+        // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
+        // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
+        // A wave that sees disorder among its own queries, or finds the batch already marked, fills
+        // nothing: firstQ[] is not going to be used.
+        const bool disorder = __ballot(unordered) != 0 || ctl[CTL_UNSORTED] == epoch;
+        const bool big = hi - lo >= 8;
+        if (!big && !disorder) for (int tt = lo; tt <= hi; tt++) firstQ[tt] = i;
+        unsigned long long m = disorder ? 0ull : __ballot(big);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int l2 = __builtin_amdgcn_readlane(lo, src), h2 = __builtin_amdgcn_readlane(hi, src);
+            const int v2 = __builtin_amdgcn_readlane(i, src);
+            if (h2 - l2 >= 256) {
+                int spent = 0;
+                if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
+                spent = __builtin_amdgcn_readfirstlane(spent);
+                if (spent > (db.nT >> 8) + 16) {
+                    if (lane == 0) {
+                        ctl[CTL_UNSORTED] = epoch;
+                        if (promised) ctl[CTL_BROKEN] = epoch;
+                    }
+                    continue;
                 }
-                continue;
             }
+            for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) firstQ[tt] = v2;
         }
-        for (int t = l2 + lane; t <= h2; t += IGD_WAVE) firstQ[t] = v2;
     }
-    // the tail: tiles after the last query's key (done by the last wave)
-    if (nq > 0 && (nq - 1) / IGD_WAVE == i / IGD_WAVE) {
+#undef QB_BASE
+#undef QB_NTILE
+    if (VEC == 4) {
+        if (i0 + 3 < nq) {
+            *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
+            if (packed) *(int4 *)(qw1 + i0) = make_int4(w1v[0], w1v[1 % VEC], w1v[2 % VEC], w1v[3 % VEC]);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; v++)
+                if (i0 + v < nq) { qw0[i0 + v] = w0v[v]; if (packed) qw1[i0 + v] = w1v[v]; }
+        }
+    } else if (i0 < nq) { qw0[i0] = w0v[0]; if (packed) qw1[i0] = w1v[0]; }
+    if (packed) {   // per 64 queries: the last tile any of them covers as a later tile (the scan skips the blocks that end before its tile)
+        int mx = lastTile;
+        for (int o = 32 / VEC; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+        if ((lane & (IGD_WAVE / VEC - 1)) == 0 && i0 < nq) blockLast[i0 >> 6] = mx;
+    }
+    // the tail: tiles after the last query's key (done by the wave of the last query)
+    if (nq > 0 && (nq - 1) / (IGD_WAVE * VEC) == i0 / (IGD_WAVE * VEC)) {
         const int kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
-        for (int t = kl + 1 + lane; t <= db.nT; t += IGD_WAVE) firstQ[t] = nq;
+        for (int tt = kl + 1 + lane; tt <= db.nT; tt += IGD_WAVE) firstQ[tt] = nq;
     }
 }
 
@@ -1270,21 +1330,23 @@ struct SortArgs {
     const int32_t *firstQ;       // [nT+1] first query of each tile
     const int32_t *spill;        // [nT]   == epoch: some query covers the tile as a later tile
     const int32_t *qw0, *qw1;    // per-query words (k_query_bounds)
-    const int32_t *q_qs;         // the caller's query starts (rank method, B term)
+    const int32_t *blockLast;    // per 64 queries: last tile covered as a later tile
+    const int32_t *q_qs;         // the caller's query starts (rank method: exceptions, and tiles with more queries than sbCap)
     const int32_t *ctl;
-    int nq, v, epoch, mode;
+    int nq, v, epoch, mode, rule;
+    int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
 
 // A unit's descriptor and query ranges, one unit per lane (broadcast with v_readlane when its turn comes)
-struct SRegs { int32_t offLo, offHi, n /* | (tile & 3) << 16 */, jf, w[IGD_SLOTS], f0, c0, cl; };
+struct SRegs { int32_t offLo, offHi, n, g /* global tile */, jf, w[IGD_SLOTS], f0, c0, cl; };
 
 struct Raw2 {
     uint32_t a[IGD_SLOTS];       // s' | e' << 16 (inverted s', see k_pack_units)
     int32_t x[IGD_SLOTS];        // idx (| value << 16)
     int32_t q;                   // first 64 first-tile words (already un-inverted)
-    int32_t c0, cl, f0, nn;      // wave-uniform (SGPRs): the unit's query ranges and n | (tile & 3) << 16, kept from the issue
+    int32_t c0, cl, f0, n;       // wave-uniform (SGPRs): the unit's query ranges and record count, kept from the issue
 };
 
 // Branch-free on purpose (see issue_unit): the same number of loads whatever the unit looks like, so that
@@ -1301,9 +1363,8 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
     int c0 = __builtin_amdgcn_readlane(L.c0, kq), cl = __builtin_amdgcn_readlane(L.cl, kq);
     if (!valid) { c0 = 0; cl = 0; }
     const int f0 = __builtin_amdgcn_readlane(L.f0, kq);
-    const int nn = (c0 | cl) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
-    const int n = nn & 0xFFFF;
-    R.c0 = c0; R.cl = cl; R.f0 = f0; R.nn = nn;
+    const int n = (c0 | cl) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
+    R.c0 = c0; R.cl = cl; R.f0 = f0; R.n = n;
     const unsigned offLo = (unsigned)__builtin_amdgcn_readlane(L.offLo, kq);
     const int vo4 = lane * 4, vo2 = lane * 2;
     if (BIG) {
@@ -1385,10 +1446,11 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
 }
 
 // later-tile candidate word qw1 -> compare word for this tile (IGD_NEVER when the query does not reach it)
-__device__ __forceinline__ int later_word(const DbView &db, int q1, int g3, bool &covers)
+__device__ __forceinline__ int later_word(const DbView &db, int q1, int g, int deadk, bool &covers)
 {
-    const int k = (g3 - ((q1 >> 22) & 3)) & 3;           // tiles between the query's first tile and this one (1..3)
-    covers = ((q1 >> 24) & 1) && k != 0 && ((q1 >> 20) & 3) >= k;
+    const int k = (g - ((q1 >> 22) & 3)) & 3;            // tiles between the query's first tile and this one (1..3)
+    // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); deadk bit k = tile j-k is empty
+    covers = ((q1 >> 24) & 1) && k != 0 && ((q1 >> 20) & 3) >= k && !((deadk >> k) & 1);
     int rel = (q1 & 0xFFFFF) - __mul24(k, db.nbp);       // qe - T for this tile
     rel = (rel < db.nbp ? rel : db.nbp) + 1;             // qe'
     return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
@@ -1416,14 +1478,35 @@ __device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key
     return pos;
 }
 
+// The later-tile candidates of a unit: queries [fl, f0) of the (up to) 3 tiles before its tile, visited in the 64-query
+// blocks k_query_bounds summarised (blockLast): a block none of whose queries reaches this tile is skipped unread.
+// FN(word, covers) is called once per visited block with every lane's compare word (IGD_NEVER where !covers).
+template <typename FN>
+__device__ __forceinline__ void for_later_blocks(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane, FN fn)
+{
+    const int b0 = fl >> 6, nb = ((f0 - 1) >> 6) - b0 + 1;
+    for (int bb = 0; bb < nb; bb += IGD_WAVE) {
+        const int bl = (bb + lane < nb) ? a.blockLast[b0 + bb + lane] : -1;
+        unsigned long long bm = __ballot(bl >= g);
+        while (bm) {
+            const int j = __builtin_ctzll(bm);
+            bm &= ~(1ull << j);
+            const int i = ((b0 + bb + j) << 6) + lane;
+            const int q1 = (i >= fl && i < f0) ? a.qw1[i] : 0;
+            bool covers;
+            const int w = later_word(db, q1, g, deadk, covers);
+            fn(w, covers);
+        }
+    }
+}
+
 template <bool USE_V, bool CNT32>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
-                                          u64 *hits, unsigned short *sl, unsigned int *hist, bool rankOK)
+                                          u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK)
 {
     const int c0 = R.c0, cl = R.cl;
     if ((c0 | cl) == 0) return;                          // nobody asks about this unit
-    const int nn = R.nn;
-    const int un = nn & 0xFFFF, g3 = nn >> 16;
+    const int un = R.n;
     if (un == 0) return;                                 // placeholder of an empty tile
     const int f0 = R.f0;
     uint32_t W[IGD_SLOTS];
@@ -1441,6 +1524,12 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             keep[r] = (R.x[r] >> 16) >= a.v;             // arithmetic shift: the signed 16-bit value
             R.x[r] &= 0xFFFF;
         }
+    }
+    // later tiles: the unit's global tile number and which of the 3 tiles before it are empty (rule NEST)
+    int g = 0, deadk = 0;
+    if (cl) {
+        g = __builtin_amdgcn_readlane(L.g, kk);
+        deadk = a.rule == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
     }
 #if IGD_EXP & 4
     {
@@ -1461,65 +1550,49 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
             match_words(R, cnt, W, w);
         }
-        for (int p = 0; p < cl; p += IGD_WAVE) {
-            const int q1 = (p + lane < cl) ? a.qw1[f0 - cl + p + lane] : 0;
-            bool covers;
-            const int w = later_word(db, q1, g3, covers);
-            nLater += __popcll(__ballot(covers));
-            match_words(R, cnt, W, w);
-        }
-        // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
-        // query, none of which may count them (the reference's tS skip, :510-511)
-        if (nLater != 0) {
+        if (cl) {
+            for_later_blocks(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+                nLater += __popcll(__ballot(covers));
+                match_words(R, cnt, W, w);
+            });
+            // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
+            // query, none of which may count them (the reference's tS skip, :510-511)
+            if (nLater != 0) {
 #pragma unroll
-            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+            }
         }
     } else {
         // ---- rank ---------------------------------------------------------------------------------
-        // a first-tile query misses the record at the front (term B) iff  qs > key,  key = e' + T - 1
-        const int Tm1 = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp) - 1;
-#define RANK_KEY(r) ((int)(R.a[r] >> 16) + Tm1)
+        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp);
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++)
             sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
-        // term B first, with cnt[] as the bisection's position: #{first-tile q: qs > key} = c0 - #{qs <= key};
-        // q_qs[f0 .. f0+c0) is ordered (CTL_NOTSTART says when it is not)
-        {
-            int top = 1;
-            while (top <= c0) top <<= 1;                 // c0 < 2^31
-            for (int step = top >> 1; step > 0; step >>= 1) {
-                int vq[IGD_SLOTS];
-#pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) {
-                    const int at = cnt[r] + step - 1;
-                    vq[r] = at < c0 ? a.q_qs[f0 + at] : INT_MAX;
-                }
-#pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] += vq[r] <= RANK_KEY(r) ? step : 0;
-            }
-#pragma unroll
-            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0;   // = -(term B)
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        const bool inLds = c0 <= a.sbCap;                // the tile's query starts fit the wave's LDS array
         int nFirst = 0;
         for (int p = 0; p < c0; p += IGD_WAVE) {
             int w = R.q;
             if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
             const bool there = p + lane < c0;
-            const int qe2 = 65536 - (w & 0xFFFF), qs2 = (int)((unsigned)w >> 16);
+            const int qe2 = 65536 - (w & 0xFFFF);
+            int qs2 = (int)((unsigned)w >> 16);
             const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;
             const int pos = lds_lower_bound(sl, qe2);
             if (good) atomicAdd(&hist[pos], 1u);
             nFirst += __popcll(__ballot(good));
-            // the exceptions: in the range (so the bisection of q_qs[] above counted them) but not in the sums
+            // the exceptions: masked-out (IGD_NEVER) or inverted queries.  They stay in the ordered list of starts that
+            // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                const int qsx = there ? a.q_qs[f0 + p + lane] : 0;
+                int t = there ? a.q_qs[f0 + p + lane] - T + 1 : 65535;   // = qs' for a query of this tile; beyond it: clamped
+                t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+                qs2 = t;
                 while (x) {
                     const int src = __builtin_ctzll(x);
                     x &= ~(1ull << src);
-                    const int s_ = __builtin_amdgcn_readlane(qsx, src), wq = __builtin_amdgcn_readlane(w, src);
+                    const int s_ = __builtin_amdgcn_readlane(qs2, src), wq = __builtin_amdgcn_readlane(w, src);
 #pragma unroll
                     for (int r = 0; r < IGD_SLOTS; r++) {
                         igd_u16x2 rec, qw;
@@ -1528,22 +1601,51 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                         const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);
                         uint32_t mxw;
                         __builtin_memcpy(&mxw, &mx, 4);
-                        cnt[r] += (s_ > RANK_KEY(r) ? 1 : 0) + (mxw == R.a[r] ? 1 : 0);   // undo term B; an inverted query's own hits
+                        cnt[r] += (s_ > (int)(R.a[r] >> 16) ? 1 : 0) + (mxw == R.a[r] ? 1 : 0);   // undo term B; an inverted query's own hits
                     }
                 }
             }
+            if (inLds && there) sb[p + lane] = (unsigned short)qs2;
         }
-        for (int p = 0; p < cl; p += IGD_WAVE) {
-            const int q1 = (p + lane < cl) ? a.qw1[f0 - cl + p + lane] : 0;
-            bool covers;
-            const int w = later_word(db, q1, g3, covers);
-            const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
-            if (covers) atomicAdd(&hist[pos], 1u);
-            nLater += __popcll(__ballot(covers));
-        }
-#undef RANK_KEY
+        if (cl)
+            for_later_blocks(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+                const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
+                if (covers) atomicAdd(&hist[pos], 1u);
+                nLater += __popcll(__ballot(covers));
+            });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // term B: #{first-tile q: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
+        {
+            int top = 1;
+            while (top <= c0) top <<= 1;                 // c0 < 2^31
+            int pos[IGD_SLOTS];
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
+            if (inLds) {
+                for (int step = top >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int at = pos[r] + step - 1;
+                        const int vq = at < c0 ? (int)sb[at] : 65536;
+                        pos[r] += vq <= (int)(R.a[r] >> 16) ? step : 0;
+                    }
+                }
+            } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
+                for (int step = top >> 1; step > 0; step >>= 1) {
+                    int vq[IGD_SLOTS];
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int at = pos[r] + step - 1;
+                        vq[r] = at < c0 ? a.q_qs[f0 + at] : INT_MAX;
+                    }
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) + T - 1 ? step : 0;   // qs' <= e'
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0 - pos[r];
+        }
         // term A: #{q: p_q <= i} = inclusive prefix sum of the histogram over the record positions
         int carry = 0;
 #pragma unroll
@@ -1585,8 +1687,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const size_t hitBytes = LDS_HITS ? (((size_t)db.nFiles * (CNT32 ? 4 : 8) + 15) & ~(size_t)15) : 0;
     u64 *hits = LDS_HITS ? (u64 *)smem : a.out;
-    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * IGD_WLDS_BYTES);
+    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)a.wldsBytes);
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
+    unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
     for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     if (LDS_HITS) {
@@ -1616,7 +1719,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
 
     for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
         SRegs L;
-        L.offLo = L.offHi = L.n = L.jf = L.f0 = L.c0 = L.cl = 0;
+        L.offLo = L.offHi = L.n = L.g = L.jf = L.f0 = L.c0 = L.cl = 0;
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = 0;
         {
@@ -1624,7 +1727,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
             if (mi < db.nUnits) {
                 const UnitRegs u = load_unit_regs(db.units + mi);
                 L.offLo = u.offLo; L.offHi = u.offHi; L.jf = u.jf;
-                L.n = u.n | ((u.tile & 3) << 16);
+                L.n = u.n; L.g = u.tile;
 #pragma unroll
                 for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = u.w[r];
                 if (u.n > 0) {
@@ -1647,9 +1750,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32>(db, a, L, kk, lane, A, hits, sl, hist, rankOK);
+            s_compute<USE_V, CNT32>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
             s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32>(db, a, L, kk + 1, lane, B, hits, sl, hist, rankOK);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
@@ -2099,7 +2202,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_qw1, db->d_spill,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast,
                     db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
@@ -2260,7 +2363,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         if (cus <= 0) cus = 256;
         db->ldsBytes = (int)((size_t)d->nFiles * 8);
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
-        db->ldsSorted = (db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0) + (IGD_WG / IGD_WAVE) * IGD_WLDS_BYTES;
+        {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
+            // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
+            const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0;
+            int spare = (80 * 1024 - 512 - hitB) / (IGD_WG / IGD_WAVE) - IGD_WLDS_BYTES;
+            db->sbCap = spare < 128 ? 0 : (spare / 2 > 2048 ? 2048 : (spare / 2) & ~63);
+            db->ldsSorted = hitB + (IGD_WG / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
+        }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
         if (db->ldsHits && db->ldsBytes > 0) {
@@ -2475,11 +2584,13 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
         if (db->d_fix) (void)hipFree(db->d_fix);
         if (db->d_qw) (void)hipFree(db->d_qw);
         if (db->d_qw1) (void)hipFree(db->d_qw1);
-        db->d_fix = nullptr; db->d_qw = nullptr; db->d_qw1 = nullptr;
+        if (db->d_blockLast) (void)hipFree(db->d_blockLast);
+        db->d_fix = nullptr; db->d_qw = nullptr; db->d_qw1 = nullptr; db->d_blockLast = nullptr;
         db->wsQueries = 0;
         if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
         if ((rc = dalloc(&db->d_qw, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
         if ((rc = dalloc(&db->d_qw1, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_blockLast, (size_t)nq / 64 + 2, nullptr)) != IGD_HIP_OK) return rc;
         db->wsQueries = nq;
     }
     if (pairBytes == 0 || (nq <= db->wsBucket && pairBytes <= db->pairBytes)) return IGD_HIP_OK;
@@ -2556,7 +2667,9 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
     if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
         SortArgs sa;
         sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.qw1 = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
-        sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out;
+        sa.blockLast = db->d_blockLast;
+        sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
+        sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
         sa.stamps = nullptr;
 #if IGD_EXP & 32
         {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -2624,11 +2737,15 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     // IGD_HIP_FLAG_ZERO_FIRST: the first kernel of the batch clears hits[] (and total)
     u64 *zh = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_hits : nullptr;
     u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
-    const int gridQ = (int)(((nq > db->nFiles ? nq : db->nFiles) + 255) / 256);
-    if (mode != 2)
-        k_query_bounds<<<gridQ, 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                                              db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill,
-                                              mode == 1 ? 1 : 0);
+    if (mode != 2) {
+        const bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
+        if (vec)
+            k_query_bounds<4><<<(int)((nq + 1023) / 1024), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
+                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast, mode == 1 ? 1 : 0);
+        else
+            k_query_bounds<1><<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
+                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast, mode == 1 ? 1 : 0);
+    }
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
         if (db->spShift >= 0 && !oldBucket)

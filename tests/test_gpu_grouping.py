@@ -248,6 +248,38 @@ def test_a_broken_promise_among_several_async_batches_is_not_lost(workdir):
         orc.close()
 
 
+def test_unaligned_device_arrays_take_the_scalar_reader(workdir):
+    """igd_hip_search_dev reads the query arrays as dwordx4 when they are 16-byte aligned and one query per thread
+    otherwise (views into larger tensors): same counts."""
+    import torch
+    from igd_amd import Database
+    rng = random.Random(99)
+    nbp = 1 << 12
+    path, ctgs, span = _random_db(rng, workdir, "unal", nbp, 1, 9, 3, 30, 80, 20)
+    orc = Oracle(path)
+    db = Database(path)
+    try:
+        ichr, qs, qe = _random_queries(rng, [0, 1, 2], nbp, span, 5003)
+        si, ss, se = _sorted(ichr, qs, qe)
+        want = orc.search(si, ss, se, 0)[0]
+        dev = torch.device("cuda", 0)
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            for shift in (0, 1, 2, 3):
+                t = [torch.cat([torch.zeros(shift, dtype=torch.int32), torch.from_numpy(x)]).to(dev)[shift:] for x in (si, ss, se)]
+                assert all((x.data_ptr() % 16) == (4 * shift) % 16 for x in t)
+                hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+                for fl in (0, FLAG_SORTED, FLAG_BUCKET):
+                    hits.zero_()
+                    db.search_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(si), hits.data_ptr(), None,
+                                  v=0, stream=stream.cuda_stream, flags=fl)
+                    db.sync(stream.cuda_stream)
+                    np.testing.assert_array_equal(hits.cpu().numpy(), want, err_msg="shift %d flags %d" % (shift, fl))
+    finally:
+        db.close()
+        orc.close()
+
+
 def test_blocking_api_repairs_a_wrong_order_promise(workdir):
     """igd_hip_search_ex(..., IGD_HIP_FLAG_SORTED) on UNSORTED host arrays: the device reports the
     broken promise, the call repeats the slice in auto mode -- counts are right, never doubled."""
