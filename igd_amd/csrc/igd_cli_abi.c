@@ -12,6 +12,7 @@
  * tool -- turns that into a non-zero return value instead of printing a table of zeros.
  */
 #define _GNU_SOURCE
+#include <fcntl.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <unistd.h>
@@ -189,10 +190,28 @@ iGD_t *get_igdinfo(char *igdFile)                                  /* src/igd_ba
 }
 
 /* ------------------------------- one query -------------------------------------------- */
+/* Single intervals (`-r`, get_overlaps*): while no engine is resident the host reads the interval's own tiles, like the
+ * reference does (:469-476), instead of uploading the whole database for one wave of work (igdc_walk_one, igd_core.h) */
+static int one_query_fd(void)
+{
+    if (g_core && g_core->dev) return -1;                     /* the database is on the GPU already: ask it */
+    if (g_core_path) return open(g_core_path, O_RDONLY);
+    return fP ? dup(fileno(fP)) : -1;
+}
+
 static int32_t one_query(const char *chrm, int32_t qs, int32_t qe, int32_t v, int rule, int64_t *hits)
 {
     int32_t ichr = get_id(chrm);
     if (ichr < 0) return 0;                                   /* :456-457 */
+    if (g_core && cur_igd()) {
+        const int fd = one_query_fd();
+        if (fd >= 0) {
+            g_core->nFiles = cur_igd()->nFiles;
+            const int64_t n = igdc_walk_one(g_core, fd, ichr, qs, qe, v, v != IGD_HIP_NO_VALUE_FILTER, rule, hits, NULL, NULL);
+            close(fd);
+            if (n >= 0) return (int32_t)n;
+        }
+    }
     igd_hip_db *dev = engine();
     if (!dev) return 0;
     int64_t total = 0;
@@ -458,6 +477,8 @@ static void *fmt_run(void *arg)
 typedef struct {
     const igdc_queries *q; char **names; const iGD_t *G; const size_t *flen; size_t maxL;
     int64_t q0; int nt;
+    obuf keep[64];                    /* the formatting threads' text buffers, kept from chunk to chunk: fresh 100 MB
+                                         allocations per chunk would spend the time in page faults, not in formatting */
 } print_ctx;
 
 /* igd_hip_enum_sink: one chunk = queries [b0,b1) of the call, its overlaps in pinned memory */
@@ -485,10 +506,15 @@ static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, c
         J->q = P->q; J->names = P->names; J->G = P->G; J->flen = P->flen; J->q0 = P->q0; J->qoff = qoff; J->hit = hit;
         J->hbase = qoff[b0];
         J->i0 = i0; J->i1 = i1;
+        const size_t need = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + P->maxL) + 64;
+        if (need > P->keep[used].cap) {
+            free(P->keep[used].buf);
+            P->keep[used].cap = need + need / 4;
+            P->keep[used].buf = (char *)malloc(P->keep[used].cap);
+        }
+        J->o = P->keep[used];
         J->o.n = 0;
-        J->o.cap = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + P->maxL) + 64;
-        J->o.buf = (char *)malloc(J->o.cap);
-        if (!J->o.buf) { for (int k = 0; k < used; k++) { if (started[k]) pthread_join(th[k], NULL); free(job[k].o.buf); } return 1; }
+        if (!J->o.buf) { P->keep[used].cap = 0; for (int k = 0; k < used; k++) if (started[k]) pthread_join(th[k], NULL); return 1; }
         /* a thread that cannot be started is simply run here */
         started[used] = used > 0 && pthread_create(&th[used], NULL, fmt_run, J) == 0;
         if (used > 0 && !started[used]) fmt_run(J);
@@ -499,7 +525,6 @@ static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, c
     for (int t = 0; t < used; t++) {
         if (started[t]) pthread_join(th[t], NULL);
         if (job[t].o.n) fwrite(job[t].o.buf, 1, job[t].o.n, stdout);
-        free(job[t].o.buf);
     }
     return 0;
 }
@@ -523,6 +548,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
     fflush(stdout);
     print_ctx P;
     P.q = q; P.names = names; P.G = G; P.flen = flen; P.maxL = maxL; P.nt = nt;
+    memset(P.keep, 0, sizeof P.keep);
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
         P.q0 = q0;
@@ -530,6 +556,7 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
         if (rc != IGD_HIP_OK) { engine_failed("enumerate", rc); break; }
         grand += total;
     }
+    for (int t = 0; t < 64; t++) free(P.keep[t].buf);
     free(flen);
     free(qoff);
     return grand;
@@ -568,10 +595,32 @@ static int64_t file_enumerate(const char *qFile)
 int64_t getOverlaps_f1(char *qFile) { return file_enumerate(qFile); }        /* :721-744 */
 int64_t getOverlaps_f0(char *qFile) { return file_enumerate(qFile); }        /* :227-250 */
 
+typedef struct { int32_t k; const iGD_t *G; } emit_ctx;
+static void emit_line(void *ctx, int32_t idx, int32_t start, int32_t end)
+{
+    emit_ctx *E = (emit_ctx *)ctx;
+    printf("%i\t %i\t %i\t %s\n", E->k++, start, end, E->G->finfo[idx].fileName);          /* :577,:610 */
+}
+
 static int32_t one_enumerate(char *chrm, int32_t qs, int32_t qe)
 {
     int32_t ichr = get_id(chrm);
     if (ichr < 0) return 0;
+    if (g_core && cur_igd()) {                                /* `-r ... -f`: the interval's own tiles, on the host */
+        const iGD_t *G = cur_igd();
+        const int32_t n1 = qs / G->nbp;
+        const int fd = one_query_fd();
+        if (fd >= 0) {
+            if (n1 > G->nTile[ichr] - 1 || n1 < 0) { close(fd); return 0; }              /* :544-545 */
+            g_core->nFiles = G->nFiles;
+            printf("Query %s, %i, %i: \n", chrm, qs, qe);                                 /* :548 */
+            emit_ctx E;
+            E.k = 0; E.G = G;
+            const int64_t n = igdc_walk_one(g_core, fd, ichr, qs, qe, 0, 0, IGD_HIP_RULE_NEST, NULL, emit_line, &E);
+            close(fd);
+            if (n >= 0) return (int32_t)n;
+        }
+    }
     igdc_queries q;
     memset(&q, 0, sizeof q);
     igdc_queries_push(&q, ichr, qs, qe);

@@ -217,6 +217,50 @@ int igdc_attach_fp(igdc_db *db, FILE *fp, int device)
     return rc;
 }
 
+/* ---- one interval on the host (igd_core.h: igdc_walk_one) -------------------------------- */
+int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32_t qe, int32_t v, int use_v, int rule,
+                      int64_t *hits, igdc_emit_fn emit, void *ctx)
+{
+    if (!db || fd < 0 || ichr < 0 || ichr >= db->nCtg) return 0;           /* :456-457 */
+    const int32_t nbp = db->nbp, mT = db->nTile[ichr] - 1;
+    const int32_t n1 = qs / nbp;                                           /* C division, as :459 */
+    int32_t n2 = (int32_t)((uint32_t)qe - 1u) / nbp;                       /* (qe-1)/nbp with the reference's wrap */
+    if (n1 < 0 || n1 > mT) return 0;                                       /* n1 < 0: out of bounds in the reference */
+    if (n2 > mT) n2 = mT;
+    if (rule == IGD_HIP_RULE_NEST && db->nCnt[ichr][n1] == 0) return 0;    /* :468 */
+    const size_t recBytes = db->gType == 0 ? 12 : 16;
+    if (db->gType == 0) use_v = 0;
+    int64_t total = 0;
+    int32_t *buf = NULL;
+    size_t cap = 0;
+    for (int32_t j = n1; j <= (n2 > n1 ? n2 : n1); j++) {
+        const int32_t cnt = db->nCnt[ichr][j];
+        if (cnt <= 0) continue;
+        const size_t bytes = (size_t)cnt * recBytes;
+        if (bytes > cap) { free(buf); buf = (int32_t *)malloc(bytes); cap = bytes; if (!buf) return -1; }
+        size_t done = 0;
+        while (done < bytes) {
+            ssize_t got = pread(fd, (char *)buf + done, bytes - done, (off_t)(db->tIdx[ichr][j] + (int64_t)done));
+            if (got <= 0) { free(buf); return -1; }
+            done += (size_t)got;
+        }
+        /* later tiles skip the records that start before the tile: they were met in an earlier tile (:510-511) */
+        const int64_t lob = j == n1 ? INT64_MIN : (int64_t)(int32_t)((uint32_t)nbp * (uint32_t)j);
+        const size_t w = recBytes / 4;
+        for (int32_t i = cnt - 1; i >= 0; i--) {                           /* the reverse scans of :489-493, :522-526 */
+            const int32_t *r = buf + (size_t)i * w;                        /* idx, start, end[, value] (src/igd_base.h:41-52) */
+            if (r[1] < qe && (int64_t)r[1] >= lob && r[2] > qs && (!use_v || r[3] >= v)) {
+                if (r[0] < 0 || r[0] >= db->nFiles) continue;              /* the reference indexes hits[] unchecked (:491) */
+                if (hits) hits[r[0]]++;
+                if (emit) emit(ctx, r[0], r[1], r[2]);
+                total++;
+            }
+        }
+    }
+    free(buf);
+    return total;
+}
+
 /* ---- multi-GPU in one process ----------------------------------------------------------- */
 void igd_hip_set_error_(const char *msg);      /* libigd_hip.so: sets the calling thread's igd_hip_last_error() text */
 int igdc_devices_from_env(int *devices, int max)

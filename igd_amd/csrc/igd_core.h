@@ -70,6 +70,19 @@ int igdc_search_multi(igdc_db *db, const int32_t *ichr, const int32_t *qs, const
 /* "0,1,2" -> devices[]; returns the count (0 when the variable is unset or empty) */
 int igdc_devices_from_env(int *devices, int max);
 
+/* ONE query interval without the GPU.  The reference answers `-r` / get_overlaps() by reading the one to few tiles the
+ * interval touches (fseek/fread of cnt records, src/igd_search.c:469-476) -- a few KB -- while putting the database on
+ * the GPU means uploading all of it (851 MB at roadmap scale) for a single wave's work: for the single-interval entry
+ * points of the three flavours (`igd search -r`, get_overlaps*, search_1) the host therefore reads those tiles itself
+ * (pread) and counts.  Batches -- query files, search_n -- never come here: they have no CPU path.
+ * Semantics = the engine's (and the reference's, src/igd_search.c:454-534 / :623-694 / :30-112): rule NEST or FLAT,
+ * hits are the records with lob <= start < qe && end > qs [&& value >= v], lob = the tile's start in later tiles.
+ * `emit` (may be NULL) is called per overlap in the reference's -f order (tiles ascending, record index descending).
+ * Returns the number of overlaps, or -1 on an I/O error. */
+typedef void (*igdc_emit_fn)(void *ctx, int32_t idx, int32_t start, int32_t end);
+int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32_t qe, int32_t v, int use_v, int rule,
+                      int64_t *hits, igdc_emit_fn emit, void *ctx);
+
 /* BED line -> (contig, start, end).  Mutates `line`.  require_chr=1 is the CLI rule
  * (name starts with "chr", shorter than 40, end > 0: src/igd_base.c:69); require_chr=0 is
  * the rule of the Python/R forks (>= 3 fields: src_py/igd_base.c:44). */

@@ -164,6 +164,7 @@ struct DbView {
     const int32_t *tileBd;                      // [nT] tile start coordinate j*nbp (INT_MIN for j==0)
     const int32_t *ctgBase;                     // [nCtg] global tile id of the contig's tile 0
     const int32_t *ctgNTile;                    // [nCtg]
+    const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
 };
 
 struct igd_hip_db {
@@ -178,7 +179,8 @@ struct igd_hip_db {
     uint32_t *d_pxv;
     bool packed, packedV;         // compact image usable (nbp<=32768, nFiles<=65536) / values fit int16
     int64_t *d_tileOff;
-    int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile;
+    int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_tileUnit0;
+    int32_t *d_heavy;             // [IGD_HEAVY_MAX] tiles of the batch with more pairs than a wave should take alone
     Unit *d_units;
     int32_t nUnits;
     int64_t resident;
@@ -302,6 +304,12 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define CTL_UNSORTED 1
 #define CTL_BROKEN 2
 #define CTL_NOTSTART 3   // epoch of the last batch whose queries were ordered by tile but NOT by start inside a tile
+#define CTL_NHEAVY 10    // + (epoch & 1): tiles of the batch listed for igd_scan_heavy (bucket path)
+#define IGD_HEAVY_PAIRS 2048   // a tile with more (query, tile) pairs than this is shared out in slices of that many
+#define IGD_HEAVY_MAX 4096     // listed heavy tiles per batch (a further one stays with its own wave)
+#define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for igd_sorted_heavy (merge join)
+#define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
+#define IGD_HEAVY_SLICE 4096
 #define CTL_NLONG 4
 #define CTL_NFIX 6
 #define CTL_BUDGET 8
@@ -383,6 +391,8 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
     }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
@@ -538,6 +548,8 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
     }
     if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     if (i >= nq) return;
@@ -590,6 +602,8 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
             ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
             ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
             ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
         }
     }
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
@@ -679,7 +693,8 @@ __global__ __launch_bounds__(1024) void k_split_totals(const uint32_t *__restric
 __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
                                                       const SpTuple *__restrict__ reg, const int32_t *__restrict__ totals,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
-                                                      int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate)
+                                                      int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
+                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
 {
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
     extern __shared__ uint32_t sp_lds[];
@@ -726,7 +741,15 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
         for (int k = 0; k < per; k++) {
             const uint32_t c = cnt[f0 + k];
             start[f0 + k] = run;
-            if (t0 + f0 + k < nT) { pairN[t0 + f0 + k] = (int32_t)c; pairPos[t0 + f0 + k] = (int32_t)(run + c); }
+            if (t0 + f0 + k < nT) {
+                pairPos[t0 + f0 + k] = (int32_t)(run + c);
+                int32_t pn = (int32_t)c;
+                if (heavy && c > IGD_HEAVY_PAIRS) {       // too many pairs for one wave: igd_scan_heavy shares the tile out
+                    const int at = atomicAdd(&ctlw[CTL_NHEAVY + (epoch & 1)], 1);
+                    if (at < IGD_HEAVY_MAX) { heavy[at] = t0 + f0 + k; pn = -pn; }   // negative: "not yours" for igd_scan_tiles
+                }
+                pairN[t0 + f0 + k] = pn;
+            }
             run += c;
         }
     }
@@ -962,6 +985,7 @@ struct ScanArgs {
     int mode;                    // 0: device decides (ctl[CTL_UNSORTED]); 1: sorted promised; 2: bucket
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *total;                  // k_exact_walk: batch total (may be null)
+    u64 *hitsOut;                // the caller's hits[] (the skew kernels add to it directly)
 };
 
 // Issue the loads of unit kk.  BRANCH-FREE on purpose: every call issues exactly the same
@@ -1267,6 +1291,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
                     }
                 } else if (L.n > 0) {
                     Lr0 = a.pairN[L.tile];
+                    if (Lr0 < 0) Lr0 = 0;                 // listed for igd_scan_heavy
                     Lr1 = a.pairPos[L.tile];
                 }
             }
@@ -1293,6 +1318,70 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
         __syncthreads();
         u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
         for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// igd_scan_heavy: the bucket path's skew valve.  The tile chunk is the unit of work, so a batch whose queries pile
+// up in a few tiles (10^6 unordered queries in ONE tile: 62 ms) would be serialised on the waves that own them.
+// k_split_fine lists the tiles with more than IGD_HEAVY_PAIRS pairs and hides them from igd_scan_tiles (negative
+// pair count); here every (unit of the tile, slice of IGD_HEAVY_PAIRS pairs) is one work item, dealt round-robin to
+// all waves of the grid, compared exactly like any other unit (compute_unit) and counted into the workgroup's LDS
+// counters, which are then added to hits[] (and the batch total).  Returns at once when nothing was listed.
+template <bool USE_V, bool LDS_HITS>
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_heavy(DbView db, ScanArgs a, const int32_t *__restrict__ heavy,
+                                                                  u64 *__restrict__ d_hits, u64 *__restrict__ d_total)
+{
+    int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVY + (a.epoch & 1)]);
+    if (nH == 0) return;
+    if (nH > IGD_HEAVY_MAX) nH = IGD_HEAVY_MAX;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *hits = LDS_HITS ? (u64 *)smem : d_hits;
+    if (LDS_HITS) {
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int gwave = blockIdx.x * (IGD_WG / IGD_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nwaves = gridDim.x * (IGD_WG / IGD_WAVE);
+    long long base = 0;
+    for (int h = 0; h < nH; h++) {
+        const int t = __builtin_amdgcn_readfirstlane(heavy[h]);
+        const int np = -__builtin_amdgcn_readfirstlane(a.pairN[t]);
+        const int pend = __builtin_amdgcn_readfirstlane(a.pairPos[t]);
+        const int u0 = __builtin_amdgcn_readfirstlane(db.tileUnit0[t]), nu = __builtin_amdgcn_readfirstlane(db.tileUnit0[t + 1]) - u0;
+        const int ns = (np + IGD_HEAVY_PAIRS - 1) / IGD_HEAVY_PAIRS;
+        const long long items = (long long)nu * ns;
+        long long it = ((long long)gwave - base % nwaves + nwaves) % nwaves;     // this wave's first item of the tile
+        for (; it < items; it += nwaves) {
+            const int u = u0 + (int)(it % nu), sl = (int)(it / nu);
+            const int p1 = sl * IGD_HEAVY_PAIRS + IGD_HEAVY_PAIRS < np ? sl * IGD_HEAVY_PAIRS + IGD_HEAVY_PAIRS : np;
+            const UnitRegs L = load_unit_regs(db.units + u);                      // the same unit in every lane
+            const int Lr0 = p1 - sl * IGD_HEAVY_PAIRS, Lr1 = pend - np + p1;      // pairs of the slice, end of the slice
+            Raw A;
+            issue_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A);
+            compute_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A, hits);
+        }
+        base += items;
+    }
+    if (LDS_HITS) {
+        __syncthreads();
+        __shared__ u64 red[IGD_WG / IGD_WAVE];
+        u64 s = 0;
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) {
+            const u64 c = hits[f];
+            if (c) { atomicAdd(&d_hits[f], c); s += c; }
+        }
+        if (d_total) {
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) red[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u64 tsum = 0;
+                for (int w = 0; w < IGD_WG / IGD_WAVE; w++) tsum += red[w];
+                if (tsum) atomicAdd(d_total, tsum);
+            }
+        }
     }
 }
 
@@ -1335,6 +1424,7 @@ struct SortArgs {
     const int32_t *ctl;
     int nq, v, epoch, mode, rule;
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
+    int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to igd_sorted_heavy
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
@@ -1736,6 +1826,12 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
                     L.f0 = a.firstQ[u.tile];
                     L.c0 = a.firstQ[u.tile + 1] - L.f0;
                     if (a.spill[u.tile] == a.epoch) L.cl = L.f0 - a.firstQ[u.tile - lb];
+                    // a tile with very many first-tile queries is shared out over all waves (igd_sorted_heavy); its own
+                    // waves keep the later-tile candidates.  (<= 2^24 queries per batch: at most 2047 such tiles.)
+                    if (L.c0 > IGD_HEAVY_FIRST) {
+                        if (u.jf & 1) a.heavyS[atomicAdd(&a.ctlw[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
+                        L.c0 = 0;
+                    }
                 }
             }
         }
@@ -1780,6 +1876,80 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
         o[0] = t_start; o[1] = t_desc; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
     }
 #endif
+}
+
+// igd_sorted_heavy: the merge join's skew valve.  A tile with more than IGD_HEAVY_FIRST first-tile queries (10^6 ordered
+// queries inside ONE tile would keep one wave busy for 9 ms) is listed by igd_scan_sorted and left out there; here every
+// (unit of the tile, slice of IGD_HEAVY_SLICE queries) is one work item, dealt round-robin to all waves of the grid
+// -- the rank method is a sum over queries, so slices simply add up -- and counted into the workgroup's LDS counters,
+// which are then added to hits[] (and the batch total).  Returns at once when nothing was listed.
+template <bool USE_V, bool LDS_HITS, bool BIG>
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(DbView db, SortArgs a, u64 *__restrict__ d_hits, u64 *__restrict__ d_total)
+{
+    if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;
+    const int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVYS + (a.epoch & 1)]);
+    if (nH == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const size_t hitBytes = LDS_HITS ? (((size_t)db.nFiles * 8 + 15) & ~(size_t)15) : 0;
+    u64 *hits = LDS_HITS ? (u64 *)smem : d_hits;
+    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)a.wldsBytes);
+    unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
+    unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
+    for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
+    for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
+    if (LDS_HITS) {
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
+        __syncthreads();
+    }
+    const bool rankOK = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NOTSTART]) != a.epoch;
+    const int gwave = blockIdx.x * (IGD_WG / IGD_WAVE) + wid;
+    const int nwaves = gridDim.x * (IGD_WG / IGD_WAVE);
+    long long base = 0;
+    for (int h = 0; h < nH; h++) {
+        const int t = __builtin_amdgcn_readfirstlane(a.heavyS[h]);
+        const int f0 = __builtin_amdgcn_readfirstlane(a.firstQ[t]);
+        const int c0 = __builtin_amdgcn_readfirstlane(a.firstQ[t + 1]) - f0;
+        const int u0 = __builtin_amdgcn_readfirstlane(db.tileUnit0[t]), nu = __builtin_amdgcn_readfirstlane(db.tileUnit0[t + 1]) - u0;
+        const int ns = (c0 + IGD_HEAVY_SLICE - 1) / IGD_HEAVY_SLICE;
+        const long long items = (long long)nu * ns;
+        long long it = ((long long)gwave - base % nwaves + nwaves) % nwaves;     // this wave's first item of the tile
+        for (; it < items; it += nwaves) {
+            const int u = u0 + (int)(it % nu), sc = (int)(it / nu);
+            const UnitRegs ur = load_unit_regs(db.units + u);                     // the same unit in every lane
+            SRegs L;
+            L.offLo = ur.offLo; L.offHi = ur.offHi; L.n = ur.n; L.g = ur.tile; L.jf = ur.jf;
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = ur.w[r];
+            L.f0 = f0 + sc * IGD_HEAVY_SLICE;
+            L.c0 = c0 - sc * IGD_HEAVY_SLICE < IGD_HEAVY_SLICE ? c0 - sc * IGD_HEAVY_SLICE : IGD_HEAVY_SLICE;
+            L.cl = 0;
+            Raw2 A;
+            s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
+            s_compute<USE_V, false>(db, a, L, 0, lane, A, hits, sl, hist, sb, rankOK);
+        }
+        base += items;
+    }
+    if (LDS_HITS) {
+        __syncthreads();
+        __shared__ u64 red[IGD_WG / IGD_WAVE];
+        u64 s = 0;
+        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) {
+            const u64 c = hits[f];
+            if (c) { atomicAdd(&d_hits[f], c); s += c; }
+        }
+        if (d_total) {
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) red[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u64 tsum = 0;
+                for (int w = 0; w < IGD_WG / IGD_WAVE; w++) tsum += red[w];
+                if (tsum) atomicAdd(d_total, tsum);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2199,7 +2369,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     if (t_arenaOwner == db) t_arenaOwner = nullptr;
     (void)hipSetDevice(db->device);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
-                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast,
@@ -2306,7 +2476,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     db->nT = (int32_t)nT;
     std::vector<int64_t> tileOff((size_t)nT + 1);
     std::vector<int32_t> tileCnt((size_t)nT + 1), tileBd((size_t)nT + 1), ctgBase((size_t)d->nCtg + 1),
-        ctgNTile((size_t)d->nCtg + 1);
+        ctgNTile((size_t)d->nCtg + 1), tileUnit0((size_t)nT + 1);
     std::vector<Unit> units;
     int64_t off = 0;
     int32_t maxIdxCheck = 0;
@@ -2322,6 +2492,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                 if (cnt > db->maxTileCnt) db->maxTileCnt = cnt;
                 tileOff[t] = off;
                 tileCnt[t] = cnt;
+                tileUnit0[t] = (int32_t)units.size();
                 // tile start coordinate; computed with wrap like `bd` at src/igd_search.c:496,529
                 tileBd[t] = (j == 0) ? INT_MIN : (int32_t)((uint32_t)d->nbp * (uint32_t)j);
                 for (int32_t r0 = 0; r0 < cnt || r0 == 0; r0 += IGD_CHUNK) {
@@ -2341,6 +2512,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             }
         }
         tileOff[nT] = off;
+        tileUnit0[nT] = (int32_t)units.size();
     }
     if (off != d->nRecords) {
         snprintf(g_err, sizeof g_err, "igd_hip_open: nRecords %lld != sum(nCnt) %lld",
@@ -2381,7 +2553,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 72 * ((size_t)nT + 2) + sizeof(Unit) * units.size() +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + sizeof(Unit) * units.size() + 8 * IGD_HEAVY_MAX +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -2398,6 +2570,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_tileBd, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_ctgBase, (size_t)d->nCtg + 1, acct));
     TRY(dalloc(&db->d_ctgNTile, (size_t)d->nCtg + 1, acct));
+    TRY(dalloc(&db->d_tileUnit0, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_heavy, 2 * IGD_HEAVY_MAX, acct));   // bucket path's list, merge join's list
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -2414,6 +2588,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRYHIP(hipMemcpy(db->d_tileBd, tileBd.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgBase, ctgBase.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
+    TRYHIP(hipMemcpy(db->d_tileUnit0, tileUnit0.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     if (!units.empty())
         TRYHIP(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(Unit), hipMemcpyHostToDevice));
     OPEN_PHASE("other table copies");
@@ -2517,6 +2692,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                                  (const void *)igd_scan_tiles<false, false, true, true>, (const void *)igd_scan_tiles<false, true, true, true>};
             for (const void *fn : fns)
                 TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_heavy<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_heavy<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
         }
     }
     if (db->ldsSorted > 64 * 1024) {
@@ -2524,6 +2701,9 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                              (const void *)igd_scan_sorted<false, true, true, false>, (const void *)igd_scan_sorted<true, true, true, false>,
                              (const void *)igd_scan_sorted<false, true, false, true>, (const void *)igd_scan_sorted<true, true, false, true>};
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
+        const void *hfn[] = {(const void *)igd_sorted_heavy<false, true, false>, (const void *)igd_sorted_heavy<true, true, false>,
+                             (const void *)igd_sorted_heavy<false, true, true>, (const void *)igd_sorted_heavy<true, true, true>};
+        for (const void *fn : hfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
     }
 #undef TRY
 #undef TRYHIP
@@ -2536,7 +2716,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
     v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
-    v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile;
+    v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile; v.tileUnit0 = db->d_tileUnit0;
     OPEN_PHASE("idx check, slab");
     // compact image (see k_pack_units): needs tile-relative offsets and idx to fit 16 bits
     db->packed = db->nbp <= 32768 && db->nFiles <= 65536 && db->nRec > 0 && !getenv("IGD_HIP_NO_PACK");
@@ -2655,7 +2835,7 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
     k_split_fine<<<db->spCoarse, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
                                                                           db->d_spT, db->d_spBase,
                                                                           db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs,
-                                                                          db->d_ctl, gate);
+                                                                          db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
@@ -2670,6 +2850,7 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         sa.blockLast = db->d_blockLast;
         sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
         sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
+        sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
         sa.stamps = nullptr;
 #if IGD_EXP & 32
         {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -2688,6 +2869,10 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
         else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
         else igd_scan_sorted<USE_V, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
+        if (a.nq > IGD_HEAVY_FIRST) {                    // a smaller batch cannot hold a tile that igd_scan_sorted would list
+            if (big) igd_sorted_heavy<USE_V, LDS_HITS, true><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa, (u64 *)a.hitsOut, a.total);
+            else igd_sorted_heavy<USE_V, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa, (u64 *)a.hitsOut, a.total);
+        }
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
@@ -2760,11 +2945,15 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     ScanArgs a;
     a.firstQ = db->d_firstQ; a.pairN = db->d_pairN; a.pairPos = db->d_pairPos; a.pairs = (const int2 *)db->d_pairs;
     a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe; a.q_w = db->d_qw;
-    a.total = (u64 *)d_total;
+    a.total = (u64 *)d_total; a.hitsOut = (u64 *)d_hits;
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     if (db->ldsHits) {
         a.out = db->d_slab;
         launch_scan_any<true>(db, a, useV, packed, st);
+        if (mode != 1 && packed && db->spShift >= 0) {     // tiles the bucket grouping found too heavy for one wave
+            if (useV) igd_scan_heavy<true, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, (u64 *)d_total);
+            else igd_scan_heavy<false, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, (u64 *)d_total);
+        }
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         {   // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
@@ -2781,6 +2970,10 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         a.out = (u64 *)d_hits;
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
         launch_scan_any<false>(db, a, useV, packed, st);
+        if (mode != 1 && packed && db->spShift >= 0) {
+            if (useV) igd_scan_heavy<true, false><<<db->grid, IGD_WG, 0, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, nullptr);
+            else igd_scan_heavy<false, false><<<db->grid, IGD_WG, 0, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, nullptr);
+        }
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         {   // total is taken from the growth of sum(hits) here (k_sum_hits), not by the walk
             ScanArgs w = a;
@@ -2942,7 +3135,7 @@ static int ensure_enum_workspace(igd_hip_db *db, int64_t nq, int64_t chunkHits, 
     return IGD_HIP_OK;
 }
 
-#define IGD_ENUM_CHUNK_HITS ((int64_t)4 << 20)     // 64 MiB of igd_hip_hit per chunk buffer
+#define IGD_ENUM_CHUNK_HITS ((int64_t)2 << 20)     // 32 MiB of igd_hip_hit per chunk buffer (pinning memory costs ~0.3 ms per MiB)
 
 // whole != nullptr: the chunks are copied straight to their place in `whole` (pinned, qoff[nq] records);
 // otherwise every chunk is handed to `sink` from one of the two pinned chunk buffers.
@@ -3456,9 +3649,9 @@ __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, co
                     if (cl) np = (u64)(f0 - firstQ[un.tile - (lb ? 1 : 0)]);   // the previous tile's queries: read as later candidates
                     if (rankOK && c0 >= IGD_DENSE_MIN) nd = (u64)c0;
                 }
-            } else if (pairN[un.tile] > 0) {
+            } else if (pairN[un.tile] != 0) {             // negative: the tile went to igd_scan_heavy
                 nu = 1; nr = (u64)un.n;
-                if (firstUnit) np = (u64)pairN[un.tile];
+                if (firstUnit) np = (u64)(pairN[un.tile] < 0 ? -pairN[un.tile] : pairN[un.tile]);
             }
         }
     }

@@ -3,8 +3,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sysexits.h>
+#include <unistd.h>
 
 #include "igdr_abi.h"
 #include "igd_core.h"
@@ -103,12 +105,26 @@ void get_overlaps32(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int32_t *hit
     igdr_search_n32(iGD, 1, &name, &qs, &qe, hits);
 }
 
+/* One interval on a database that is opened for just this call (IGDr/R/IGDr.R search_1 via .C): the host reads the
+ * interval's own tiles (igdc_walk_one) -- the reference reads them too (IGDr/src/igd_search.c:25-103) -- instead of
+ * uploading the whole database to the GPU for a single query. */
 void search_1(char **igdFile, char **qchr, int32_t *qs, int32_t *qe, int64_t *hits)
 {
-    iGD_t *h = open_iGD(*igdFile);
-    if (!h) return;
-    get_overlaps(h, *qchr, *qs, *qe, hits);
-    close_iGD(h);
+    igdc_db *core = igdc_open(*igdFile);
+    if (!core) {
+        printf("Can't open file %s", *igdFile);
+        return;
+    }
+    char *tsv = igdc_index_path(*igdFile);
+    if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
+    free(tsv);
+    const int32_t id = igdc_get_id(core, *qchr);
+    const int fd = id >= 0 ? open(*igdFile, O_RDONLY) : -1;
+    if (fd >= 0) {
+        (void)igdc_walk_one(core, fd, id, *qs, *qe, 0, 0, IGD_HIP_RULE_NEST, hits, NULL, NULL);
+        close(fd);
+    }
+    igdc_close(core);
 }
 
 void getOverlaps(char **igdFile, char **qFile, int64_t *hits)

@@ -134,7 +134,7 @@ int  igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs,
 void igd_hip_free(void *p);
 
 /* The same enumeration, STREAMED: the overlaps are produced in chunks of contiguous query ranges
- * (<= 64 MiB of records each, a whole query never split) and each chunk is handed to `sink` from
+ * (<= 32 MiB of records each, a whole query never split) and each chunk is handed to `sink` from
  * pinned host memory while the next chunks are being filled and copied -- the caller (the command
  * line tool's formatter, getOverlaps_f1 src/igd_search.c:721-744) works on chunk k while chunk k+1
  * crosses PCIe.  qoff[0..nq] is complete before the first sink call; a chunk covers queries [q0,q1),

@@ -109,8 +109,8 @@ def test_config5_enumeration_of_all_queries_streamed_equals_counts_and_whole_arr
     qoff2, rec = db.enumerate(ichr, qs, qe)
     np.testing.assert_array_equal(qoff2, qoff)
     crc, qa, nch = 0, 0, 0
-    while qa < Q:                                   # same chunking rule: longest query range within 4 Mi overlaps
-        qb = max(qa + 1, int(np.searchsorted(qoff, qoff[qa] + (4 << 20), side="right")) - 1)
+    while qa < Q:                                   # same chunking rule: longest query range within 2 Mi overlaps
+        qb = max(qa + 1, int(np.searchsorted(qoff, qoff[qa] + (2 << 20), side="right")) - 1)
         crc = (crc * 31 + int(rec[qoff[qa]:qoff[qb]].astype(np.int64).sum())) & 0xFFFFFFFFFFFF
         qa, nch = qb, nch + 1
     assert nch == seen["chunks"] and crc == seen["crc"]

@@ -1,0 +1,67 @@
+"""Skew: batches whose queries pile up in very few tiles.  The tile chunk is the unit of work, so without a valve
+such a batch is serialised on the waves that own those tiles (10^6 unordered queries inside ONE tile took 62 ms).
+Unordered batches: k_split_fine lists the heavy tiles and igd_scan_heavy shares them out in slices over all waves;
+ordered batches: the merge join's rank method is linear in the queries.  Counts must not change -- checked against the
+oracle on a sample and between the engine's paths on the whole batch -- and the time must stay in the milliseconds."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from helpers import Oracle
+
+pytestmark = pytest.mark.gpu
+PATH = "/tmp/igdb/rm1900x26316.igd"
+
+
+@pytest.fixture(scope="module")
+def big():
+    from igd_amd import Database, synth
+    if not (os.path.exists(PATH) and os.path.exists(PATH + ".done")):
+        os.makedirs(os.path.dirname(PATH), exist_ok=True)
+        synth.make_db(PATH, files=1900, per_file=26316, seed=1000, nbp_log=14, genome=synth.HG38)
+        open(PATH + ".done", "w").write("ok")
+    db = Database(PATH)
+    yield db
+    db.close()
+
+
+@pytest.mark.parametrize("span_tiles,limit_ms", [(1, 8.0), (10, 8.0), (1000, 8.0)])
+def test_piled_up_queries_are_shared_out(big, span_tiles, limit_ms):
+    import torch
+    db = big
+    rng = np.random.default_rng(5 + span_tiles)
+    Q = 1000000
+    qs = (50_000_000 + rng.integers(0, 16384 * span_tiles, Q)).astype(np.int32)
+    qe = (qs + rng.integers(100, 2000, Q)).astype(np.int32)
+    qe[::1000] = qs[::1000] - 5                      # a few inverted ones
+    ichr = np.zeros(Q, np.int32)
+    order = np.argsort(qs, kind="stable")
+    want, wtot = db.search(ichr[order], qs[order], qe[order], flags=1)       # ordered: merge join + rank method
+    o = Oracle(PATH)
+    idx = np.arange(0, Q, 500)
+    ow, _ = o.search(ichr[idx], qs[idx], qe[idx], 0)
+    np.testing.assert_array_equal(db.search(ichr[idx], qs[idx], qe[idx], flags=2)[0], ow)
+    np.testing.assert_array_equal(db.search(ichr[np.sort(idx)], np.sort(qs[idx]), qe[idx][np.argsort(qs[idx], kind="stable")], flags=1)[0], ow)
+    o.close()
+    dev = torch.device("cuda", 0)
+    d = [torch.from_numpy(a).to(dev) for a in (ichr, qs, qe)]
+    ds = [torch.from_numpy(np.ascontiguousarray(a[order])).to(dev) for a in (ichr, qs, qe)]
+    hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        for arrs, flags, name in ((d, 8, "unordered, device decides"), (d, 8 | 2, "bucket path"), (ds, 8 | 1, "ordered")):
+            for _ in range(2):
+                db.search_dev(arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), Q, hits.data_ptr(), None,
+                              stream=st.cuda_stream, flags=flags)
+            st.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                db.search_dev(arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), Q, hits.data_ptr(), None,
+                              stream=st.cuda_stream, flags=flags)
+            db.sync(st.cuda_stream)
+            ms = (time.perf_counter() - t) / 5 * 1e3
+            np.testing.assert_array_equal(hits.cpu().numpy(), want, err_msg=name)
+            assert ms < limit_ms, "%s: %.2f ms per batch of 10^6 queries inside %d tile(s)" % (name, ms, span_tiles)
+            print("%-28s inside %4d tiles: %.3f ms" % (name, span_tiles, ms))

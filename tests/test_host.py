@@ -296,3 +296,94 @@ def test_create_without_gpu_fails_loudly_and_leaves_no_database(N):
         assert not os.path.exists(d + "/out/db.igd")
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# --------------------------------------------------------------------------------------------
+# single intervals are answered on the host from the interval's own tiles (no database upload)
+def _golden_r_runs():
+    out = []
+    for fam in ("edge", "quirk", "gtype0"):
+        man = json.load(open(os.path.join(GOLDEN, fam, "manifest.json")))
+        for k, run in enumerate(man["runs"]):
+            if "-r" in run["args"]:
+                out.append((fam, k))
+    return out
+
+
+@pytest.mark.parametrize("fam,k", _golden_r_runs())
+def test_single_region_runs_print_what_the_reference_printed_without_a_gpu(fam, k):
+    """`igd search db -r chr s e [-v N] [-f]`: byte-identical to the reference's stdout (tests/golden), read from the
+    interval's own tiles by the host (igdc_walk_one) -- this runs on the GPU-less build container."""
+    man = json.load(open(os.path.join(GOLDEN, fam, "manifest.json")))
+    run = man["runs"][k]
+    args = [os.path.join(GOLDEN, fam, a) if a in ("db.igd", "q.bed") else a for a in run["args"]]
+    p = subprocess.run([os.path.join(ROOT, "bin", "igd")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-300:]
+    assert p.stdout.decode() == open(os.path.join(GOLDEN, fam, run["stdout"])).read(), run["args"]
+    assert b"GPU" not in p.stderr
+
+
+def test_single_interval_walk_equals_oracle_on_random_intervals(N):
+    """igdc_walk_one (host, product code) against the oracle on random single intervals incl. inverted, zero-length,
+    multi-tile and out-of-range ones, both rules, with and without the value filter."""
+    L = N.cli()
+    L.igdc_walk_one.restype = C.c_int64
+    L.igdc_walk_one.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int,
+                                N.i64p, C.c_void_p, C.c_void_p]
+    rng = random.Random(5)
+    for fam in ("smallrand", "quirk", "gtype0", "edge"):
+        path = os.path.join(GOLDEN, fam, "db.igd")
+        core = L.igdc_open(path.encode())
+        tsv = L.igdc_index_path(path.encode())
+        assert L.igdc_load_index(core, C.cast(tsv, C.c_char_p)) == 0
+        N.free(tsv)
+        o = Oracle(path)
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            nbp, nctg = core.contents.nbp, core.contents.nCtg
+            for _ in range(400):
+                c = rng.randrange(-1, nctg + 1)
+                span = nbp * (core.contents.nTile[c] if 0 <= c < nctg else 4)
+                qs = rng.randrange(-nbp, span + 2 * nbp)
+                qe = qs + rng.choice([0, 1, 50, nbp // 3, nbp, 3 * nbp + 7, 9 * nbp, -rng.randint(1, 300)])
+                for v in (0, 300):
+                    want, wtot = o.search(np.array([c], np.int32), np.array([qs], np.int32), np.array([qe], np.int32), v)
+                    hits = np.zeros(max(o.nfiles, 1), np.int64)
+                    use_v = 1 if (v > 0 and o.gtype == 1) else 0           # the CLI dispatch (src/igd_search.c:1023-1030)
+                    rule = 1 if use_v else 0
+                    if qs <= -nbp:
+                        continue                                           # n1 < 0: out-of-bounds read in the reference
+                    got = L.igdc_walk_one(core, fd, c, qs, qe, v, use_v, rule, hits.ctypes.data_as(N.i64p), None, None)
+                    assert got == wtot, (fam, c, qs, qe, v)
+                    np.testing.assert_array_equal(hits[:o.nfiles], want)
+        finally:
+            os.close(fd)
+            o.close()
+            L.igdc_close(core)
+
+
+def test_r_flavour_search_1_needs_no_gpu(N):
+    """IGDr's .C entry point search_1(igdFile, chr, start, end, hits): one interval on a database opened for the call --
+    answered from its own tiles on the host, equal to the oracle's counts (and so to the reference's, see the goldens)."""
+    R = N.rabi()
+    path = os.path.join(GOLDEN, "smallrand", "db.igd")
+    o = Oracle(path)
+    try:
+        for chrom, s_, e_ in (("chr1", 1000, 90000), ("chr2", 100000, 260000), ("chr9", 5, 50), ("chr1", 70000, 70000)):
+            h = np.zeros(o.nfiles + 1, np.int64)
+            a, b = (C.c_char_p * 1)(path.encode()), (C.c_char_p * 1)(chrom.encode())
+            cs, ce = C.c_int32(s_), C.c_int32(e_)
+            R.search_1(a, b, C.byref(cs), C.byref(ce), h.ctypes.data_as(N.i64p))
+            cid = o.contig_id(chrom) if hasattr(o, "contig_id") else None
+            ichr = np.array([cid if cid is not None else -1], np.int32)
+            if cid is None:
+                import ctypes
+                L = N.cli()
+                core = L.igdc_open(path.encode())
+                ichr[0] = L.igdc_get_id(core, chrom.encode())
+                L.igdc_close(core)
+            want, _ = o.search(ichr, np.array([s_], np.int32), np.array([e_], np.int32), 0)
+            np.testing.assert_array_equal(h[:o.nfiles], want)
+        assert R.igd_engine_status() == 0
+    finally:
+        o.close()
