@@ -88,6 +88,9 @@ typedef unsigned long long u64;
 #ifndef IGD_EXP
 #define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 32 time stamps
 #endif
+#ifndef IGD_NT_AUX
+#define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
+#endif
 #ifndef IGD_OPT_PRIO
 #define IGD_OPT_PRIO 1 // igd_scan_sorted: waves lower their issue priority as they get through their share
 #endif
@@ -310,6 +313,7 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for igd_sorted_heavy (merge join)
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
+#define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to igd_sorted_heavy
 #define CTL_NLONG 4
 #define CTL_NFIX 6
 #define CTL_BUDGET 8
@@ -396,9 +400,10 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
-    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.  A plain
-    // (L1-cached, possibly stale) load: this is only a shortcut.
-    if (__builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) == epoch) return;
+    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.  A device-scope
+    // load: an L1-cached one would keep returning the stale line and the whole unordered batch would be worked
+    // through, gap filling included (5 -> 50 us).
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
     int qc[VEC], qs_[VEC], qe_[VEC];
     if (VEC == 4) {
         int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
@@ -417,12 +422,14 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     int pc = -1, ps = INT_MIN, prevKey = -1;
     if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; prevKey = tile_key(db, pc, ps); }
     int w0v[VEC], w1v[VEC];
+    const bool marked = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;   // by another wave, meanwhile
     int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
-    bool unordered = false;
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
         int lo = 0, hi = -1;                                // this query fills firstQ[lo..hi] = i
+        int kNow = 0, sNow = 0;
+        bool unordered = false, notStart = false;
         w0v[v] = packed ? 0 : -1; w1v[v] = 0;
         if (i < nq) {
             const int c = qc[v], s0 = qs_[v];
@@ -432,14 +439,30 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
             // key(i): global number of the first tile, clamped into the contig (tile_key)
             const int n1c = n1r < 0 ? 0 : (n1r > cMT ? cMT : n1r);
             const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cBase + n1c);
-            if (k < prevKey) {
-                ctl[CTL_UNSORTED] = epoch;
-                if (promised) ctl[CTL_BROKEN] = epoch;      // sticky until the next igd_hip_sync (any promised batch since)
-                unordered = true;
-            }
-            // ordered by tile but not by start inside a tile: the merge join still holds, the rank method does not
-            if (k == prevKey && s0 < ps) ctl[CTL_NOTSTART] = epoch;
+            unordered = k < prevKey;
+            notStart = k == prevKey && s0 < ps;
             lo = prevKey + 1; hi = k;
+            kNow = k; sNow = s0;
+        }
+        // One lane per wave reports (hundreds of thousands of stores to ONE address would queue up for tens of
+        // microseconds), and a wave that has seen disorder leaves: nothing it would still produce is going to be read.
+        {
+            const unsigned long long bu = __ballot(unordered), bs = __ballot(notStart);
+            if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
+                                                                                // the merge join still holds, the rank method does not
+            if (bu) {
+                if (!marked && lane == __builtin_ctzll(bu)) {
+                    ctl[CTL_UNSORTED] = epoch;
+                    if (promised) ctl[CTL_BROKEN] = epoch;  // sticky until the next igd_hip_sync (any promised batch since)
+                }
+                return;
+            }
+        }
+        if (i < nq) {
+            const int c = qc[v], s0 = qs_[v];
+            const bool cOk = c >= 0 && c < db.nCtg;
+            const int cBase = cOk ? QB_BASE(c) : 0, cMT = cOk ? QB_NTILE(c) - 1 : 0;
+            const int n1r = tile_of(db, s0);
             if (cOk && n1r >= 0 && n1r <= cMT) {
                 const int n1 = n1r, e0 = qe_[v];
                 int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
@@ -467,15 +490,15 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                     }
                 }
             }
-            prevKey = k; ps = s0;
         }
+        if (i < nq) { prevKey = kNow; ps = sNow; }
         // firstQ: short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
         // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
         // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
         // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
         // A wave that sees disorder among its own queries, or finds the batch already marked, fills
         // nothing: firstQ[] is not going to be used.
-        const bool disorder = __ballot(unordered) != 0 || ctl[CTL_UNSORTED] == epoch;
+        const bool disorder = marked;                       // (a wave that saw disorder itself has left above)
         const bool big = hi - lo >= 8;
         if (!big && !disorder) for (int tt = lo; tt <= hi; tt++) firstQ[tt] = i;
         unsigned long long m = disorder ? 0ull : __ballot(big);
@@ -1429,6 +1452,20 @@ struct SortArgs {
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
 
+// The two merge-join kernels take ONE argument struct, and read everything their inner loop does not need -- a dozen
+// pointers of the rarer paths -- from the kernel-argument segment WHERE it is needed (KARG): with 8 waves per SIMD a
+// wave has 80 scalar registers, and values loaded at kernel entry would sit in (or be spilled from) them all along.
+struct SortK { DbView db; SortArgs a; u64 *hitsOut, *totalOut; };
+typedef const __attribute__((address_space(4))) char *karg_ptr;
+template <typename T>
+__device__ __forceinline__ T karg_load(unsigned off)
+{
+    karg_ptr p = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                           // opaque: the scalar load below stays in the branch it is written in
+    return *(const __attribute__((address_space(4))) T *)(p + off);
+}
+#define KARG(field) karg_load<decltype(((SortK *)0)->field)>((unsigned)offsetof(SortK, field))
+
 // A unit's descriptor and query ranges, one unit per lane (broadcast with v_readlane when its turn comes)
 struct SRegs { int32_t offLo, offHi, n, g /* global tile */, jf, w[IGD_SLOTS], f0, c0, cl; };
 
@@ -1464,15 +1501,15 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + off), 0, n * 4, 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);
-                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4, r * 256, 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, IGD_NT_AUX);
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4, r * 256, IGD_NT_AUX);
             }
         } else {
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + off), 0, n * 2, 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, 0);
-                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2, r * 128, 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4, r * 256, IGD_NT_AUX);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2, r * 128, IGD_NT_AUX);
             }
         }
     } else {
@@ -1482,15 +1519,15 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, (int)((unsigned)end * 4u), 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
-                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
+                R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
             }
         } else {
             const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, (int)((unsigned)end * 2u), 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
-                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, (int)(offLo * 2u), 0);
+                R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
+                R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, (int)(offLo * 2u), IGD_NT_AUX);
             }
         }
     }
@@ -1536,13 +1573,13 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
 }
 
 // later-tile candidate word qw1 -> compare word for this tile (IGD_NEVER when the query does not reach it)
-__device__ __forceinline__ int later_word(const DbView &db, int q1, int g, int deadk, bool &covers)
+__device__ __forceinline__ int later_word(int nbp, int q1, int g, int deadk, bool &covers)
 {
     const int k = (g - ((q1 >> 22) & 3)) & 3;            // tiles between the query's first tile and this one (1..3)
     // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); deadk bit k = tile j-k is empty
     covers = ((q1 >> 24) & 1) && k != 0 && ((q1 >> 20) & 3) >= k && !((deadk >> k) & 1);
-    int rel = (q1 & 0xFFFFF) - __mul24(k, db.nbp);       // qe - T for this tile
-    rel = (rel < db.nbp ? rel : db.nbp) + 1;             // qe'
+    int rel = (q1 & 0xFFFFF) - __mul24(k, nbp);          // qe - T for this tile
+    rel = (rel < nbp ? rel : nbp) + 1;                   // qe'
     return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
 }
 
@@ -1571,26 +1608,31 @@ __device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key
 // The later-tile candidates of a unit: queries [fl, f0) of the (up to) 3 tiles before its tile, visited in the 64-query
 // blocks k_query_bounds summarised (blockLast): a block none of whose queries reaches this tile is skipped unread.
 // FN(word, covers) is called once per visited block with every lane's compare word (IGD_NEVER where !covers).
-template <typename FN>
+template <bool KA, typename FN>
 __device__ __forceinline__ void for_later_blocks(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane, FN fn)
 {
+    const int32_t *blockLast = KA ? KARG(a.blockLast) : a.blockLast, *qw1 = KA ? KARG(a.qw1) : a.qw1;
+    const int nbp = KA ? KARG(db.nbp) : db.nbp;
     const int b0 = fl >> 6, nb = ((f0 - 1) >> 6) - b0 + 1;
     for (int bb = 0; bb < nb; bb += IGD_WAVE) {
-        const int bl = (bb + lane < nb) ? a.blockLast[b0 + bb + lane] : -1;
+        const int bl = (bb + lane < nb) ? blockLast[b0 + bb + lane] : -1;
         unsigned long long bm = __ballot(bl >= g);
         while (bm) {
             const int j = __builtin_ctzll(bm);
             bm &= ~(1ull << j);
             const int i = ((b0 + bb + j) << 6) + lane;
-            const int q1 = (i >= fl && i < f0) ? a.qw1[i] : 0;
+            const int q1 = (i >= fl && i < f0) ? qw1[i] : 0;
             bool covers;
-            const int w = later_word(db, q1, g, deadk, covers);
+            const int w = later_word(nbp, q1, g, deadk, covers);
             fn(w, covers);
         }
     }
 }
 
-template <bool USE_V, bool CNT32>
+// RANK = false: the lean build for batches that are sparse on average (the host decides by queries per tile): no rank
+// method in the kernel at all -- its registers would burden the pairwise path, which is what such a batch runs --
+// and a tile that is dense after all goes to igd_sorted_heavy from IGD_LEAN_FIRST first-tile queries on.
+template <bool USE_V, bool CNT32, bool RANK>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK)
 {
@@ -1619,7 +1661,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     int g = 0, deadk = 0;
     if (cl) {
         g = __builtin_amdgcn_readlane(L.g, kk);
-        deadk = a.rule == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
+        deadk = (RANK ? KARG(a.rule) : a.rule) == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
     }
 #if IGD_EXP & 4
     {
@@ -1629,7 +1671,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         return;
     }
 #endif
-    if (!(rankOK && c0 >= IGD_DENSE_MIN)) {
+    if (!RANK || !(rankOK && c0 >= IGD_DENSE_MIN)) {
         // ---- pairwise ---------------------------------------------------------------------------
         if (USE_V) {
 #pragma unroll
@@ -1641,7 +1683,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             match_words(R, cnt, W, w);
         }
         if (cl) {
-            for_later_blocks(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+            for_later_blocks<RANK>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
                 nLater += __popcll(__ballot(covers));
                 match_words(R, cnt, W, w);
             });
@@ -1654,13 +1696,14 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
     } else {
         // ---- rank ---------------------------------------------------------------------------------
-        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp);
+        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)KARG(db.nbp));
+        const int32_t *q_qs = KARG(a.q_qs);
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++)
             sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool inLds = c0 <= a.sbCap;                // the tile's query starts fit the wave's LDS array
+        const bool inLds = c0 <= KARG(a.sbCap);          // the tile's query starts fit the wave's LDS array
         int nFirst = 0;
         for (int p = 0; p < c0; p += IGD_WAVE) {
             int w = R.q;
@@ -1676,7 +1719,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                int t = there ? a.q_qs[f0 + p + lane] - T + 1 : 65535;   // = qs' for a query of this tile; beyond it: clamped
+                int t = there ? q_qs[f0 + p + lane] - T + 1 : 65535;   // = qs' for a query of this tile; beyond it: clamped
                 t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
                 qs2 = t;
                 while (x) {
@@ -1698,7 +1741,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (inLds && there) sb[p + lane] = (unsigned short)qs2;
         }
         if (cl)
-            for_later_blocks(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+            for_later_blocks<true>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
                 const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
                 if (covers) atomicAdd(&hist[pos], 1u);
                 nLater += __popcll(__ballot(covers));
@@ -1727,7 +1770,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #pragma unroll
                     for (int r = 0; r < IGD_SLOTS; r++) {
                         const int at = pos[r] + step - 1;
-                        vq[r] = at < c0 ? a.q_qs[f0 + at] : INT_MAX;
+                        vq[r] = at < c0 ? q_qs[f0 + at] : INT_MAX;
                     }
 #pragma unroll
                     for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) + T - 1 ? step : 0;   // qs' <= e'
@@ -1768,26 +1811,39 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 
 // CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
 // reach 2^32); BIG: more than 2^30 records (see s_issue).
-template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG>
-__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, SortArgs a)
+template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK>
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
 {
-    if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;   // not ordered: the bucket path's batch
+    const DbView &db = K.db;
+    const SortArgs &a = K.a;
+    bool rankOK;
+    {
+        const int32_t *ctl = KARG(a.ctl);
+        if (__builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) == a.epoch) return;   // not ordered: the bucket path's batch
+        rankOK = __builtin_amdgcn_readfirstlane(ctl[CTL_NOTSTART]) != a.epoch;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t hitBytes = LDS_HITS ? (((size_t)db.nFiles * (CNT32 ? 4 : 8) + 15) & ~(size_t)15) : 0;
-    u64 *hits = LDS_HITS ? (u64 *)smem : a.out;
-    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)a.wldsBytes);
+    u64 *hits;
+    unsigned short *sl;
+    {
+        const int nFiles = KARG(db.nFiles);
+        const size_t hitBytes = LDS_HITS ? (((size_t)nFiles * (CNT32 ? 4 : 8) + 15) & ~(size_t)15) : 0;
+        hits = LDS_HITS ? (u64 *)smem : KARG(a.out);
+        sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)KARG(a.wldsBytes));
+        if (LDS_HITS) {
+            if (CNT32) for (int f = threadIdx.x; f < nFiles; f += IGD_WG) ((unsigned int *)hits)[f] = 0u;
+            else for (int f = threadIdx.x; f < nFiles; f += IGD_WG) hits[f] = 0;
+        }
+    }
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
     unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
-    for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
-    for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
-    if (LDS_HITS) {
-        if (CNT32) for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) ((unsigned int *)hits)[f] = 0u;
-        else for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
-        __syncthreads();
+    if (RANK) {
+        for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
+        for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     }
-    const bool rankOK = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NOTSTART]) != a.epoch;
+    if (LDS_HITS) __syncthreads();
     const int wavesPerWG = IGD_WG / IGD_WAVE;
     const int gwave = blockIdx.x * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
@@ -1815,7 +1871,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
         {
             const long long mi = (long long)ub + (long long)lane * nwaves;
             if (mi < db.nUnits) {
-                const UnitRegs u = load_unit_regs(db.units + mi);
+                const Unit *units = KARG(db.units);
+                const int32_t *firstQ = KARG(a.firstQ), *spill = KARG(a.spill);
+                const UnitRegs u = load_unit_regs(units + mi);
                 L.offLo = u.offLo; L.offHi = u.offHi; L.jf = u.jf;
                 L.n = u.n; L.g = u.tile;
 #pragma unroll
@@ -1823,13 +1881,13 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
                 if (u.n > 0) {
                     const int lj = u.jf >> 4;
                     const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
-                    L.f0 = a.firstQ[u.tile];
-                    L.c0 = a.firstQ[u.tile + 1] - L.f0;
-                    if (a.spill[u.tile] == a.epoch) L.cl = L.f0 - a.firstQ[u.tile - lb];
+                    L.f0 = firstQ[u.tile];
+                    L.c0 = firstQ[u.tile + 1] - L.f0;
+                    if (spill[u.tile] == a.epoch) L.cl = L.f0 - firstQ[u.tile - lb];
                     // a tile with very many first-tile queries is shared out over all waves (igd_sorted_heavy); its own
                     // waves keep the later-tile candidates.  (<= 2^24 queries per batch: at most 2047 such tiles.)
-                    if (L.c0 > IGD_HEAVY_FIRST) {
-                        if (u.jf & 1) a.heavyS[atomicAdd(&a.ctlw[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
+                    if (L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST)) {
+                        if (u.jf & 1) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
                         L.c0 = 0;
                     }
                 }
@@ -1846,9 +1904,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
+            s_compute<USE_V, CNT32, RANK>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
             s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
@@ -1866,13 +1924,14 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
 #endif
     if (LDS_HITS) {
         __syncthreads();
-        u64 *row = a.out + (size_t)blockIdx.x * db.nFiles;
-        if (CNT32) for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = (u64)((unsigned int *)hits)[f];
-        else for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) row[f] = hits[f];
+        const int nFiles = KARG(db.nFiles);
+        u64 *row = KARG(a.out) + (size_t)blockIdx.x * nFiles;
+        if (CNT32) for (int f = threadIdx.x; f < nFiles; f += IGD_WG) row[f] = (u64)((unsigned int *)hits)[f];
+        else for (int f = threadIdx.x; f < nFiles; f += IGD_WG) row[f] = hits[f];
     }
 #if IGD_EXP & 32
-    if (a.stamps && lane == 0) {
-        u64 *o = a.stamps + (size_t)gwave * 5;
+    if (KARG(a.stamps) && lane == 0) {
+        u64 *o = KARG(a.stamps) + (size_t)gwave * 5;
         o[0] = t_start; o[1] = t_desc; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
     }
 #endif
@@ -1884,8 +1943,11 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(DbView db, So
 // -- the rank method is a sum over queries, so slices simply add up -- and counted into the workgroup's LDS counters,
 // which are then added to hits[] (and the batch total).  Returns at once when nothing was listed.
 template <bool USE_V, bool LDS_HITS, bool BIG>
-__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(DbView db, SortArgs a, u64 *__restrict__ d_hits, u64 *__restrict__ d_total)
+__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(SortK K)
 {
+    const DbView &db = K.db;
+    const SortArgs &a = K.a;
+    u64 *d_hits = K.hitsOut, *d_total = K.totalOut;
     if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;
     const int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVYS + (a.epoch & 1)]);
     if (nH == 0) return;
@@ -1927,7 +1989,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(DbView db, S
             L.cl = 0;
             Raw2 A;
             s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
-            s_compute<USE_V, false>(db, a, L, 0, lane, A, hits, sl, hist, sb, rankOK);
+            s_compute<USE_V, false, true>(db, a, L, 0, lane, A, hits, sl, hist, sb, rankOK);
         }
         base += items;
     }
@@ -2538,7 +2600,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
             const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0;
-            int spare = (80 * 1024 - 512 - hitB) / (IGD_WG / IGD_WAVE) - IGD_WLDS_BYTES;
+            int spare = (160 * 1024 / ((IGD_WPE * 256) / IGD_WG) - 512 - hitB) / (IGD_WG / IGD_WAVE) - IGD_WLDS_BYTES;
             db->sbCap = spare < 128 ? 0 : (spare / 2 > 2048 ? 2048 : (spare / 2) & ~63);
             db->ldsSorted = hitB + (IGD_WG / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
         }
@@ -2697,9 +2759,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
     }
     if (db->ldsSorted > 64 * 1024) {
-        const void *sfn[] = {(const void *)igd_scan_sorted<false, true, false, false>, (const void *)igd_scan_sorted<true, true, false, false>,
-                             (const void *)igd_scan_sorted<false, true, true, false>, (const void *)igd_scan_sorted<true, true, true, false>,
-                             (const void *)igd_scan_sorted<false, true, false, true>, (const void *)igd_scan_sorted<true, true, false, true>};
+        const void *sfn[] = {(const void *)igd_scan_sorted<false, true, false, false, true>, (const void *)igd_scan_sorted<true, true, false, false, true>,
+                             (const void *)igd_scan_sorted<false, true, true, false, true>, (const void *)igd_scan_sorted<true, true, true, false, true>,
+                             (const void *)igd_scan_sorted<false, true, false, false, false>, (const void *)igd_scan_sorted<true, true, false, false, false>,
+                             (const void *)igd_scan_sorted<false, true, true, false, false>, (const void *)igd_scan_sorted<true, true, true, false, false>,
+                             (const void *)igd_scan_sorted<false, true, false, true, true>, (const void *)igd_scan_sorted<true, true, false, true, true>};
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
         const void *hfn[] = {(const void *)igd_sorted_heavy<false, true, false>, (const void *)igd_sorted_heavy<true, true, false>,
                              (const void *)igd_sorted_heavy<false, true, true>, (const void *)igd_sorted_heavy<true, true, true>};
@@ -2866,12 +2930,21 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const bool cnt32 = IGD_OPT_CNT32 && LDS_HITS && (int64_t)a.nq * IGD_SHORT_TILES * (unitsPerTile > 0 ? unitsPerTile : 1) * IGD_CHUNK < (1ll << 32);
         const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
-        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
-        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
-        else igd_scan_sorted<USE_V, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa);
-        if (a.nq > IGD_HEAVY_FIRST) {                    // a smaller batch cannot hold a tile that igd_scan_sorted would list
-            if (big) igd_sorted_heavy<USE_V, LDS_HITS, true><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa, (u64 *)a.hitsOut, a.total);
-            else igd_sorted_heavy<USE_V, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(db->v, sa, (u64 *)a.hitsOut, a.total);
+        SortK K;
+        K.db = db->v; K.a = sa; K.hitsOut = (u64 *)a.hitsOut; K.totalOut = a.total;
+        // sparse on average (fewer than 8 queries per tile): the lean build, whose pairwise path is not burdened with the rank
+        // method's registers; tiles that are dense all the same go to igd_sorted_heavy
+        const char *fr = getenv("IGD_HIP_RANK");          // tests: 0 lean, 1 full
+        const int forceRank = fr && *fr ? atoi(fr) : -1;
+        const bool lean = forceRank >= 0 ? forceRank == 0 : (int64_t)a.nq < 8ll * db->nT;
+        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        if (a.nq > (lean && !big ? IGD_LEAN_FIRST : IGD_HEAVY_FIRST)) {   // a smaller batch cannot hold a tile that igd_scan_sorted would list
+            if (big) igd_sorted_heavy<USE_V, LDS_HITS, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+            else igd_sorted_heavy<USE_V, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
         }
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
@@ -3745,6 +3818,22 @@ __global__ __launch_bounds__(256) void k_read16(const float4 *__restrict__ in, s
     if (acc == 123.456f) *sink = acc;                       // never true for the zero-filled buffer; keeps the loads
 }
 
+// one 16-byte vector per thread, non-temporal: the plainest streaming copy / read there is
+typedef float igd_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy16_flat(const float4 *__restrict__ in, float4 *__restrict__ outp, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load((const igd_f4 *)in + i), (igd_f4 *)outp + i);
+}
+__global__ __launch_bounds__(256) void k_read16_flat(const float4 *__restrict__ in, size_t n, float *__restrict__ sink)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const igd_f4 a = __builtin_nontemporal_load((const igd_f4 *)in + i);
+        if (a.x + a.y + a.z + a.w == 123.456f) *sink = a.x;
+    }
+}
+
 extern "C" int igd_hip_measure_rates(int device, double rates[4])
 {
     if (!rates) return IGD_HIP_ERR_ARG;
@@ -3766,13 +3855,14 @@ extern "C" int igd_hip_measure_rates(int device, double rates[4])
     if (e == hipSuccess) e = hipMemsetAsync(a, 0, bytes, st);
     if (e == hipSuccess) e = hipMemsetAsync(b, 0, bytes, st);
     if (e == hipSuccess) memset(h, 0, hb);
-    const int grid = 256 * 16, reps = 10;
+    const int grid = 256 * 16, reps = 12;
     for (int which = 0; which < 4 && e == hipSuccess; which++) {
         float best = 1e30f;
         for (int r = 0; r < reps + 2 && e == hipSuccess; r++) {
             e = hipEventRecord(e0, st);
-            if (which == 0) k_copy16<<<grid, 256, 0, st>>>(a, b, n16);
-            else if (which == 1) k_read16<<<grid, 256, 0, st>>>(a, n16, sink);
+            // two shapes of each kernel, alternating: grid-stride with four loads in flight / one float4 per thread; best wins
+            if (which == 0) { if (r & 1) k_copy16_flat<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>(a, b, n16); else k_copy16<<<grid, 256, 0, st>>>(a, b, n16); }
+            else if (which == 1) { if (r & 1) k_read16_flat<<<(unsigned)((n16 + 255) / 256), 256, 0, st>>>(a, n16, sink); else k_read16<<<grid, 256, 0, st>>>(a, n16, sink); }
             else if (which == 2) { if (e == hipSuccess) e = hipMemcpyAsync(h, a, hb, hipMemcpyDeviceToHost, st); }
             else { if (e == hipSuccess) e = hipMemcpyAsync(a, h, hb, hipMemcpyHostToDevice, st); }
             if (e == hipSuccess) e = hipEventRecord(e1, st);
