@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
+    ap.add_argument("--slab-of", type=int, default=0, metavar="G",
+                    help="N=1 only: this GPU's step is slab 0 of a G-GPU config-4 job (G x --queries position-sorted queries) -- "
+                         "what one of G GPUs would run, measured without the other G-1")
     ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
     ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
                     help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
@@ -273,9 +276,11 @@ def extra_configs(db, dev, stream, args, box):
     base = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=True)
     shuf = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=False)
     dense = synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
+    slab8 = synth.make_queries_slab(8 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100),
              ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100),
-             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30)]
+             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30),
+             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30)]
     for name, (ichr, qs, qe), v, gflags, steps in cases:
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags)
@@ -344,7 +349,13 @@ def main():
     t = time.time()
     db = Database(igd_path, device=local)
     open_s = time.time() - t
-    if world == 1:
+    if world == 1 and args.slab_of > 1:
+        Q = args.queries or CONFIG4_PER_GPU
+        ichr, qs, qe = synth.make_queries_slab(args.slab_of * Q, 0, Q, seed=7, genome=synth.HG38)
+        args.shuffled = False
+        wl = ("slab 0 (%d queries) of ONE position-sorted set of %d x %d queries (seed 7): one GPU's share of a %d-GPU config-4 job"
+              % (Q, args.slab_of, Q, args.slab_of))
+    elif world == 1:
         Q = args.queries or 1000000
         ichr, qs, qe = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=not args.shuffled)
         wl = ("%d %s queries per step (seed 7)" % (Q, "generation-order" if args.shuffled else "position-sorted"))

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
             unordered = k < prevKey;
             notStart = k == prevKey && s0 < ps;
             lo = prevKey + 1; hi = k;
+            if (i == 0) lo = hi + 1;                        // the tiles up to the first query's key: filled by the whole grid (below)
             kNow = k; sNow = s0;
         }
         // One lane per wave reports (hundreds of thousands of stores to ONE address would queue up for tens of
@@ -539,10 +540,14 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
         for (int o = 32 / VEC; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
         if ((lane & (IGD_WAVE / VEC - 1)) == 0 && i0 < nq) blockLast[i0 >> 6] = mx;
     }
-    // the tail: tiles after the last query's key (done by the wave of the last query)
-    if (nq > 0 && (nq - 1) / (IGD_WAVE * VEC) == i0 / (IGD_WAVE * VEC)) {
-        const int kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
-        for (int tt = kl + 1 + lane; tt <= db.nT; tt += IGD_WAVE) firstQ[tt] = nq;
+    // head and tail of firstQ[] -- the tiles up to the first query's key and after the last one's, together all the
+    // tiles a batch does not reach (7/8 of them for one GPU's slab of an 8-GPU job) -- are filled by the whole grid:
+    // left to the first / last query's own wave they took longer than everything else in this kernel
+    if (nq > 0) {
+        const int k0 = tile_key(db, ichr[0], qs[0]), kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
+        const int nth = gridDim.x * blockDim.x;
+        for (int tt = t; tt <= k0; tt += nth) firstQ[tt] = 0;
+        for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;
     }
 }
 
@@ -1677,10 +1682,11 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) if (!keep[r]) R.a[r] = 0u;    // the word nothing matches
         }
-        for (int p = 0; p < c0; p += IGD_WAVE) {
-            int w = R.q;
-            if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
+        for (int p = 0, w = R.q; p < c0; p += IGD_WAVE) {
+            // the next 64 words are on their way while these are compared (a dense tile is a chain of such batches)
+            const int wn = (p + IGD_WAVE + lane < c0) ? ~a.qw0[f0 + p + IGD_WAVE + lane] : (int)IGD_NEVER;
             match_words(R, cnt, W, w);
+            w = wn;
         }
         if (cl) {
             for_later_blocks<RANK>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
@@ -1705,9 +1711,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         __builtin_amdgcn_wave_barrier();
         const bool inLds = c0 <= KARG(a.sbCap);          // the tile's query starts fit the wave's LDS array
         int nFirst = 0;
-        for (int p = 0; p < c0; p += IGD_WAVE) {
-            int w = R.q;
-            if (p) w = (p + lane < c0) ? ~a.qw0[f0 + p + lane] : (int)IGD_NEVER;
+        for (int p = 0, wcur = R.q; p < c0; p += IGD_WAVE) {
+            const int w = wcur;
+            wcur = (p + IGD_WAVE + lane < c0) ? ~a.qw0[f0 + p + IGD_WAVE + lane] : (int)IGD_NEVER;   // next batch, in flight meanwhile
             const bool there = p + lane < c0;
             const int qe2 = 65536 - (w & 0xFFFF);
             int qs2 = (int)((unsigned)w >> 16);
@@ -2996,7 +3002,8 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     u64 *zh = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_hits : nullptr;
     u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
     if (mode != 2) {
-        const bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
+        bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
+        if (getenv("IGD_HIP_QB_VEC1")) vec = false;   // A/B
         if (vec)
             k_query_bounds<4><<<(int)((nq + 1023) / 1024), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
                 db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast, mode == 1 ? 1 : 0);

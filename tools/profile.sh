@@ -13,11 +13,11 @@ tag=$1; shift
 root=$PWD
 out=$root/gpurun_out/profile_$tag
 mkdir -p $out
-python3 bench.py "$@" > $out/bench.json 2> $out/bench.err || true
+python3 bench.py --no-extra "$@" > $out/bench.json 2> $out/bench.err || true
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu "$@" > $out/stats.log 2>&1 || true
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu --steps 10 --warmup 2 "$@" > $out/fetch.log 2>&1 || true
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu --steps 10 --warmup 2 "$@" > $out/write.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu --no-extra "$@" > $out/stats.log 2>&1 || true
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu --no-extra --steps 10 --warmup 2 "$@" > $out/fetch.log 2>&1 || true
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu --no-extra --steps 10 --warmup 2 "$@" > $out/write.log 2>&1 || true
 cd $root
 cp $out/stats/*/*_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || true
 cp $out/fetch/*/*_counter_collection.csv $out/pmc_fetch.csv 2>/dev/null || true
@@ -37,7 +37,7 @@ try:
     best = -1
     for k in f:
         # the variant of the timed steps: most launches (set-up code may run another variant once; the gated twin reads ~nothing)
-        if "igd_scan_tiles" in k and f[k] > 1000 and nf[k] > best:
+        if ("igd_scan_sorted" in k or "igd_scan_tiles" in k) and f[k] > 1000 and nf[k] > best:
             best = nf[k]
             res = {"kernel": k, "launches_sampled": nf[k], "FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w.get(k, 0.0),
                    "hbm_bytes_per_launch": int((2 * f[k] + w.get(k, 0.0)) * 1024),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/profile_all.sh -- run ON THE GPU BOX (via gpurun): refreshes every summary kept under profiles/r01/
+# tools/profile_all.sh -- run ON THE GPU BOX (via gpurun): refreshes every summary kept under profiles/rNN/ (tools/collect_profiles.py copies them there)
 python tools/prep.py > gpurun_out/prep.log 2>&1
 bash tools/profile.sh sorted > gpurun_out/p_sorted.log 2>&1
 bash tools/profile.sh auto --grouping auto > gpurun_out/p_auto.log 2>&1
