@@ -1302,6 +1302,14 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
     const int gwave = blockIdx.x * wavesPerWG + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nwaves = gridDim.x * wavesPerWG;
     Raw A, B;
+    // issue-priority balancing between the waves of a SIMD (see igd_scan_sorted): a wave lowers its priority as it
+    // gets through its share, so that the eight waves of a SIMD finish together instead of oldest first
+    const int myUnits = (db.nUnits - gwave + nwaves - 1) / nwaves;
+    const int quarter = (myUnits + 3) >> 2;
+    int prioAt = quarter, prioLevel = 3, done = 0;
+#if IGD_OPT_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
 
     for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
         UnitRegs L;
@@ -1333,11 +1341,31 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
                 compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
                 if (kk + 2 < cntU) issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 2, lane, A);
                 if (kk + 1 < cntU) compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 1, lane, B, hits);
+#if IGD_OPT_PRIO
+                done += 2;
+                if (done >= prioAt) {
+                    prioAt += quarter;
+                    prioLevel--;
+                    if (prioLevel == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (prioLevel == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
             }
         } else {
             for (int kk = 0; kk < cntU; kk++) {
                 issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A);
                 compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
+#if IGD_OPT_PRIO
+                done += 1;
+                if (done >= prioAt) {
+                    prioAt += quarter;
+                    prioLevel--;
+                    if (prioLevel == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (prioLevel == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
             }
         }
     }
