@@ -156,6 +156,7 @@ def hip():
         L.igd_hip_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.igd_hip_profile_end.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                           C.POINTER(C.c_double)]
+        L.igd_hip_profile_sampling.argtypes = [C.c_void_p, C.c_int]
         L.igd_hip_scan_kernel_name.restype = C.c_char_p
         L.igd_hip_seqpare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.igd_hip_create.argtypes = [C.POINTER(HipCreateDesc), C.c_int, C.POINTER(HipCreated)]

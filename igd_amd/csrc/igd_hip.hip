@@ -73,6 +73,7 @@
 #ifndef IGD_REDUCE_GROUPS
 #define IGD_REDUCE_GROUPS 128
 #endif
+#define IGD_PIPE_EVENTS 16                   // profiling: launches whose whole pipeline (not just the scan kernel) is timed
 #define IGD_LDS_HITS_MAX_BYTES (120 * 1024)   // + 37 KiB of rank-method areas (igd_scan_sorted) stays below 160 KiB
 
 typedef unsigned long long u64;
@@ -229,6 +230,7 @@ struct igd_hip_db {
     // profiling
     std::vector<hipEvent_t> ev;   // 4 per launch: pipeline start, scan start, scan stop, pipeline stop
     int evMax, evUsed;
+    int evEvery, evSeen;          // every evEvery-th launch is timed (igd_hip_profile_sampling)
     bool evOn;
 };
 
@@ -3024,8 +3026,11 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     }
     db->epoch++;
     int slot = -1;
-    if (db->evOn && db->evUsed < db->evMax) slot = db->evUsed++;
-    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
+    if (db->evOn && db->evUsed < db->evMax && (db->evSeen++ % (db->evEvery > 0 ? db->evEvery : 1)) == 0) slot = db->evUsed++;
+    // the whole pipeline is bracketed for the first IGD_PIPE_EVENTS launches only: every event is one more packet in the
+    // stream between two kernels, and the scan kernel's own pair is the one every timed launch needs
+    const bool pipeEv = slot >= 0 && slot < IGD_PIPE_EVENTS;
+    if (pipeEv) HIPCHK(hipEventRecord(db->ev[4 * slot + 0], st));
     // IGD_HIP_FLAG_ZERO_FIRST: the first kernel of the batch clears hits[] (and total)
     u64 *zh = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_hits : nullptr;
     u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
@@ -3091,7 +3096,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         }
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
     }
-    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
+    if (pipeEv) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
     if (mode == 1) db->promised = db->epoch;
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
@@ -3931,7 +3936,15 @@ extern "C" int igd_hip_profile_begin(igd_hip_db *db, int max_launches)
     }
     db->evMax = max_launches;
     db->evUsed = 0;
+    db->evSeen = 0;
     db->evOn = true;
+    return IGD_HIP_OK;
+}
+
+extern "C" int igd_hip_profile_sampling(igd_hip_db *db, int every)
+{
+    if (!db || every < 1) return IGD_HIP_ERR_ARG;
+    db->evEvery = every;
     return IGD_HIP_OK;
 }
 
@@ -3942,16 +3955,21 @@ extern "C" int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_
     db->evOn = false;
     int n = db->evUsed;
     double scan = 0, pipe = 0;
+    int npipe = 0;
     for (int i = 0; i < n; i++) {
-        HIPCHK(hipEventSynchronize(db->ev[4 * i + 3]));
+        HIPCHK(hipEventSynchronize(db->ev[4 * i + 2]));
         float a = 0, b = 0;
         HIPCHK(hipEventElapsedTime(&a, db->ev[4 * i + 1], db->ev[4 * i + 2]));
-        HIPCHK(hipEventElapsedTime(&b, db->ev[4 * i + 0], db->ev[4 * i + 3]));
-        scan += a; pipe += b;
+        scan += a;
+        if (i < IGD_PIPE_EVENTS) {
+            HIPCHK(hipEventSynchronize(db->ev[4 * i + 3]));
+            HIPCHK(hipEventElapsedTime(&b, db->ev[4 * i + 0], db->ev[4 * i + 3]));
+            pipe += b; npipe++;
+        }
     }
     if (n_launches) *n_launches = n;
     if (avg_scan_ms) *avg_scan_ms = n ? scan / n : 0.0;
-    if (avg_pipeline_ms) *avg_pipeline_ms = n ? pipe / n : 0.0;
+    if (avg_pipeline_ms) *avg_pipeline_ms = npipe ? pipe / npipe : 0.0;
     db->evUsed = 0;
     return IGD_HIP_OK;
 }

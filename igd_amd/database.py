@@ -215,7 +215,9 @@ class Database:
             b += 4 * stats["H"] + 16 * stats["H"] + 8 * nq
         return b
 
-    def profile_begin(self, max_launches):
+    def profile_begin(self, max_launches, every=1):
+        """Arm HIP-event timing of the scan kernel for up to max_launches launches, every `every`-th one."""
+        _chk(self._H.igd_hip_profile_sampling(self.dev, int(every)), "igd_hip_profile_sampling")
         _chk(self._H.igd_hip_profile_begin(self.dev, int(max_launches)), "igd_hip_profile_begin")
 
     def profile_end(self):

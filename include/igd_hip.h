@@ -224,6 +224,10 @@ int igd_hip_measure_rates(int device, double rates[4]);
 int igd_hip_profile_begin(igd_hip_db *db, int max_launches);
 int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_scan_ms,
                         double *avg_pipeline_ms);
+/* Time only every `every`-th launch (default 1): an event is a packet of its own in the stream between two kernels and
+ * costs the job about as much as a small kernel (10^6-query steps: 104 -> 95 us when the pipeline pair is dropped,
+ * another ~4 us for the scan pair), so a job that is itself being timed samples.  Sticky per database. */
+int igd_hip_profile_sampling(igd_hip_db *db, int every);
 /* Name of the dominant kernel as rocprofv3 --kernel-trace prints it (for profiles/). */
 const char *igd_hip_scan_kernel_name(void);
 
