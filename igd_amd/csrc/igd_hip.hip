@@ -1169,7 +1169,7 @@ __device__ __forceinline__ void match_slots(const Raw &R, int (&cnt)[IGD_SLOTS],
 
 template <bool SORTED, bool USE_V, bool PACKED>
 __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a, const UnitRegs &L, int Lr0,
-                                             int Lr1, int kk, int lane, Raw &R, u64 *hits)
+                                             int Lr1, int kk, int lane, Raw &R, u64 *hits, u64 *found = nullptr)
 {
     const int r0 = __builtin_amdgcn_readlane(Lr0, kk), r1 = __builtin_amdgcn_readlane(Lr1, kk);
     const bool active = SORTED ? (r1 > r0) : (r0 > 0);
@@ -1280,6 +1280,13 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
         const int c = cnt[r];
         if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
     }
+    if (found) {                                         // skew valves: the batch total is kept by the caller of this unit
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) t += cnt[r];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        if (lane == 0 && t) atomicAdd(found, (u64)(unsigned)t);
+    }
 }
 
 // SORTED = true : merge join over the caller's ordered arrays (firstQ[])
@@ -1380,28 +1387,20 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
 }
 
 // ------------------------------------------------------------------------------------------
-// igd_scan_heavy: the bucket path's skew valve.  The tile chunk is the unit of work, so a batch whose queries pile
+// heavy_bucket_body: the bucket path's skew valve.  The tile chunk is the unit of work, so a batch whose queries pile
 // up in a few tiles (10^6 unordered queries in ONE tile: 62 ms) would be serialised on the waves that own them.
 // k_split_fine lists the tiles with more than IGD_HEAVY_PAIRS pairs and hides them from igd_scan_tiles (negative
 // pair count); here every (unit of the tile, slice of IGD_HEAVY_PAIRS pairs) is one work item, dealt round-robin to
-// all waves of the grid, compared exactly like any other unit (compute_unit) and counted into the workgroup's LDS
-// counters, which are then added to hits[] (and the batch total).  Returns at once when nothing was listed.
-template <bool USE_V, bool LDS_HITS>
-__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_heavy(DbView db, ScanArgs a, const int32_t *__restrict__ heavy,
-                                                                  u64 *__restrict__ d_hits, u64 *__restrict__ d_total)
+// all waves of the hosting launch (the batch's last kernel: k_reduce_slabs / k_exact_walk -- a launch of its own would
+// cost every batch 4 us), compared exactly like any other unit (compute_unit) and added to hits[] and the batch
+// total with global atomics.  Nothing listed: one load per wave.
+template <bool USE_V>
+__device__ __forceinline__ void heavy_bucket_body(const DbView &db, const ScanArgs &a, const int32_t *__restrict__ heavy,
+                                                  u64 *__restrict__ d_hits, u64 *__restrict__ d_total, int gwave, int nwaves, int lane)
 {
     int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVY + (a.epoch & 1)]);
     if (nH == 0) return;
     if (nH > IGD_HEAVY_MAX) nH = IGD_HEAVY_MAX;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *hits = LDS_HITS ? (u64 *)smem : d_hits;
-    if (LDS_HITS) {
-        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63;
-    const int gwave = blockIdx.x * (IGD_WG / IGD_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nwaves = gridDim.x * (IGD_WG / IGD_WAVE);
     long long base = 0;
     for (int h = 0; h < nH; h++) {
         const int t = __builtin_amdgcn_readfirstlane(heavy[h]);
@@ -1418,28 +1417,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_heavy(DbView db, Sca
             const int Lr0 = p1 - sl * IGD_HEAVY_PAIRS, Lr1 = pend - np + p1;      // pairs of the slice, end of the slice
             Raw A;
             issue_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A);
-            compute_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A, hits);
+            compute_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A, d_hits, d_total);
         }
         base += items;
-    }
-    if (LDS_HITS) {
-        __syncthreads();
-        __shared__ u64 red[IGD_WG / IGD_WAVE];
-        u64 s = 0;
-        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) {
-            const u64 c = hits[f];
-            if (c) { atomicAdd(&d_hits[f], c); s += c; }
-        }
-        if (d_total) {
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-            if (lane == 0) red[threadIdx.x >> 6] = s;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u64 tsum = 0;
-                for (int w = 0; w < IGD_WG / IGD_WAVE; w++) tsum += red[w];
-                if (tsum) atomicAdd(d_total, tsum);
-            }
-        }
     }
 }
 
@@ -1669,7 +1649,8 @@ __device__ __forceinline__ void for_later_blocks(const DbView &db, const SortArg
 // and a tile that is dense after all goes to igd_sorted_heavy from IGD_LEAN_FIRST first-tile queries on.
 template <bool USE_V, bool CNT32, bool RANK>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
-                                          u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK)
+                                          u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
+                                          u64 *found = nullptr)
 {
     const int c0 = R.c0, cl = R.cl;
     if ((c0 | cl) == 0) return;                          // nobody asks about this unit
@@ -1843,6 +1824,13 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         if (CNT32) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)c);
         else if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
     }
+    if (found) {                                         // skew valve: the batch total is kept by the caller of this unit
+        int t = 0;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) t += cnt[r];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        if (lane == 0 && t) atomicAdd(found, (u64)(unsigned)t);
+    }
 }
 
 // CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
@@ -1973,37 +1961,27 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
 #endif
 }
 
-// igd_sorted_heavy: the merge join's skew valve.  A tile with more than IGD_HEAVY_FIRST first-tile queries (10^6 ordered
-// queries inside ONE tile would keep one wave busy for 9 ms) is listed by igd_scan_sorted and left out there; here every
-// (unit of the tile, slice of IGD_HEAVY_SLICE queries) is one work item, dealt round-robin to all waves of the grid
-// -- the rank method is a sum over queries, so slices simply add up -- and counted into the workgroup's LDS counters,
-// which are then added to hits[] (and the batch total).  Returns at once when nothing was listed.
-template <bool USE_V, bool LDS_HITS, bool BIG>
-__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(SortK K)
+// heavy_sorted_body: the merge join's skew valve.  A tile with more than IGD_HEAVY_FIRST (lean build: IGD_LEAN_FIRST)
+// first-tile queries -- 10^6 ordered queries inside ONE tile would keep one wave busy for 9 ms -- is listed by
+// igd_scan_sorted and left out there; here every (unit of the tile, slice of IGD_HEAVY_SLICE queries) is one work item,
+// dealt round-robin to all waves of the hosting launch (the batch's last kernel) -- the rank method is a sum over
+// queries, so slices simply add up -- and added to hits[] and the batch total with global atomics.  `wsm`: this wave's
+// LDS area for the rank method.  Must sit in a kernel whose FIRST argument is the batch's SortK (KARG).
+template <bool USE_V, bool BIG>
+__device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restrict__ d_hits, u64 *__restrict__ d_total,
+                                                  unsigned char *wsm, int gwave, int nwaves, int lane)
 {
     const DbView &db = K.db;
     const SortArgs &a = K.a;
-    u64 *d_hits = K.hitsOut, *d_total = K.totalOut;
     if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;
     const int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVYS + (a.epoch & 1)]);
     if (nH == 0) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const size_t hitBytes = LDS_HITS ? (((size_t)db.nFiles * 8 + 15) & ~(size_t)15) : 0;
-    u64 *hits = LDS_HITS ? (u64 *)smem : d_hits;
-    unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)a.wldsBytes);
+    unsigned short *sl = (unsigned short *)wsm;
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
     unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
     for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
-    if (LDS_HITS) {
-        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) hits[f] = 0;
-        __syncthreads();
-    }
     const bool rankOK = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NOTSTART]) != a.epoch;
-    const int gwave = blockIdx.x * (IGD_WG / IGD_WAVE) + wid;
-    const int nwaves = gridDim.x * (IGD_WG / IGD_WAVE);
     long long base = 0;
     for (int h = 0; h < nH; h++) {
         const int t = __builtin_amdgcn_readfirstlane(a.heavyS[h]);
@@ -2025,28 +2003,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_sorted_heavy(SortK K)
             L.cl = 0;
             Raw2 A;
             s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
-            s_compute<USE_V, false, true>(db, a, L, 0, lane, A, hits, sl, hist, sb, rankOK);
+            s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
         }
         base += items;
-    }
-    if (LDS_HITS) {
-        __syncthreads();
-        __shared__ u64 red[IGD_WG / IGD_WAVE];
-        u64 s = 0;
-        for (int f = threadIdx.x; f < db.nFiles; f += IGD_WG) {
-            const u64 c = hits[f];
-            if (c) { atomicAdd(&d_hits[f], c); s += c; }
-        }
-        if (d_total) {
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-            if (lane == 0) red[threadIdx.x >> 6] = s;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u64 tsum = 0;
-                for (int w = 0; w < IGD_WG / IGD_WAVE; w++) tsum += red[w];
-                if (tsum) atomicAdd(d_total, tsum);
-            }
-        }
     }
 }
 
@@ -2109,25 +2068,45 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
     if (a.total && lane == 0 && found) atomicAdd(a.total, found);
 }
 
+// The batch's last launch.  Besides its own job it hosts the exact walks and the two skew valves (`valves` bit 0:
+// bucket path, bit 1: merge join; bit 2: BIG image), all of which normally find nothing to do.  SortK comes first:
+// the merge join's code reads its rarer arguments from the kernel-argument segment (KARG).
 template <bool USE_V>
-__global__ __launch_bounds__(256) void k_exact_walk(DbView db, ScanArgs a, const int2 *__restrict__ fixList,
-                                                    const int2 *__restrict__ longList)
+__device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, const int2 *__restrict__ fixList,
+                                           const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves,
+                                           u64 *__restrict__ d_hits, u64 *__restrict__ d_total, unsigned char *smem, int gwave, int nwaves)
 {
+    const int lane = threadIdx.x & 63;
+    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves);
+    if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane);
+    if (valves & 2) {
+        unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
+        if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane);
+        else heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane);
+    }
+}
+
+template <bool USE_V>
+__global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const int2 *__restrict__ fixList,
+                                                    const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    exact_walk_body<USE_V>(db, a, fixList, longList, gwave, gridDim.x * (blockDim.x >> 6));
+    batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6));
 }
 
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
 template <bool USE_V>
-__global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ slab, int rows, int nFiles,
+__global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
                                                       u64 *__restrict__ hits, u64 *__restrict__ total,
-                                                      const int32_t *__restrict__ ctl, int brokenIf, DbView db,
+                                                      const int32_t *__restrict__ ctl, int brokenIf,
                                                       ScanArgs wa, const int2 *__restrict__ fixList,
-                                                      const int2 *__restrict__ longList)
+                                                      const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves)
 {
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
     if (brokenIf != 0 && ctl[CTL_UNSORTED] == brokenIf) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u64 red[4];
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
@@ -2143,11 +2122,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const u64 *__restrict__ sl
             if (t) atomicAdd(total, t);
         }
     }
-    // ... and the batch's exact-walk list (normally empty) rides in the same launch
+    // ... and the batch's exact-walk list and skew valves (normally empty) ride in the same launch
     const int nb = gridDim.x * gridDim.y;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int gwave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    exact_walk_body<USE_V>(db, wa, fixList, longList, gwave, nb * 4);
+    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, hits, total, smem, gwave, nb * 4);
 }
 
 // without LDS counters the batch total is the growth of sum(hits): measured around the launch
@@ -2790,8 +2769,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                                  (const void *)igd_scan_tiles<false, false, true, true>, (const void *)igd_scan_tiles<false, true, true, true>};
             for (const void *fn : fns)
                 TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_heavy<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
-            TRYHIP(hipFuncSetAttribute((const void *)igd_scan_heavy<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
         }
     }
     if (db->ldsSorted > 64 * 1024) {
@@ -2801,9 +2778,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                              (const void *)igd_scan_sorted<false, true, true, false, false>, (const void *)igd_scan_sorted<true, true, true, false, false>,
                              (const void *)igd_scan_sorted<false, true, false, true, true>, (const void *)igd_scan_sorted<true, true, false, true, true>};
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
-        const void *hfn[] = {(const void *)igd_sorted_heavy<false, true, false>, (const void *)igd_sorted_heavy<true, true, false>,
-                             (const void *)igd_sorted_heavy<false, true, true>, (const void *)igd_sorted_heavy<true, true, true>};
-        for (const void *fn : hfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
     }
 #undef TRY
 #undef TRYHIP
@@ -2940,34 +2914,41 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
     return IGD_HIP_OK;
 }
 
+// the merge join's arguments for one batch (also handed to the batch's last launch, which hosts its skew valve)
+static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
+{
+    SortArgs sa;
+    sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.qw1 = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
+    sa.blockLast = db->d_blockLast;
+    sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
+    sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
+    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
+    sa.stamps = nullptr;
+#if IGD_EXP & 32
+    {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
+        static u64 *d_st = nullptr;
+        if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)db->grid * (IGD_WG / IGD_WAVE) * 5 * 8);
+        sa.stamps = d_st;
+        g_stamps = d_st; g_stampWaves = db->grid * (IGD_WG / IGD_WAVE);
+    }
+#endif
+    SortK K;
+    K.db = db->v; K.a = sa; K.hitsOut = (u64 *)a.hitsOut; K.totalOut = a.total;
+    return K;
+}
+
 template <bool USE_V, bool LDS_HITS, bool PACKED>
 static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
 {
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
     if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
-        SortArgs sa;
-        sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.qw1 = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
-        sa.blockLast = db->d_blockLast;
-        sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
-        sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
-        sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
-        sa.stamps = nullptr;
-#if IGD_EXP & 32
-        {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
-            static u64 *d_st = nullptr;
-            if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)db->grid * (IGD_WG / IGD_WAVE) * 5 * 8);
-            sa.stamps = d_st;
-            g_stamps = d_st; g_stampWaves = db->grid * (IGD_WG / IGD_WAVE);
-        }
-#endif
         // 32-bit workgroup counters when nothing can reach 2^32: a record is counted at most once per candidate query of
         // its unit, a query is a candidate in <= IGD_SHORT_TILES tiles, i.e. in <= 4 * (units per tile) units of <= 320 records
         const int64_t unitsPerTile = (db->maxTileCnt + IGD_CHUNK - 1) / IGD_CHUNK;
         const bool cnt32 = IGD_OPT_CNT32 && LDS_HITS && (int64_t)a.nq * IGD_SHORT_TILES * (unitsPerTile > 0 ? unitsPerTile : 1) * IGD_CHUNK < (1ll << 32);
         const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
-        SortK K;
-        K.db = db->v; K.a = sa; K.hitsOut = (u64 *)a.hitsOut; K.totalOut = a.total;
+        const SortK K = make_sortk(db, a);
         // sparse on average (fewer than 8 queries per tile): the lean build, whose pairwise path is not burdened with the rank
         // method's registers; tiles that are dense all the same go to igd_sorted_heavy
         const char *fr = getenv("IGD_HIP_RANK");          // tests: 0 lean, 1 full
@@ -2978,10 +2959,6 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
         else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
         else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
-        if (a.nq > (lean && !big ? IGD_LEAN_FIRST : IGD_HEAVY_FIRST)) {   // a smaller batch cannot hold a tile that igd_scan_sorted would list
-            if (big) igd_sorted_heavy<USE_V, LDS_HITS, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
-            else igd_sorted_heavy<USE_V, LDS_HITS, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
-        }
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
@@ -3060,39 +3037,37 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe; a.q_w = db->d_qw;
     a.total = (u64 *)d_total; a.hitsOut = (u64 *)d_hits;
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
+    // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
+    const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
+                       (db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
+    const size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)(IGD_WLDS_BYTES + 2 * db->sbCap) : 0;
     if (db->ldsHits) {
         a.out = db->d_slab;
+        const SortK K = make_sortk(db, a);
         launch_scan_any<true>(db, a, useV, packed, st);
-        if (mode != 1 && packed && db->spShift >= 0) {     // tiles the bucket grouping found too heavy for one wave
-            if (useV) igd_scan_heavy<true, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, (u64 *)d_total);
-            else igd_scan_heavy<false, true><<<db->grid, IGD_WG, db->ldsBytes, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, (u64 *)d_total);
-        }
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         {   // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
             dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
             if (useV)
-                k_reduce_slabs<true><<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                         db->d_ctl, mode == 1 ? db->epoch : 0, db->v, w, db->d_fix, db->d_long);
+                k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(K, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                                                               db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
             else
-                k_reduce_slabs<false><<<rg, 256, 0, st>>>(db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                          db->d_ctl, mode == 1 ? db->epoch : 0, db->v, w, db->d_fix, db->d_long);
+                k_reduce_slabs<false><<<rg, 256, tailLds, st>>>(K, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
         }
     } else {
         a.out = (u64 *)d_hits;
+        const SortK K = make_sortk(db, a);
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, -1);
         launch_scan_any<false>(db, a, useV, packed, st);
-        if (mode != 1 && packed && db->spShift >= 0) {
-            if (useV) igd_scan_heavy<true, false><<<db->grid, IGD_WG, 0, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, nullptr);
-            else igd_scan_heavy<false, false><<<db->grid, IGD_WG, 0, st>>>(db->v, a, db->d_heavy, (u64 *)d_hits, nullptr);
-        }
         if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
         {   // total is taken from the growth of sum(hits) here (k_sum_hits), not by the walk
             ScanArgs w = a;
             w.total = nullptr;
-            if (useV) k_exact_walk<true><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
-            else k_exact_walk<false><<<256, 256, 0, st>>>(db->v, w, db->d_fix, db->d_long);
+            if (useV) k_exact_walk<true><<<1024, 256, tailLds, st>>>(K, w, db->d_fix, db->d_long, db->d_heavy, valves);
+            else k_exact_walk<false><<<1024, 256, tailLds, st>>>(K, w, db->d_fix, db->d_long, db->d_heavy, valves);
         }
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
     }
