@@ -87,7 +87,7 @@ typedef unsigned long long u64;
 #endif
 
 #ifndef IGD_EXP
-#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 32 time stamps
+#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
@@ -1699,7 +1699,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             match_words(R, cnt, W, w);
             w = wn;
         }
-        if (cl) {
+        if (cl && !(IGD_EXP & 8)) {
             for_later_blocks<RANK>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
                 nLater += __popcll(__ballot(covers));
                 match_words(R, cnt, W, w);
@@ -1757,7 +1757,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             }
             if (inLds && there) sb[p + lane] = (unsigned short)qs2;
         }
-        if (cl)
+        if (cl && !(IGD_EXP & 8))
             for_later_blocks<true>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
                 const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
                 if (covers) atomicAdd(&hist[pos], 1u);
