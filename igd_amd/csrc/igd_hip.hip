@@ -190,12 +190,13 @@ struct igd_hip_db {
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
-    int32_t *d_qw1;               // [wsQueries] later-tile word (compact image only)
+    int32_t *d_qw1;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
     int ldsSorted;                // dynamic LDS of igd_scan_sorted: counters + the waves' rank-method areas
     int32_t maxTileCnt;           // records of the fullest tile
     int sbCap;                    // igd_scan_sorted, rank method: query starts of one tile a wave keeps in LDS
-    int32_t *d_blockLast;         // [wsQueries / 64 + 2] per 64 queries: last tile covered as a later tile
+    int32_t *d_blockLast;         // laterHdr[]: int2 per later block (entries, last tile covered as a later tile)
+    int lbShift;                  // log2(queries per later block) of the batch in flight
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
     int32_t *d_spBase;            // pairs per coarse bucket
@@ -339,6 +340,18 @@ __device__ __forceinline__ int tile_key(const DbView &db, int c, int qs)
     return db.ctgBase[c] + n1;
 }
 
+// inclusive prefix sum over the 64 lanes (DPP: row_shr 1,2,4,8, then row_bcast 15 and 31)
+__device__ __forceinline__ int wave_inclusive_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // The compact query word of k_pack_units' image (defined here because k_query_bounds writes it):
 //     (65536 - qe') | qs' << 16   with   qe' = min(qe - T, W) + 1,   qs' = first ? max(qs - T + 1, 1) : 1
 // A record word matches when both of its 16-bit halves are >= the query's.
@@ -359,13 +372,17 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 //              there (unknown contig, first tile out of range, rule NEST with an empty first tile, or the one case
 //              the image cannot express, listed as WALK_FIRST).  Stored inverted so that a bounds-checked
 //              buffer load past a tile's last query (which returns 0) reads as "never matches".
-//     qw1[i] = 0 unless the query also covers LATER tiles; then  min(qe - T0, 4W)  [bits 0..19]
-//              | min(span, 3) << 20 | (first global tile & 3) << 22 | 1 << 24:  all a later tile needs
-//              (there, qs' = 1 and qe' = min(qeRel - k W, W) + 1; k = (tile - first tile) follows from 2 bits).
+//     later[]: the queries that also cover LATER tiles (6 % of the benchmark's), compacted per "later block" (the
+//              256 * VEC consecutive queries of one workgroup; region [B << lbShift, ...) of the array), in query
+//              order, one word each:  min(qe - T0, 4W) [bits 0..17] | min(span, 3) << 18 | (first global tile & 3) << 20
+//              | (index inside the block) << 22 -- all a later tile needs (there, qs' = 1 and
+//              qe' = min(qeRel - k W, W) + 1; k = (tile - first tile) follows from 2 bits).  Zeros follow the last entry
+//              up to the end of its group of 64 (an entry is never 0): the scan reads a block's first group blind,
+//              together with the unit's records, and goes on while the group it holds is full.
+//     laterHdr[B] = (entries of block B, last tile any of them covers): for the groups after the first and the
+//              blocks before the last -- a block none of whose queries reaches a tile is skipped unread.
 //     spill[t] = epoch for every tile t that some query covers as a later tile (k = 1..3): most units have
 //              none and never look at the queries of the tiles before theirs.
-//     blockLast[i / 64] = the last tile any of the 64 queries covers as a later tile (-1: none): a unit that does
-//              look back skips the 64-query blocks that end before its tile.
 //   exact arrays (packed == 0):
 //     qw0[i] = (global number of the first tile) << 4 | min(n2 - n1, 15), -1 when it visits nothing.
 // VEC queries per thread (4: the three query arrays are read, and the word arrays written, as dwordx4 -- a quarter of
@@ -377,8 +394,8 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       int packed, int32_t *__restrict__ firstQ,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
-                                                      int32_t *__restrict__ qw0, int32_t *__restrict__ qw1,
-                                                      int32_t *__restrict__ spill, int32_t *__restrict__ blockLast, int promised)
+                                                      int32_t *__restrict__ qw0, int32_t *__restrict__ later,
+                                                      int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
@@ -487,7 +504,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                         const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
                         int rel = e0 - T0;                  // > W here, since the query reaches the next tile
                         if (rel > 4 * db.nbp) rel = 4 * db.nbp;
-                        w1v[v] = rel | (sp << 20) | ((g0 & 3) << 22) | (1 << 24);
+                        w1v[v] = rel | (sp << 18) | ((g0 & 3) << 20) | ((int)(threadIdx.x * VEC + v) << 22);
                         for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
                         if (g0 + sp > lastTile) lastTile = g0 + sp;
                     }
@@ -528,19 +545,39 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
 #undef QB_BASE
 #undef QB_NTILE
     if (VEC == 4) {
-        if (i0 + 3 < nq) {
-            *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
-            if (packed) *(int4 *)(qw1 + i0) = make_int4(w1v[0], w1v[1 % VEC], w1v[2 % VEC], w1v[3 % VEC]);
-        } else {
+        if (i0 + 3 < nq) *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
+        else {
 #pragma unroll
             for (int v = 0; v < VEC; v++)
-                if (i0 + v < nq) { qw0[i0 + v] = w0v[v]; if (packed) qw1[i0 + v] = w1v[v]; }
+                if (i0 + v < nq) qw0[i0 + v] = w0v[v];
         }
-    } else if (i0 < nq) { qw0[i0] = w0v[0]; if (packed) qw1[i0] = w1v[0]; }
-    if (packed) {   // per 64 queries: the last tile any of them covers as a later tile (the scan skips the blocks that end before its tile)
+    } else if (i0 < nq) qw0[i0] = w0v[0];
+    if (packed) {
+        // the workgroup's later-tile words, compacted in query order into its block of later[].  (A wave that left above
+        // is not waited for by the barrier -- and nothing of an unordered batch's block is read.)
+        __shared__ int sCnt[4], sMax[4];
+        int c = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) c += w1v[v] != 0 ? 1 : 0;
+        const int inc = wave_inclusive_sum(c);
         int mx = lastTile;
-        for (int o = 32 / VEC; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-        if ((lane & (IGD_WAVE / VEC - 1)) == 0 && i0 < nq) blockLast[i0 >> 6] = mx;
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
+        if (lane == 63) { sCnt[threadIdx.x >> 6] = inc; sMax[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        int off = inc - c, total = 0, bmx = -1;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < (int)(threadIdx.x >> 6)) off += sCnt[w];
+            total += sCnt[w];
+            bmx = sMax[w] > bmx ? sMax[w] : bmx;
+        }
+        int32_t *reg = later + (size_t)blockIdx.x * (256 * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; v++)
+            if (w1v[v] != 0) reg[off++] = w1v[v];
+        const int padEnd = ((total + 64) & ~63) < 256 * VEC ? ((total + 64) & ~63) : 256 * VEC;
+        if (total + (int)threadIdx.x < padEnd) reg[total + threadIdx.x] = 0;
+        if (threadIdx.x == 0) laterHdr[blockIdx.x] = make_int2(total, bmx);
     }
     // head and tail of firstQ[] -- the tiles up to the first query's key and after the last one's, together all the
     // tiles a batch does not reach (7/8 of them for one GPU's slab of an 8-GPU job) -- are filled by the whole grid:
@@ -1456,8 +1493,9 @@ __device__ __forceinline__ void heavy_bucket_body(const DbView &db, const ScanAr
 struct SortArgs {
     const int32_t *firstQ;       // [nT+1] first query of each tile
     const int32_t *spill;        // [nT]   == epoch: some query covers the tile as a later tile
-    const int32_t *qw0, *qw1;    // per-query words (k_query_bounds)
-    const int32_t *blockLast;    // per 64 queries: last tile covered as a later tile
+    const int32_t *qw0, *later;  // per-query first-tile words; later-tile words, compacted per later block (k_query_bounds)
+    const int2 *laterHdr;        // per later block: (entries, last tile covered as a later tile)
+    int lbShift;                 // log2(queries per later block): 10 (k_query_bounds<4>) or 8 (<1>)
     const int32_t *q_qs;         // the caller's query starts (rank method: exceptions, and tiles with more queries than sbCap)
     const int32_t *ctl;
     int nq, v, epoch, mode, rule;
@@ -1488,6 +1526,7 @@ struct Raw2 {
     uint32_t a[IGD_SLOTS];       // s' | e' << 16 (inverted s', see k_pack_units)
     int32_t x[IGD_SLOTS];        // idx (| value << 16)
     int32_t q;                   // first 64 first-tile words (already un-inverted)
+    int32_t lw;                  // first group of later-tile words of the block the tile's predecessors end in (0 = no entry)
     int32_t c0, cl, f0, n;       // wave-uniform (SGPRs): the unit's query ranges and record count, kept from the issue
 };
 
@@ -1546,11 +1585,14 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
             }
         }
     }
-    // the first 64 first-tile words (no memory access when there are none); the later-tile words of the 29 % of the
-    // units that have any are loaded when their turn comes
+    // the first 64 first-tile words (no memory access when there are none), and -- for the 29 % of the units that
+    // have later-tile candidates -- the first group of later-tile words of the block that holds the last of them
     const int b0 = c0 < IGD_WAVE ? c0 : IGD_WAVE;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, (f0 + b0) * 4, 0x00020000);
     R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, vo4, f0 * 4, 0);             // past the last query: ~0 = IGD_NEVER
+    const int lb = (int)((unsigned)((f0 - 1) >> a.lbShift) << a.lbShift);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void *)a.later, 0, cl ? (lb + IGD_WAVE) * 4 : 0, 0x00020000);
+    R.lw = (int)__builtin_amdgcn_raw_buffer_load_b32(rsL, vo4, lb * 4, 0);
 }
 
 // The queries of one batch of <= 64 candidates (word `P0` per lane, IGD_NEVER where there is none) against the
@@ -1587,27 +1629,15 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
     }
 }
 
-// later-tile candidate word qw1 -> compare word for this tile (IGD_NEVER when the query does not reach it)
-__device__ __forceinline__ int later_word(int nbp, int q1, int g, int deadk, bool &covers)
+// later-tile word (k_query_bounds: later[]) -> compare word for this tile (IGD_NEVER when the query does not reach it)
+__device__ __forceinline__ int later_word(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
 {
-    const int k = (g - ((q1 >> 22) & 3)) & 3;            // tiles between the query's first tile and this one (1..3)
+    const int k = (g - ((e >> 20) & 3)) & 3;             // tiles between the query's first tile and this one (1..3)
     // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); deadk bit k = tile j-k is empty
-    covers = ((q1 >> 24) & 1) && k != 0 && ((q1 >> 20) & 3) >= k && !((deadk >> k) & 1);
-    int rel = (q1 & 0xFFFFF) - __mul24(k, nbp);          // qe - T for this tile
+    covers = inRange && k != 0 && ((e >> 18) & 3) >= k && !((deadk >> k) & 1);
+    int rel = (e & 0x3FFFF) - __mul24(k, nbp);           // qe - T for this tile
     rel = (rel < nbp ? rel : nbp) + 1;                   // qe'
     return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
-}
-
-// inclusive prefix sum over the 64 lanes (DPP: row_shr 1,2,4,8, then row_bcast 15 and 31)
-__device__ __forceinline__ int wave_inclusive_sum(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
 }
 
 // #{entries of the wave's sorted s' array that are < key}: 9 dependent LDS reads; entries past the unit's
@@ -1620,27 +1650,55 @@ __device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key
     return pos;
 }
 
-// The later-tile candidates of a unit: queries [fl, f0) of the (up to) 3 tiles before its tile, visited in the 64-query
-// blocks k_query_bounds summarised (blockLast): a block none of whose queries reaches this tile is skipped unread.
-// FN(word, covers) is called once per visited block with every lane's compare word (IGD_NEVER where !covers).
+// The later-tile candidates of a unit: the later[] entries of the queries [fl, f0) of the (up to) 3 tiles before its
+// tile.  They sit in the later block that holds query f0 - 1 -- whose first group of 64 words `lw` came with the unit's
+// records -- and, when the range reaches back across a block boundary, in the blocks before it (read only if the
+// header says one of their queries reaches this tile).  Entries are in query order: the groups in front of the range
+// are skipped by bisection over the groups' last words, the scan ends with the first group that ends beyond it.
+// FN(word, covers) is called once per group that holds a covering query, with every lane's compare word.
 template <bool KA, typename FN>
-__device__ __forceinline__ void for_later_blocks(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane, FN fn)
+__device__ __forceinline__ void for_later_groups(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane,
+                                                 int lw, FN fn)
 {
-    const int32_t *blockLast = KA ? KARG(a.blockLast) : a.blockLast, *qw1 = KA ? KARG(a.qw1) : a.qw1;
+    const int sh = KA ? KARG(a.lbShift) : a.lbShift;
     const int nbp = KA ? KARG(db.nbp) : db.nbp;
-    const int b0 = fl >> 6, nb = ((f0 - 1) >> 6) - b0 + 1;
-    for (int bb = 0; bb < nb; bb += IGD_WAVE) {
-        const int bl = (bb + lane < nb) ? blockLast[b0 + bb + lane] : -1;
-        unsigned long long bm = __ballot(bl >= g);
-        while (bm) {
-            const int j = __builtin_ctzll(bm);
-            bm &= ~(1ull << j);
-            const int i = ((b0 + bb + j) << 6) + lane;
-            const int q1 = (i >= fl && i < f0) ? qw1[i] : 0;
+    const int32_t *later = KA ? KARG(a.later) : a.later;
+    const int blo = fl >> sh;
+    int e = lw;
+    for (int b = (f0 - 1) >> sh;;) {
+        const int base = b << sh;
+        int gi = 0, ng = 0;                               // ng: groups of the block (looked up when the first one is full)
+        for (;;) {
+            const int e63 = __builtin_amdgcn_readlane(e, 63);
+            const bool full = e63 != 0;
+            if (full && base + (int)((unsigned)e63 >> 22) < fl) {
+                // the whole group lies in front of the range: find the first group that does not
+                if (ng == 0) ng = ((KA ? KARG(a.laterHdr) : a.laterHdr)[b].x + 63) >> 6;
+                int lo = gi + 1, hi = ng;                 // the answer is in [lo, hi]; hi = ng: no such group
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int x = later[base + mid * 64 + 63];
+                    if (x != 0 && base + (int)((unsigned)x >> 22) < fl) lo = mid + 1; else hi = mid;
+                }
+                if (lo >= ng) break;
+                gi = lo;
+                e = later[base + gi * 64 + lane];
+                continue;
+            }
+            const int i = base + (int)((unsigned)e >> 22);
             bool covers;
-            const int w = later_word(nbp, q1, g, deadk, covers);
-            fn(w, covers);
+            const int w = later_word(nbp, e, g, deadk, e != 0 && i >= fl && i < f0, covers);
+            if (__ballot(covers)) fn(w, covers);
+            if (!full || base + (int)((unsigned)e63 >> 22) >= f0) break;
+            if (ng == 0) ng = ((KA ? KARG(a.laterHdr) : a.laterHdr)[b].x + 63) >> 6;
+            if (++gi >= ng) break;
+            e = later[base + gi * 64 + lane];
         }
+        const int2 *hdr = KA ? KARG(a.laterHdr) : a.laterHdr;
+        do {
+            if (--b < blo) return;
+        } while (hdr[b].y < g);
+        e = later[(b << sh) + lane];
     }
 }
 
@@ -1700,7 +1758,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             w = wn;
         }
         if (cl && !(IGD_EXP & 8)) {
-            for_later_blocks<RANK>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+            for_later_groups<RANK>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
                 nLater += __popcll(__ballot(covers));
                 match_words(R, cnt, W, w);
             });
@@ -1758,7 +1816,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (inLds && there) sb[p + lane] = (unsigned short)qs2;
         }
         if (cl && !(IGD_EXP & 8))
-            for_later_blocks<true>(db, a, f0 - cl, f0, g, deadk, lane, [&](int w, bool covers) {
+            for_later_groups<true>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
                 const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
                 if (covers) atomicAdd(&hist[pos], 1u);
                 nLater += __popcll(__ballot(covers));
@@ -1835,9 +1893,14 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 
 // CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
 // reach 2^32); BIG: more than 2^30 records (see s_issue).
+#ifndef IGD_WG_RANK
+#define IGD_WG_RANK IGD_WG      // threads per workgroup / waves per SIMD of the full (rank method) build
+#define IGD_WPE_RANK IGD_WPE
+#endif
 template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK>
-__global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
+__global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG, RANK ? IGD_WPE_RANK : IGD_WPE) void igd_scan_sorted(SortK K)
 {
+    constexpr int WGT = RANK ? IGD_WG_RANK : IGD_WG;
     const DbView &db = K.db;
     const SortArgs &a = K.a;
     bool rankOK;
@@ -1857,8 +1920,8 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
         hits = LDS_HITS ? (u64 *)smem : KARG(a.out);
         sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)KARG(a.wldsBytes));
         if (LDS_HITS) {
-            if (CNT32) for (int f = threadIdx.x; f < nFiles; f += IGD_WG) ((unsigned int *)hits)[f] = 0u;
-            else for (int f = threadIdx.x; f < nFiles; f += IGD_WG) hits[f] = 0;
+            if (CNT32) for (int f = threadIdx.x; f < nFiles; f += WGT) ((unsigned int *)hits)[f] = 0u;
+            else for (int f = threadIdx.x; f < nFiles; f += WGT) hits[f] = 0;
         }
     }
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
@@ -1868,7 +1931,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
         for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     }
     if (LDS_HITS) __syncthreads();
-    const int wavesPerWG = IGD_WG / IGD_WAVE;
+    const int wavesPerWG = WGT / IGD_WAVE;
     const int gwave = blockIdx.x * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
     Raw2 A, B;
@@ -1950,8 +2013,8 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_sorted(SortK K)
         __syncthreads();
         const int nFiles = KARG(db.nFiles);
         u64 *row = KARG(a.out) + (size_t)blockIdx.x * nFiles;
-        if (CNT32) for (int f = threadIdx.x; f < nFiles; f += IGD_WG) row[f] = (u64)((unsigned int *)hits)[f];
-        else for (int f = threadIdx.x; f < nFiles; f += IGD_WG) row[f] = hits[f];
+        if (CNT32) for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = (u64)((unsigned int *)hits)[f];
+        else for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = hits[f];
     }
 #if IGD_EXP & 32
     if (KARG(a.stamps) && lane == 0) {
@@ -2843,8 +2906,8 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
         db->wsQueries = 0;
         if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
         if ((rc = dalloc(&db->d_qw, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
-        if ((rc = dalloc(&db->d_qw1, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
-        if ((rc = dalloc(&db->d_blockLast, (size_t)nq / 64 + 2, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_qw1, (size_t)nq + 1024 + 64, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_blockLast, 2 * ((size_t)nq / 256 + 2), nullptr)) != IGD_HIP_OK) return rc;
         db->wsQueries = nq;
     }
     if (pairBytes == 0 || (nq <= db->wsBucket && pairBytes <= db->pairBytes)) return IGD_HIP_OK;
@@ -2918,8 +2981,8 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
 static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
 {
     SortArgs sa;
-    sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.qw1 = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
-    sa.blockLast = db->d_blockLast;
+    sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.later = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
+    sa.laterHdr = (const int2 *)db->d_blockLast; sa.lbShift = db->lbShift;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
     sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
@@ -2954,11 +3017,11 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const char *fr = getenv("IGD_HIP_RANK");          // tests: 0 lean, 1 full
         const int forceRank = fr && *fr ? atoi(fr) : -1;
         const bool lean = forceRank >= 0 ? forceRank == 0 : (int64_t)a.nq < 8ll * db->nT;
-        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
         else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
-        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
-        else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
@@ -3016,10 +3079,11 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         if (getenv("IGD_HIP_QB_VEC1")) vec = false;   // A/B
         if (vec)
             k_query_bounds<4><<<(int)((nq + 1023) / 1024), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast, mode == 1 ? 1 : 0);
+                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, (int2 *)db->d_blockLast, mode == 1 ? 1 : 0);
         else
             k_query_bounds<1><<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast, mode == 1 ? 1 : 0);
+                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, (int2 *)db->d_blockLast, mode == 1 ? 1 : 0);
+        db->lbShift = vec ? 10 : 8;
     }
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
@@ -3717,7 +3781,7 @@ extern "C" int igd_hip_batch_stats(igd_hip_db *db, const int32_t *d_ichr, const 
 // instrumentation: compulsory traffic of the scan kernel for one batch (include/igd_hip.h)
 __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, const int32_t *__restrict__ pairN,
                                const int32_t *__restrict__ spill, int epoch, int path /* 0 bucket, 1 merge join exact, 2 merge join compact */,
-                               int rankOK, u64 *__restrict__ acc /* units, records, pairs | later-range queries, queries of rank-method tiles */)
+                               int rankOK, u64 *__restrict__ acc /* units, records, pairs (bucket path), queries of rank-method tiles */)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     u64 nu = 0, nr = 0, np = 0, nd = 0;
@@ -3734,7 +3798,6 @@ __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, co
                 const int cl = spill[un.tile] == epoch ? f0 - firstQ[un.tile - lb] : 0;
                 if (c0 | cl) { nu = 1; nr = (u64)un.n; }
                 if (firstUnit) {
-                    if (cl) np = (u64)(f0 - firstQ[un.tile - (lb ? 1 : 0)]);   // the previous tile's queries: read as later candidates
                     if (rankOK && c0 >= IGD_DENSE_MIN) nd = (u64)c0;
                 }
             } else if (pairN[un.tile] != 0) {             // negative: the tile went to igd_scan_heavy
@@ -3792,9 +3855,17 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         out->records = (int64_t)acc[1];
         out->record_bytes = (int64_t)acc[1] * recB;
         out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (path == 2 ? 8ll * (db->nT + 1) : sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
-        // merge join, compact image: one 4-byte word per query (qw0), the later-tile words (qw1) of the queries in front of a
-        // marked tile, the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe; bucket path: 8 B per pair
-        out->query_bytes = path == 2 ? 4ll * nq + 4ll * (int64_t)acc[2] + 4ll * (int64_t)acc[3]
+        // merge join, compact image: one 4-byte word per query (qw0), the compacted later-tile words (later[]: every entry is
+        // read at least once), the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe;
+        // bucket path: 8 B per pair
+        int64_t nLaterWords = 0;
+        if (path == 2) {
+            const int64_t nb = (nq + ((int64_t)1 << db->lbShift) - 1) >> db->lbShift;
+            std::vector<int32_t> hdr((size_t)nb * 2);
+            e = hipMemcpy(hdr.data(), db->d_blockLast, (size_t)nb * 8, hipMemcpyDeviceToHost);
+            for (int64_t b = 0; b < nb; b++) nLaterWords += hdr[(size_t)b * 2];
+        }
+        out->query_bytes = path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
                          : path == 1 ? 12ll * nq : 8ll * (int64_t)acc[2];
         out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * 8 : 8ll * db->nFiles;
         out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;
