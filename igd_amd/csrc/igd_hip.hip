@@ -1897,10 +1897,14 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #define IGD_WG_RANK IGD_WG      // threads per workgroup / waves per SIMD of the full (rank method) build
 #define IGD_WPE_RANK IGD_WPE
 #endif
+#ifndef IGD_WG_LEAN
+#define IGD_WG_LEAN IGD_WG      // ... and of the lean build
+#define IGD_WPE_LEAN IGD_WPE
+#endif
 template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK>
-__global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG, RANK ? IGD_WPE_RANK : IGD_WPE) void igd_scan_sorted(SortK K)
+__global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RANK : IGD_WPE_LEAN) void igd_scan_sorted(SortK K)
 {
-    constexpr int WGT = RANK ? IGD_WG_RANK : IGD_WG;
+    constexpr int WGT = RANK ? IGD_WG_RANK : IGD_WG_LEAN;
     const DbView &db = K.db;
     const SortArgs &a = K.a;
     bool rankOK;
@@ -3018,8 +3022,8 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const int forceRank = fr && *fr ? atoi(fr) : -1;
         const bool lean = forceRank >= 0 ? forceRank == 0 : (int64_t)a.nq < 8ll * db->nT;
         if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-        else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
-        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG, ldsS, st>>>(K);
+        else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, ldsS, st>>>(K);
+        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG_LEAN, ldsS, st>>>(K);
         else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
     } else
