@@ -1778,7 +1778,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool inLds = c0 <= KARG(a.sbCap);          // the tile's query starts fit the wave's LDS array
+        const bool inLds = c0 < KARG(a.sbCap);           // the tile's query starts fit the wave's LDS array (a power of two)
         int nFirst = 0;
         for (int p = 0, wcur = R.q; p < c0; p += IGD_WAVE) {
             const int w = wcur;
@@ -1831,13 +1831,17 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
             if (inLds) {
+                // the array is padded to top - 1 entries with 65535 (> every e'): no bounds in the loop, whose five
+                // chains of dependent LDS reads then run side by side
+                for (int k = c0 + lane; k < top - 1; k += IGD_WAVE) sb[k] = 65535;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 for (int step = top >> 1; step > 0; step >>= 1) {
+                    int vq[IGD_SLOTS];
 #pragma unroll
-                    for (int r = 0; r < IGD_SLOTS; r++) {
-                        const int at = pos[r] + step - 1;
-                        const int vq = at < c0 ? (int)sb[at] : 65536;
-                        pos[r] += vq <= (int)(R.a[r] >> 16) ? step : 0;
-                    }
+                    for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)sb[pos[r] + step - 1];
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) ? step : 0;
                 }
             } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
                 for (int step = top >> 1; step > 0; step >>= 1) {
@@ -1893,9 +1897,12 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 
 // CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
 // reach 2^32); BIG: more than 2^30 records (see s_issue).
+// The full (rank method) build wants ~82 VGPRs and ~100 SGPRs: cut to the 64 / 80 of 8 waves per SIMD it spilled 13 + 34 of
+// them; at 6 waves per SIMD (two workgroups of 768) nothing spills -- 1.25e7 queries: 234 -> 210 us, and the pairwise
+// path of this build runs the headline batch in 72 instead of 94 us.  The lean build is as fast at either.
 #ifndef IGD_WG_RANK
-#define IGD_WG_RANK IGD_WG      // threads per workgroup / waves per SIMD of the full (rank method) build
-#define IGD_WPE_RANK IGD_WPE
+#define IGD_WG_RANK 768         // threads per workgroup / waves per SIMD of the full (rank method) build
+#define IGD_WPE_RANK 6
 #endif
 #ifndef IGD_WG_LEAN
 #define IGD_WG_LEAN IGD_WG      // ... and of the lean build
@@ -2683,7 +2690,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
             const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0;
             int spare = (160 * 1024 / ((IGD_WPE * 256) / IGD_WG) - 512 - hitB) / (IGD_WG / IGD_WAVE) - IGD_WLDS_BYTES;
-            db->sbCap = spare < 128 ? 0 : (spare / 2 > 2048 ? 2048 : (spare / 2) & ~63);
+            db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
+            for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
             db->ldsSorted = hitB + (IGD_WG / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
