@@ -2689,10 +2689,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
             const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0;
-            int spare = (160 * 1024 / ((IGD_WPE * 256) / IGD_WG) - 512 - hitB) / (IGD_WG / IGD_WAVE) - IGD_WLDS_BYTES;
+            int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;   // the full build: 2 workgroups per CU
             db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
             for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
-            db->ldsSorted = hitB + (IGD_WG / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
+            db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
