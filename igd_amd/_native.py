@@ -158,6 +158,8 @@ def hip():
                                           C.POINTER(C.c_double)]
         L.igd_hip_profile_sampling.argtypes = [C.c_void_p, C.c_int]
         L.igd_hip_scan_kernel_name.restype = C.c_char_p
+        L.igd_hip_last_scan_kernel.restype = C.c_char_p
+        L.igd_hip_last_scan_kernel.argtypes = [C.c_void_p]
         L.igd_hip_seqpare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
         L.igd_hip_create.argtypes = [C.POINTER(HipCreateDesc), C.c_int, C.POINTER(HipCreated)]
         L.igd_hip_created_free.argtypes = [C.POINTER(HipCreated)]

@@ -197,6 +197,7 @@ struct igd_hip_db {
     int sbCap;                    // igd_scan_sorted, rank method: query starts of one tile a wave keeps in LDS
     int32_t *d_blockLast;         // laterHdr[]: int2 per later block (entries, last tile covered as a later tile)
     int lbShift;                  // log2(queries per later block) of the batch in flight
+    int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
     int32_t *d_spBase;            // pairs per coarse bucket
@@ -2575,7 +2576,19 @@ extern "C" void igd_hip_free(void *p)
     }
     g_pinCache = hdr; g_pinCacheBytes = hdr[0];
 }
-extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_tiles"; }
+extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_sorted"; }
+
+// which scan kernel the last batch of `db` ran on (waits for it: the device decides for an IGD_HIP_FLAG default batch)
+extern "C" const char *igd_hip_last_scan_kernel(igd_hip_db *db)
+{
+    if (!db || db->epoch == 0) return "";
+    if (db->lastMode == 2) return "igd_scan_tiles";
+    int32_t uns = 0;
+    if (hipSetDevice(db->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(&uns, db->d_ctl + CTL_UNSORTED, 4, hipMemcpyDeviceToHost) != hipSuccess) return "";
+    if (uns == db->epoch) return "igd_scan_tiles";       // found unordered: the bucket path's kernel
+    return db->lastPacked ? "igd_scan_sorted" : "igd_scan_tiles";
+}
 
 static double wall_s(void)
 {
@@ -3149,6 +3162,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     }
     if (pipeEv) HIPCHK(hipEventRecord(db->ev[4 * slot + 3], st));
     if (mode == 1) db->promised = db->epoch;
+    db->lastMode = mode; db->lastPacked = packed ? 1 : 0;
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }

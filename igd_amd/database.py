@@ -225,6 +225,10 @@ class Database:
         _chk(self._H.igd_hip_profile_end(self.dev, C.byref(n), C.byref(a), C.byref(b)), "igd_hip_profile_end")
         return dict(launches=n.value, scan_ms=a.value, pipeline_ms=b.value)
 
+    def last_scan_kernel(self):
+        """Name of the scan kernel the last batch ran on ("igd_scan_sorted" / "igd_scan_tiles"); waits for it."""
+        return (self._H.igd_hip_last_scan_kernel(self.dev) or b"").decode()
+
 
 def measure_rates(device=0):
     """GB/s of this box, measured now: HBM float4 copy (read+write), HBM float4 read, pinned D2H, pinned H2D."""

@@ -230,6 +230,9 @@ int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_scan_ms,
 int igd_hip_profile_sampling(igd_hip_db *db, int every);
 /* Name of the dominant kernel as rocprofv3 --kernel-trace prints it (for profiles/). */
 const char *igd_hip_scan_kernel_name(void);
+/* ... and the one the last batch of `db` actually ran on: "igd_scan_sorted" (merge join over the compact image) or
+ * "igd_scan_tiles" (bucket path, exact arrays).  Waits for the batch. */
+const char *igd_hip_last_scan_kernel(igd_hip_db *db);
 
 #ifdef __cplusplus
 }
