@@ -94,3 +94,44 @@ def test_tile_ordered_but_start_unordered_batch_falls_back_to_pairwise(workdir):
             np.testing.assert_array_equal(got, want)
     finally:
         db.close(); orc.close()
+
+
+@pytest.mark.parametrize("build", ["lean", "full"])
+def test_every_query_reaching_into_later_tiles(build, workdir, monkeypatch):
+    """All queries one to three tiles long: every one of them leaves a later-tile word, so k_query_bounds' later
+    blocks are full (1024 entries, 16 groups, no terminating zero) and a unit finds its candidates deep inside a
+    block -- the group bisection and the walk back over block boundaries of for_later_groups -- on aligned
+    (1024-query blocks) and unaligned (256-query blocks) device arrays."""
+    import torch
+    from igd_amd import Database
+    monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")
+    rng = random.Random(4242)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[1]
+    path, ctgs, span = _random_db(rng, workdir, "lt", nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc, db = Oracle(path), Database(path)
+    try:
+        for n in (50000, 3000):                  # dense (rank method in the full build) and sparse
+            ichr, qs, qe = _random_queries(rng, list(range(nctg)), nbp, span, n)
+            lens = np.array([rng.choice([nbp, nbp + 17, 2 * nbp + 5, 3 * nbp - 1]) for _ in range(n)], np.int32)
+            qe = (qs + lens).astype(np.int32)
+            order = np.lexsort((qs, ichr))
+            ichr, qs, qe = ichr[order], qs[order], qe[order]
+            want, wtot = orc.search(ichr, qs, qe, 0)
+            got, gtot = db.search(ichr, qs, qe, 0, flags=FLAG_SORTED)
+            assert gtot == wtot
+            np.testing.assert_array_equal(got, want)
+            # the same batch from device arrays that start 4 bytes off a 16-byte boundary (k_query_bounds<1>)
+            dev = torch.device("cuda:0")
+            buf = [torch.empty(n + 1, dtype=torch.int32, device=dev) for _ in range(3)]
+            for b, a in zip(buf, (ichr, qs, qe)):
+                b[1:].copy_(torch.from_numpy(a))
+            d_hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+            d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
+            db.search_dev(buf[0][1:].data_ptr(), buf[1][1:].data_ptr(), buf[2][1:].data_ptr(), n, d_hits.data_ptr(),
+                          d_tot.data_ptr(), flags=FLAG_SORTED)
+            db.sync()
+            np.testing.assert_array_equal(d_hits.cpu().numpy(), want)
+            assert int(d_tot.item()) == wtot
+    finally:
+        db.close(); orc.close()
