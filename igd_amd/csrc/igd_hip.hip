@@ -87,7 +87,7 @@ typedef unsigned long long u64;
 #endif
 
 #ifndef IGD_EXP
-#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps
+#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps, 64/128/256 rank method without term B / bisections of term A / prefix sums
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
@@ -1788,7 +1788,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             const int qe2 = 65536 - (w & 0xFFFF);
             int qs2 = (int)((unsigned)w >> 16);
             const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;
-            const int pos = lds_lower_bound(sl, qe2);
+            const int pos = (IGD_EXP & 128) ? (qe2 & 255) : lds_lower_bound(sl, qe2);
             if (good) atomicAdd(&hist[pos], 1u);
             nFirst += __popcll(__ballot(good));
             // the exceptions: masked-out (IGD_NEVER) or inverted queries.  They stay in the ordered list of starts that
@@ -1818,7 +1818,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
         if (cl && !(IGD_EXP & 8))
             for_later_groups<true>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
-                const int pos = lds_lower_bound(sl, 65536 - (w & 0xFFFF));
+                const int pos = (IGD_EXP & 128) ? (w & 255) : lds_lower_bound(sl, 65536 - (w & 0xFFFF));
                 if (covers) atomicAdd(&hist[pos], 1u);
                 nLater += __popcll(__ballot(covers));
             });
@@ -1831,6 +1831,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             int pos[IGD_SLOTS];
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
+            if (IGD_EXP & 64) {
+            } else
             if (inLds) {
                 // the array is padded to top - 1 entries with 65535 (> every e'): no bounds in the loop, whose five
                 // chains of dependent LDS reads then run side by side
@@ -1865,7 +1867,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         for (int r = 0; r < IGD_SLOTS; r++) {
             const int h = (int)hist[r * IGD_WAVE + lane];
             hist[r * IGD_WAVE + lane] = 0u;
-            const int inc = wave_inclusive_sum(h);
+            const int inc = (IGD_EXP & 256) ? h : wave_inclusive_sum(h);
             const bool prefix = (R.a[r] & 0xFFFFu) == 0xFFFFu;   // starts before the tile: later-tile queries do not count it
             cnt[r] += nFirst + (prefix ? 0 : nLater) - (carry + inc);
             carry += __builtin_amdgcn_readlane(inc, 63);
