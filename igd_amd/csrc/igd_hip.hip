@@ -1651,6 +1651,17 @@ __device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key
     return pos;
 }
 
+// A load the compiler's wait-count bookkeeping does not see (it is waited for right here).  For the seldom-taken
+// branches of the full build's compare phase: a tracked load inside a loop makes the compiler wait for ALL vector loads
+// in flight at the loop's head (s_waitcnt vmcnt(0)) -- the next unit's records included -- on every pass, taken or
+// not, and the dense batches this build is for run every unit through those loops.
+__device__ __forceinline__ int load_now(const int32_t *p)
+{
+    int v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // The later-tile candidates of a unit: the later[] entries of the queries [fl, f0) of the (up to) 3 tiles before its
 // tile.  They sit in the later block that holds query f0 - 1 -- whose first group of 64 words `lw` came with the unit's
 // records -- and, when the range reaches back across a block boundary, in the blocks before it (read only if the
@@ -1674,16 +1685,16 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
             const bool full = e63 != 0;
             if (full && base + (int)((unsigned)e63 >> 22) < fl) {
                 // the whole group lies in front of the range: find the first group that does not
-                if (ng == 0) ng = ((KA ? KARG(a.laterHdr) : a.laterHdr)[b].x + 63) >> 6;
+                if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
                 int lo = gi + 1, hi = ng;                 // the answer is in [lo, hi]; hi = ng: no such group
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    const int x = later[base + mid * 64 + 63];
+                    const int x = KA ? __builtin_amdgcn_readfirstlane(load_now(later + base + mid * 64 + 63)) : later[base + mid * 64 + 63];
                     if (x != 0 && base + (int)((unsigned)x >> 22) < fl) lo = mid + 1; else hi = mid;
                 }
                 if (lo >= ng) break;
                 gi = lo;
-                e = later[base + gi * 64 + lane];
+                e = KA ? load_now(later + base + gi * 64 + lane) : later[base + gi * 64 + lane];
                 continue;
             }
             const int i = base + (int)((unsigned)e >> 22);
@@ -1691,15 +1702,15 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
             const int w = later_word(nbp, e, g, deadk, e != 0 && i >= fl && i < f0, covers);
             if (__ballot(covers)) fn(w, covers);
             if (!full || base + (int)((unsigned)e63 >> 22) >= f0) break;
-            if (ng == 0) ng = ((KA ? KARG(a.laterHdr) : a.laterHdr)[b].x + 63) >> 6;
+            if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
             if (++gi >= ng) break;
-            e = later[base + gi * 64 + lane];
+            e = KA ? load_now(later + base + gi * 64 + lane) : later[base + gi * 64 + lane];
         }
         const int2 *hdr = KA ? KARG(a.laterHdr) : a.laterHdr;
         do {
             if (--b < blo) return;
-        } while (hdr[b].y < g);
-        e = later[(b << sh) + lane];
+        } while ((KA ? __builtin_amdgcn_readfirstlane(load_now(&hdr[b].y)) : hdr[b].y) < g);
+        e = KA ? load_now(later + (b << sh) + lane) : later[(b << sh) + lane];
     }
 }
 
@@ -1783,7 +1794,11 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         int nFirst = 0;
         for (int p = 0, wcur = R.q; p < c0; p += IGD_WAVE) {
             const int w = wcur;
-            wcur = (p + IGD_WAVE + lane < c0) ? ~a.qw0[f0 + p + IGD_WAVE + lane] : (int)IGD_NEVER;   // next batch, in flight meanwhile
+            wcur = (int)IGD_NEVER;
+            if (p + IGD_WAVE < c0) {                     // (untracked loads: see load_now)
+                const int i = p + IGD_WAVE + lane < c0 ? f0 + p + IGD_WAVE + lane : f0;
+                wcur = p + IGD_WAVE + lane < c0 ? ~load_now(a.qw0 + i) : (int)IGD_NEVER;
+            }
             const bool there = p + lane < c0;
             const int qe2 = 65536 - (w & 0xFFFF);
             int qs2 = (int)((unsigned)w >> 16);
@@ -1795,7 +1810,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                int t = there ? q_qs[f0 + p + lane] - T + 1 : 65535;   // = qs' for a query of this tile; beyond it: clamped
+                int t = load_now(q_qs + (there ? f0 + p + lane : f0)) - T + 1;   // = qs' for a query of this tile; beyond it: clamped
+                if (!there) t = 65535;
                 t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
                 qs2 = t;
                 while (x) {
@@ -1818,6 +1834,10 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
         if (cl && !(IGD_EXP & 8))
             for_later_groups<true>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
+#if IGD_EXP & 512
+                nLater += __popcll(__ballot(covers));
+                return;
+#endif
                 const int pos = (IGD_EXP & 128) ? (w & 255) : lds_lower_bound(sl, 65536 - (w & 0xFFFF));
                 if (covers) atomicAdd(&hist[pos], 1u);
                 nLater += __popcll(__ballot(covers));
