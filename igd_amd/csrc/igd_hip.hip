@@ -87,7 +87,7 @@ typedef unsigned long long u64;
 #endif
 
 #ifndef IGD_EXP
-#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps, 64/128/256 rank method without term B / bisections of term A / prefix sums
+#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps, 1024 section timers of the rank method, 64/128/256 rank method without term B / bisections of term A / prefix sums
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
@@ -97,6 +97,13 @@ typedef unsigned long long u64;
 #endif
 #ifndef IGD_OPT_CNT32
 #define IGD_OPT_CNT32 1 // igd_scan_sorted: 32-bit LDS counters when the host can bound them
+#endif
+#if IGD_EXP & 1024
+// diagnostic build: the waves' time (s_memtime ticks) in the sections of the rank method, summed over all launches
+__device__ u64 d_sect[8];
+#define SECT(i) do { const u64 t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&hist[321 + (i)], (unsigned)(t_ - tsec)); tsec = t_; } while (0)   /* per wave, in spare words of its LDS histogram */
+#else
+#define SECT(i) do { } while (0)
 #endif
 #if IGD_EXP & 32
 static u64 *g_stamps = nullptr;     // diagnostic build: s_memtime stamps of the last igd_scan_sorted launch
@@ -1672,9 +1679,8 @@ template <bool KA, typename FN>
 __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane,
                                                  int lw, FN fn)
 {
-    const int sh = KA ? KARG(a.lbShift) : a.lbShift;
-    const int nbp = KA ? KARG(db.nbp) : db.nbp;
-    const int32_t *later = KA ? KARG(a.later) : a.later;
+    const int sh = a.lbShift;
+    const int nbp = db.nbp;
     const int blo = fl >> sh;
     int e = lw;
     for (int b = (f0 - 1) >> sh;;) {
@@ -1685,6 +1691,7 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
             const bool full = e63 != 0;
             if (full && base + (int)((unsigned)e63 >> 22) < fl) {
                 // the whole group lies in front of the range: find the first group that does not
+                const int32_t *later = KA ? KARG(a.later) : a.later;   // (kernel-argument loads stay in the branches that need them)
                 if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
                 int lo = gi + 1, hi = ng;                 // the answer is in [lo, hi]; hi = ng: no such group
                 while (lo < hi) {
@@ -1704,13 +1711,14 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
             if (!full || base + (int)((unsigned)e63 >> 22) >= f0) break;
             if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
             if (++gi >= ng) break;
-            e = KA ? load_now(later + base + gi * 64 + lane) : later[base + gi * 64 + lane];
+            e = KA ? load_now(KARG(a.later) + base + gi * 64 + lane) : a.later[base + gi * 64 + lane];
         }
+        if (b <= blo) return;                             // (nearly always: the range lies in one block)
         const int2 *hdr = KA ? KARG(a.laterHdr) : a.laterHdr;
         do {
             if (--b < blo) return;
         } while ((KA ? __builtin_amdgcn_readfirstlane(load_now(&hdr[b].y)) : hdr[b].y) < g);
-        e = KA ? load_now(later + (b << sh) + lane) : later[(b << sh) + lane];
+        e = KA ? load_now(KARG(a.later) + (b << sh) + lane) : a.later[(b << sh) + lane];
     }
 }
 
@@ -1747,7 +1755,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     int g = 0, deadk = 0;
     if (cl) {
         g = __builtin_amdgcn_readlane(L.g, kk);
-        deadk = (RANK ? KARG(a.rule) : a.rule) == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
+        deadk = a.rule == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
     }
 #if IGD_EXP & 4
     {
@@ -1783,15 +1791,19 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
     } else {
         // ---- rank ---------------------------------------------------------------------------------
-        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)KARG(db.nbp));
-        const int32_t *q_qs = KARG(a.q_qs);
+#if IGD_EXP & 1024
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        u64 tsec = __builtin_amdgcn_s_memtime();
+#endif
+        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp);
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++)
             sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool inLds = c0 < KARG(a.sbCap);           // the tile's query starts fit the wave's LDS array (a power of two)
+        const bool inLds = c0 < a.sbCap;           // the tile's query starts fit the wave's LDS array (a power of two)
         int nFirst = 0;
+        SECT(0);
         for (int p = 0, wcur = R.q; p < c0; p += IGD_WAVE) {
             const int w = wcur;
             wcur = (int)IGD_NEVER;
@@ -1810,7 +1822,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                int t = load_now(q_qs + (there ? f0 + p + lane : f0)) - T + 1;   // = qs' for a query of this tile; beyond it: clamped
+                int t = load_now(KARG(a.q_qs) + (there ? f0 + p + lane : f0)) - T + 1;   // = qs' for a query of this tile; beyond it: clamped
                 if (!there) t = 65535;
                 t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
                 qs2 = t;
@@ -1832,6 +1844,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             }
             if (inLds && there) sb[p + lane] = (unsigned short)qs2;
         }
+        SECT(1);
         if (cl && !(IGD_EXP & 8))
             for_later_groups<true>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
 #if IGD_EXP & 512
@@ -1844,6 +1857,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SECT(2);
         // term B: #{first-tile q: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
         {
             int top = 1;
@@ -1867,6 +1881,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                     for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) ? step : 0;
                 }
             } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
+                const int32_t *q_qs = KARG(a.q_qs);
                 for (int step = top >> 1; step > 0; step >>= 1) {
                     int vq[IGD_SLOTS];
 #pragma unroll
@@ -1881,6 +1896,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0 - pos[r];
         }
+        SECT(3);
         // term A: #{q: p_q <= i} = inclusive prefix sum of the histogram over the record positions
         int carry = 0;
 #pragma unroll
@@ -1894,6 +1910,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (r * IGD_WAVE + lane >= un || !keep[r]) cnt[r] = 0;   // no record here / fails the value filter
         }
         if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;  // p = 320: queries beyond every record of a full unit
+        SECT(4);
     }
     // CNT32 (the host has bounded every counter of a launch below 2^32): one 32-bit LDS atomic per slot, for all
     // lanes -- a lane without hits adds 0 (lanes past the unit: to counter 0), which costs LDS lanes but none of the
@@ -1969,6 +1986,9 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
     const int gwave = blockIdx.x * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
     Raw2 A, B;
+#if IGD_EXP & 1024
+    const u64 t_kernel = __builtin_amdgcn_s_memtime();
+#endif
 #if IGD_EXP & 32
     const u64 t_start = __builtin_amdgcn_s_memtime();
     u64 t_desc = 0, t_first = 0;
@@ -2042,6 +2062,10 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
     }
 #if IGD_EXP & 32
     const u64 t_loop = __builtin_amdgcn_s_memtime();
+#endif
+#if IGD_EXP & 1024
+    if (RANK && lane < 5) atomicAdd(&d_sect[lane], (u64)hist[321 + lane]);
+    if (RANK && lane == 5) atomicAdd(&d_sect[5], __builtin_amdgcn_s_memtime() - t_kernel);
 #endif
     if (LDS_HITS) {
         __syncthreads();
@@ -2531,6 +2555,15 @@ static int dalloc(T **p, size_t n, int64_t *acct)
 extern "C" void igd_hip_close(igd_hip_db *db)
 {
     if (!db) return;
+#if IGD_EXP & 1024
+    {
+        u64 h[8];
+        (void)hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(d_sect), sizeof h) == hipSuccess)
+            fprintf(stderr, "[igd sect] stage %.3f  A %.3f  later %.3f  B %.3f  prefix %.3f  of the waves' time in the unit loop (%llu ticks)\n",
+                    (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], (unsigned long long)h[5]);
+    }
+#endif
 #if IGD_EXP & 32
     if (g_stamps) {
         std::vector<u64> h((size_t)g_stampWaves * 5);
