@@ -1652,10 +1652,13 @@ __device__ __forceinline__ int later_word(int nbp, int e, int g, int deadk, bool
 // records hold 65535 (> every key), so no bounds are needed
 __device__ __forceinline__ int lds_lower_bound(const unsigned short *sl, int key)
 {
-    int pos = 0;
+    // carried as the LDS byte address of sl[pos]: a step is read (immediate offset), compare, select, add
+    typedef __attribute__((address_space(3))) const unsigned short *lds_u16;
+    const unsigned base = (unsigned)(size_t)(lds_u16)sl;
+    unsigned P = base;
 #pragma unroll
-    for (int step = 256; step > 0; step >>= 1) pos += ((int)sl[pos + step - 1] < key) ? step : 0;
-    return pos;
+    for (int step = 256; step > 0; step >>= 1) P += ((int)*(lds_u16)(size_t)(P + 2u * (unsigned)(step - 1)) < key) ? 2u * (unsigned)step : 0u;
+    return (int)((P - base) >> 1);
 }
 
 // A load the compiler's wait-count bookkeeping does not see (it is waited for right here).  For the seldom-taken
@@ -1860,8 +1863,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         SECT(2);
         // term B: #{first-tile q: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
         {
-            int top = 1;
-            while (top <= c0) top <<= 1;                 // c0 < 2^31
+            int top = 1, levels = 0;
+            while (top <= c0) { top <<= 1; levels++; }   // c0 < 2^31
             int pos[IGD_SLOTS];
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
@@ -1873,13 +1876,38 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 for (int k = c0 + lane; k < top - 1; k += IGD_WAVE) sb[k] = 65535;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                for (int step = top >> 1; step > 0; step >>= 1) {
-                    int vq[IGD_SLOTS];
+                // Positions are carried as LDS byte addresses and the steps are written out with their strides as immediate
+                // offsets, entered at the tile's first stride (top / 2): read, compare, select, add per chain and step.
+                // (Tried: term A's search of the last batch of queries advanced in the same steps -- six reads in flight
+                // instead of five, nine dependent steps fewer per unit -- and it was no faster.)
+                typedef __attribute__((address_space(3))) const unsigned short *lds_u16;
+                const unsigned sb0 = (unsigned)(size_t)(lds_u16)sb;
+                unsigned P[IGD_SLOTS];
 #pragma unroll
-                    for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)sb[pos[r] + step - 1];
-#pragma unroll
-                    for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) ? step : 0;
+                for (int r = 0; r < IGD_SLOTS; r++) P[r] = sb0;
+#define IGD_BSTEP(S)                                                                                                    \
+    {                                                                                                                   \
+        int vq[IGD_SLOTS];                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)*(lds_u16)(size_t)(P[r] + 2u * ((S) - 1u)); \
+        _Pragma("unroll") for (int r = 0; r < IGD_SLOTS; r++) P[r] += vq[r] <= (int)(R.a[r] >> 16) ? 2u * (S) : 0u;    \
+    }
+                switch (levels) {                        // c0 < sbCap <= 2048: at most 11 steps
+                case 11: IGD_BSTEP(1024u) [[fallthrough]];
+                case 10: IGD_BSTEP(512u) [[fallthrough]];
+                case 9: IGD_BSTEP(256u) [[fallthrough]];
+                case 8: IGD_BSTEP(128u) [[fallthrough]];
+                case 7: IGD_BSTEP(64u) [[fallthrough]];
+                case 6: IGD_BSTEP(32u) [[fallthrough]];
+                case 5: IGD_BSTEP(16u) [[fallthrough]];
+                case 4: IGD_BSTEP(8u) [[fallthrough]];
+                case 3: IGD_BSTEP(4u) [[fallthrough]];
+                case 2: IGD_BSTEP(2u) [[fallthrough]];
+                case 1: IGD_BSTEP(1u)
+                default: break;
                 }
+#undef IGD_BSTEP
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) pos[r] = (int)((P[r] - sb0) >> 1);
             } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
                 const int32_t *q_qs = KARG(a.q_qs);
                 for (int step = top >> 1; step > 0; step >>= 1) {
