@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                 if (i0 + v < nq) qw0[i0 + v] = w0v[v];
         }
     } else if (i0 < nq) qw0[i0] = w0v[0];
-    if (packed) {
+    if (packed && !(IGD_EXP & 8192)) {
         // the workgroup's later-tile words, compacted in query order into its block of later[].  (A wave that left above
         // is not waited for by the barrier -- and nothing of an unordered batch's block is read.)
         __shared__ int sCnt[4], sMax[4];
@@ -1441,9 +1441,10 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
 // total with global atomics.  Nothing listed: one load per wave.
 template <bool USE_V>
 __device__ __forceinline__ void heavy_bucket_body(const DbView &db, const ScanArgs &a, const int32_t *__restrict__ heavy,
-                                                  u64 *__restrict__ d_hits, u64 *__restrict__ d_total, int gwave, int nwaves, int lane)
+                                                  u64 *__restrict__ d_hits, u64 *__restrict__ d_total, int gwave, int nwaves, int lane,
+                                                  int ctlv)
 {
-    int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVY + (a.epoch & 1)]);
+    int nH = __builtin_amdgcn_readlane(ctlv, CTL_NHEAVY + (a.epoch & 1));
     if (nH == 0) return;
     if (nH > IGD_HEAVY_MAX) nH = IGD_HEAVY_MAX;
     long long base = 0;
@@ -2118,19 +2119,19 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 // LDS area for the rank method.  Must sit in a kernel whose FIRST argument is the batch's SortK (KARG).
 template <bool USE_V, bool BIG>
 __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restrict__ d_hits, u64 *__restrict__ d_total,
-                                                  unsigned char *wsm, int gwave, int nwaves, int lane)
+                                                  unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv)
 {
     const DbView &db = K.db;
     const SortArgs &a = K.a;
-    if (__builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch) return;
-    const int nH = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NHEAVYS + (a.epoch & 1)]);
+    if (__builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch) return;
+    const int nH = __builtin_amdgcn_readlane(ctlv, CTL_NHEAVYS + (a.epoch & 1));
     if (nH == 0) return;
     unsigned short *sl = (unsigned short *)wsm;
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
     unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
     for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
-    const bool rankOK = __builtin_amdgcn_readfirstlane(a.ctl[CTL_NOTSTART]) != a.epoch;
+    const bool rankOK = __builtin_amdgcn_readlane(ctlv, CTL_NOTSTART) != a.epoch;
     long long base = 0;
     for (int h = 0; h < nH; h++) {
         const int t = __builtin_amdgcn_readfirstlane(a.heavyS[h]);
@@ -2164,13 +2165,15 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
 // straight into the caller's global hits[] (and the batch total).  Rare by construction.
 template <bool USE_V>
 __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
-                                                const int2 *__restrict__ longList, int gwave, int nwaves)
+                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv)
 {
-    const bool uns = __builtin_amdgcn_readfirstlane(a.ctl[CTL_UNSORTED]) == a.epoch;
+    // ctlv: the batch's control words, word i in lane i (ONE load by the caller: the walk and the two skew valves
+    // would otherwise each wait for their own, one after the other, to find out that there is nothing to do)
+    const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch;
     if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
     const bool sortedPath = a.mode == 1 || (a.mode == 0 && !uns);
     const int2 *list = sortedPath ? fixList : longList;
-    const int nList = __builtin_amdgcn_readfirstlane(a.ctl[(sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1)]);
+    const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1));
     const int lane = threadIdx.x & 63;
     u64 found = 0;
     for (int li = gwave; li < nList; li += nwaves) {
@@ -2223,15 +2226,16 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
 template <bool USE_V>
 __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, const int2 *__restrict__ fixList,
                                            const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves,
-                                           u64 *__restrict__ d_hits, u64 *__restrict__ d_total, unsigned char *smem, int gwave, int nwaves)
+                                           u64 *__restrict__ d_hits, u64 *__restrict__ d_total, unsigned char *smem, int gwave, int nwaves,
+                                           int ctlv /* the batch's control words, word i in lane i */)
 {
     const int lane = threadIdx.x & 63;
-    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves);
-    if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane);
+    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv);
+    if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane, ctlv);
     if (valves & 2) {
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
-        if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane);
-        else heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane);
+        if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+        else heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
     }
 }
 
@@ -2241,7 +2245,8 @@ __global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const i
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6));
+    const int ctlv = (threadIdx.x & 63) < 16 ? a.ctl[threadIdx.x & 63] : 0;
+    batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
 }
 
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
@@ -2252,15 +2257,17 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
                                                       ScanArgs wa, const int2 *__restrict__ fixList,
                                                       const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves)
 {
-    // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
-    // scan kernel wrote no slab, so nothing may be added
-    if (brokenIf != 0 && ctl[CTL_UNSORTED] == brokenIf) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u64 red[4];
+    // the batch's control words, word i in lane i: one load, in flight together with the slab rows
+    const int ctlv = (threadIdx.x & 63) < 16 ? ctl[threadIdx.x & 63] : 0;
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
     if (f < nFiles)
         for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s += slab[(size_t)g * nFiles + f];
+    // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
+    // scan kernel wrote no slab, so nothing may be added
+    if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
     if (s) atomicAdd(&hits[f], s);
     if (total) {
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
@@ -2275,7 +2282,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     const int nb = gridDim.x * gridDim.y;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int gwave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, hits, total, smem, gwave, nb * 4);
+    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, hits, total, smem, gwave, nb * 4, ctlv);
 }
 
 // without LDS counters the batch total is the growth of sum(hits): measured around the launch
