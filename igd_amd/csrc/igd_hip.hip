@@ -396,7 +396,7 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 // VEC queries per thread (4: the three query arrays are read, and the word arrays written, as dwordx4 -- a quarter of
 // the memory instructions and four independent chains per thread; 1: arrays that are not 16-byte aligned).
 template <int VEC>
-__global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
+__global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
                                                       int packed, int32_t *__restrict__ firstQ,
@@ -405,6 +405,25 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ later,
                                                       int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
+    // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
+    // and the batch's state is looked up (a workgroup that then leaves at once has read 12 KiB for nothing).
+    const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    int qc[VEC], qs_[VEC], qe_[VEC];
+    if (VEC == 4) {
+        int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
+        if (i0 + 3 < nq) {
+            c4 = *(const int4 *)(ichr + i0); s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
+        } else {
+            if (i0 < nq) { c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
+            if (i0 + 1 < nq) { c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
+            if (i0 + 2 < nq) { c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
+        }
+        qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
+        qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
+        qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
+    } else if (i0 < nq) { qc[0] = ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
+    int pc = -1, ps = INT_MIN;
+    if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
     const bool ldsTab = db.nCtg <= QB_CTG;
@@ -415,7 +434,6 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
 #define QB_BASE(c) (ldsTab ? sBase[c] : db.ctgBase[c])
 #define QB_NTILE(c) (ldsTab ? sNTile[c] : db.ctgNTile[c])
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i0 = t * VEC;
     if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * blockDim.x) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
     if (zeroTotal && t == 0) *zeroTotal = 0;
     if (t == 0) {                                           // next batch's list counters
@@ -431,23 +449,9 @@ __global__ __launch_bounds__(256) void k_query_bounds(DbView db, const int32_t *
     // load: an L1-cached one would keep returning the stale line and the whole unordered batch would be worked
     // through, gap filling included (5 -> 50 us).
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
-    int qc[VEC], qs_[VEC], qe_[VEC];
-    if (VEC == 4) {
-        int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
-        if (i0 + 3 < nq) {
-            c4 = *(const int4 *)(ichr + i0); s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
-        } else {
-            if (i0 < nq) { c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
-            if (i0 + 1 < nq) { c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
-            if (i0 + 2 < nq) { c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
-        }
-        qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
-        qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
-        qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
-    } else if (i0 < nq) { qc[0] = ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
     // predecessor of the thread's first query
-    int pc = -1, ps = INT_MIN, prevKey = -1;
-    if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; prevKey = tile_key(db, pc, ps); }
+    int prevKey = -1;
+    if (i0 > 0 && i0 < nq) prevKey = tile_key(db, pc, ps);
     int w0v[VEC], w1v[VEC];
     const bool marked = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;   // by another wave, meanwhile
     int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
