@@ -455,103 +455,109 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     int w0v[VEC], w1v[VEC];
     const bool marked = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;   // by another wave, meanwhile
     int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
+    // 1. keys and order of the thread's queries (query i0 + v fills firstQ[lo[v]..key[v]] = i0 + v)
+    int key[VEC], lo[VEC], cBase[VEC], cMT[VEC];
+    bool unordered = false, notStart = false;
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
-        int lo = 0, hi = -1;                                // this query fills firstQ[lo..hi] = i
-        int kNow = 0, sNow = 0;
-        bool unordered = false, notStart = false;
+        lo[v] = 0; key[v] = -1; cBase[v] = 0; cMT[v] = -1;  // (cMT = -1: no tile of this query is in range)
         w0v[v] = packed ? 0 : -1; w1v[v] = 0;
         if (i < nq) {
             const int c = qc[v], s0 = qs_[v];
             const bool cOk = c >= 0 && c < db.nCtg;
-            const int cBase = cOk ? QB_BASE(c) : 0, cMT = cOk ? QB_NTILE(c) - 1 : 0;
+            const int cb = cOk ? QB_BASE(c) : 0, cm = cOk ? QB_NTILE(c) - 1 : 0;
             const int n1r = tile_of(db, s0);
             // key(i): global number of the first tile, clamped into the contig (tile_key)
-            const int n1c = n1r < 0 ? 0 : (n1r > cMT ? cMT : n1r);
-            const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cBase + n1c);
-            unordered = k < prevKey;
-            notStart = k == prevKey && s0 < ps;
-            lo = prevKey + 1; hi = k;
-            if (i == 0) lo = hi + 1;                        // the tiles up to the first query's key: filled by the whole grid (below)
-            kNow = k; sNow = s0;
+            const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
+            const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cb + n1c);
+            unordered |= k < prevKey;
+            notStart |= k == prevKey && s0 < ps;
+            lo[v] = i == 0 ? k + 1 : prevKey + 1;           // the tiles up to the first query's key: filled by the whole grid (below)
+            key[v] = k;
+            cBase[v] = cb; cMT[v] = cOk ? cm : -1;
+            prevKey = k; ps = s0;
         }
-        // One lane per wave reports (hundreds of thousands of stores to ONE address would queue up for tens of
-        // microseconds), and a wave that has seen disorder leaves: nothing it would still produce is going to be read.
-        {
-            const unsigned long long bu = __ballot(unordered), bs = __ballot(notStart);
-            if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
-                                                                                // the merge join still holds, the rank method does not
-            if (bu) {
-                if (!marked && lane == __builtin_ctzll(bu)) {
-                    ctl[CTL_UNSORTED] = epoch;
-                    if (promised) ctl[CTL_BROKEN] = epoch;  // sticky until the next igd_hip_sync (any promised batch since)
+    }
+    // 2. One lane per wave reports (hundreds of thousands of stores to ONE address would queue up for tens of
+    // microseconds), and a wave that has seen disorder leaves: nothing it would still produce is going to be read.
+    {
+        const unsigned long long bu = __ballot(unordered), bs = __ballot(notStart);
+        if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
+                                                                            // the merge join still holds, the rank method does not
+        if (bu) {
+            if (!marked && lane == __builtin_ctzll(bu)) {
+                ctl[CTL_UNSORTED] = epoch;
+                if (promised) ctl[CTL_BROKEN] = epoch;      // sticky until the next igd_hip_sync (any promised batch since)
+            }
+            return;
+        }
+    }
+    // 3. the words the scan reads
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {
+        const int i = i0 + v;
+        const int s0 = qs_[v], n1 = tile_of(db, s0);
+        if (i < nq && n1 >= 0 && n1 <= cMT[v]) {
+            const int e0 = qe_[v];
+            int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
+            if (n2 > cMT[v]) n2 = cMT[v];
+            const int span = n2 > n1 ? n2 - n1 : 0;
+            const int g0 = cBase[v] + n1;
+            const int T0 = (int)((unsigned)n1 * (unsigned)db.nbp);
+            // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
+            if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
+            const bool needExact = packed && e0 <= T0;
+            if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
+            if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
+            else {
+                // rule NEST (an empty first tile ends the query, :468) needs no look-up here: the first tile's own
+                // units have records by definition, and for the later tiles the scan knows from the unit's flags
+                // which of the tiles before it are empty
+                if (!needExact) w0v[v] = ~query_word(s0, e0, true, T0, db.nbp);
+                if (span > 0) {
+                    const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
+                    int rel = e0 - T0;                      // > W here, since the query reaches the next tile
+                    if (rel > 4 * db.nbp) rel = 4 * db.nbp;
+                    w1v[v] = rel | (sp << 18) | ((g0 & 3) << 20) | ((int)(threadIdx.x * VEC + v) << 22);
+                    for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
+                    if (g0 + sp > lastTile) lastTile = g0 + sp;
                 }
-                return;
             }
         }
-        if (i < nq) {
-            const int c = qc[v], s0 = qs_[v];
-            const bool cOk = c >= 0 && c < db.nCtg;
-            const int cBase = cOk ? QB_BASE(c) : 0, cMT = cOk ? QB_NTILE(c) - 1 : 0;
-            const int n1r = tile_of(db, s0);
-            if (cOk && n1r >= 0 && n1r <= cMT) {
-                const int n1 = n1r, e0 = qe_[v];
-                int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
-                if (n2 > cMT) n2 = cMT;
-                const int span = n2 > n1 ? n2 - n1 : 0;
-                const int g0 = cBase + n1;
-                const int T0 = (int)((unsigned)n1 * (unsigned)db.nbp);
-                // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
-                if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
-                const bool needExact = packed && e0 <= T0;
-                if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
-                if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
-                else {
-                    // rule NEST (an empty first tile ends the query, :468) needs no look-up here: the first tile's own
-                    // units have records by definition, and for the later tiles the scan knows from the unit's flags
-                    // which of the tiles before it are empty
-                    if (!needExact) w0v[v] = ~query_word(s0, e0, true, T0, db.nbp);
-                    if (span > 0) {
-                        const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
-                        int rel = e0 - T0;                  // > W here, since the query reaches the next tile
-                        if (rel > 4 * db.nbp) rel = 4 * db.nbp;
-                        w1v[v] = rel | (sp << 18) | ((g0 & 3) << 20) | ((int)(threadIdx.x * VEC + v) << 22);
-                        for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
-                        if (g0 + sp > lastTile) lastTile = g0 + sp;
+    }
+    // 4. firstQ: short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
+    // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
+    // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
+    // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
+    // A wave that finds the batch already marked fills nothing: firstQ[] is not going to be used.  (One that saw
+    // disorder itself has left above.)
+    if (!marked) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            const int i = i0 + v, l1 = lo[v], h1 = key[v];
+            const bool big = h1 - l1 >= 8;
+            if (!big) for (int tt = l1; tt <= h1; tt++) firstQ[tt] = i;
+            unsigned long long m = __ballot(big);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int l2 = __builtin_amdgcn_readlane(l1, src), h2 = __builtin_amdgcn_readlane(h1, src);
+                const int v2 = __builtin_amdgcn_readlane(i, src);
+                if (h2 - l2 >= 256) {
+                    int spent = 0;
+                    if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
+                    spent = __builtin_amdgcn_readfirstlane(spent);
+                    if (spent > (db.nT >> 8) + 16) {
+                        if (lane == 0) {
+                            ctl[CTL_UNSORTED] = epoch;
+                            if (promised) ctl[CTL_BROKEN] = epoch;
+                        }
+                        continue;
                     }
                 }
+                for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) firstQ[tt] = v2;
             }
-        }
-        if (i < nq) { prevKey = kNow; ps = sNow; }
-        // firstQ: short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
-        // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
-        // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
-        // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
-        // A wave that sees disorder among its own queries, or finds the batch already marked, fills
-        // nothing: firstQ[] is not going to be used.
-        const bool disorder = marked;                       // (a wave that saw disorder itself has left above)
-        const bool big = hi - lo >= 8;
-        if (!big && !disorder) for (int tt = lo; tt <= hi; tt++) firstQ[tt] = i;
-        unsigned long long m = disorder ? 0ull : __ballot(big);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int l2 = __builtin_amdgcn_readlane(lo, src), h2 = __builtin_amdgcn_readlane(hi, src);
-            const int v2 = __builtin_amdgcn_readlane(i, src);
-            if (h2 - l2 >= 256) {
-                int spent = 0;
-                if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
-                spent = __builtin_amdgcn_readfirstlane(spent);
-                if (spent > (db.nT >> 8) + 16) {
-                    if (lane == 0) {
-                        ctl[CTL_UNSORTED] = epoch;
-                        if (promised) ctl[CTL_BROKEN] = epoch;
-                    }
-                    continue;
-                }
-            }
-            for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) firstQ[tt] = v2;
         }
     }
 #undef QB_BASE
