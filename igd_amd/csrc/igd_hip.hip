@@ -280,6 +280,11 @@ __global__ void k_idx_range(const int32_t *__restrict__ idx, int64_t n, int32_t 
 
 // ------------------------------------------------------------------------------------------
 // coordinate -> tile index with C semantics (truncation toward zero), src/igd_search.c:459
+// x / 2^sh the way C divides (towards zero)
+__device__ __forceinline__ int tile_shift(int x, int sh)
+{
+    return (int)((unsigned)(x + ((x >> 31) & ((1 << sh) - 1)))) >> sh;
+}
 __device__ __forceinline__ int tile_of(const DbView &db, int x)
 {
     if (db.shift >= 0) {
@@ -395,11 +400,13 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 //     qw0[i] = (global number of the first tile) << 4 | min(n2 - n1, 15), -1 when it visits nothing.
 // VEC queries per thread (4: the three query arrays are read, and the word arrays written, as dwordx4 -- a quarter of
 // the memory instructions and four independent chains per thread; 1: arrays that are not 16-byte aligned).
-template <int VEC>
+// FAST: the usual case, decided by the host -- compact image, power-of-two tile size, contig tables that fit the LDS arrays --
+// compiled without the other cases' branches (a flat load picking between LDS and global tables, a division).
+template <int VEC, bool FAST>
 __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
-                                                      int packed, int32_t *__restrict__ firstQ,
+                                                      int packed_, int32_t *__restrict__ firstQ,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ later,
@@ -426,13 +433,15 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
-    const bool ldsTab = db.nCtg <= QB_CTG;
+    const bool ldsTab = FAST || db.nCtg <= QB_CTG;
+    const int packed = FAST ? 1 : packed_;
     if (ldsTab) {
         for (int c = threadIdx.x; c < db.nCtg; c += blockDim.x) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
         __syncthreads();
     }
-#define QB_BASE(c) (ldsTab ? sBase[c] : db.ctgBase[c])
-#define QB_NTILE(c) (ldsTab ? sNTile[c] : db.ctgNTile[c])
+#define QB_BASE(c) (FAST ? sBase[c] : (ldsTab ? sBase[c] : db.ctgBase[c]))
+#define QB_NTILE(c) (FAST ? sNTile[c] : (ldsTab ? sNTile[c] : db.ctgNTile[c]))
+#define QB_TILE(x) (FAST ? tile_shift(x, db.shift) : tile_of(db, x))
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * blockDim.x) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
     if (zeroTotal && t == 0) *zeroTotal = 0;
@@ -451,7 +460,16 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
     // predecessor of the thread's first query
     int prevKey = -1;
-    if (i0 > 0 && i0 < nq) prevKey = tile_key(db, pc, ps);
+    if (i0 > 0 && i0 < nq) {
+        if (FAST) {                                         // tile_key from the staged tables
+            if (pc < 0) prevKey = 0;
+            else if (pc >= db.nCtg) prevKey = db.nT - 1;
+            else {
+                const int n1 = tile_shift(ps, db.shift), mT = sNTile[pc] - 1;
+                prevKey = sBase[pc] + (n1 < 0 ? 0 : (n1 > mT ? mT : n1));
+            }
+        } else prevKey = tile_key(db, pc, ps);
+    }
     int w0v[VEC], w1v[VEC];
     const bool marked = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;   // by another wave, meanwhile
     int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
             const int c = qc[v], s0 = qs_[v];
             const bool cOk = c >= 0 && c < db.nCtg;
             const int cb = cOk ? QB_BASE(c) : 0, cm = cOk ? QB_NTILE(c) - 1 : 0;
-            const int n1r = tile_of(db, s0);
+            const int n1r = QB_TILE(s0);
             // key(i): global number of the first tile, clamped into the contig (tile_key)
             const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
             const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cb + n1c);
@@ -497,10 +515,10 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
-        const int s0 = qs_[v], n1 = tile_of(db, s0);
+        const int s0 = qs_[v], n1 = QB_TILE(s0);
         if (i < nq && n1 >= 0 && n1 <= cMT[v]) {
             const int e0 = qe_[v];
-            int n2 = tile_of(db, (int)((unsigned)e0 - 1u));
+            int n2 = QB_TILE((int)((unsigned)e0 - 1u));
             if (n2 > cMT[v]) n2 = cMT[v];
             const int span = n2 > n1 ? n2 - n1 : 0;
             const int g0 = cBase[v] + n1;
@@ -562,6 +580,7 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     }
 #undef QB_BASE
 #undef QB_NTILE
+#undef QB_TILE
     if (VEC == 4) {
         if (i0 + 3 < nq) *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
         else {
@@ -3202,12 +3221,14 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     if (mode != 2) {
         bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
         if (getenv("IGD_HIP_QB_VEC1")) vec = false;   // A/B
-        if (vec)
-            k_query_bounds<4><<<(int)((nq + 1023) / 1024), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, (int2 *)db->d_blockLast, mode == 1 ? 1 : 0);
-        else
-            k_query_bounds<1><<<(int)((nq + 255) / 256), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, packed ? 1 : 0,
-                db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill, (int2 *)db->d_blockLast, mode == 1 ? 1 : 0);
+        const bool fast = packed && db->v.shift >= 0 && db->nCtg <= QB_CTG;
+#define QB_LAUNCH(VEC_, FAST_)                                                                                                        \
+    k_query_bounds<VEC_, FAST_><<<(int)((nq + 256 * VEC_ - 1) / (256 * VEC_)), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, \
+        packed ? 1 : 0, db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill,                       \
+        (int2 *)db->d_blockLast, mode == 1 ? 1 : 0)
+        if (vec) { if (fast) QB_LAUNCH(4, true); else QB_LAUNCH(4, false); }
+        else { if (fast) QB_LAUNCH(1, true); else QB_LAUNCH(1, false); }
+#undef QB_LAUNCH
         db->lbShift = vec ? 10 : 8;
     }
     if (mode != 1) {
