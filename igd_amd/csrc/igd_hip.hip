@@ -1765,6 +1765,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 {
     const int c0 = R.c0, cl = R.cl;
     if ((c0 | cl) == 0) return;                          // nobody asks about this unit
+#if IGD_EXP & 1024
+    const u64 t_unit = __builtin_amdgcn_s_memtime();
+#endif
     const int un = R.n;
     if (un == 0) return;                                 // placeholder of an empty tile
     const int f0 = R.f0;
@@ -1825,8 +1828,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     } else {
         // ---- rank ---------------------------------------------------------------------------------
 #if IGD_EXP & 1024
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         u64 tsec = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        SECT(5);                                         // waiting for the unit's records
 #endif
         const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp);
 #pragma unroll
@@ -1984,6 +1988,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         if (CNT32) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)c);
         else if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
     }
+#if IGD_EXP & 1024
+    if (lane == 0) atomicAdd(&hist[321 + 6], (unsigned)(__builtin_amdgcn_s_memtime() - t_unit));   // all of the unit's compare phase
+#endif
     if (found) {                                         // skew valve: the batch total is kept by the caller of this unit
         int t = 0;
 #pragma unroll
@@ -2097,6 +2104,42 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 #if IGD_EXP & 32
         if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.cl)); t_desc = __builtin_amdgcn_s_memtime(); }
 #endif
+        if (RANK) {
+            // The full build also serves batches that visit a fraction of the units (one GPU's slab of config 4: one unit
+            // in eight): the wave steps through the units somebody asks about only -- an unvisited one still cost its
+            // dozen zero-size loads, which queue up behind everybody's real ones.
+            unsigned long long m = __ballot((L.c0 | L.cl) != 0 && L.n > 0);
+            const int visited = __popcll(m);
+            int qd = (visited + 3) >> 2, at = qd, level = 3, nd = 0;
+#if IGD_OPT_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            int ka = -1, kb = -1;
+            if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
+            if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
+            s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
+            while (ka >= 0) {
+                s_issue<USE_V, BIG>(db, a, L, kb < 0 ? 0 : kb, kb >= 0, lane, B);
+                s_compute<USE_V, CNT32, RANK>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK);
+                ka = -1;
+                if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
+                s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
+                if (kb >= 0) s_compute<USE_V, CNT32, RANK>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK);
+                kb = -1;
+                if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
+#if IGD_OPT_PRIO
+                nd += 2;
+                if (nd >= at) {
+                    at += qd;
+                    level--;
+                    if (level == 2) __builtin_amdgcn_s_setprio(2);
+                    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
+            }
+            continue;
+        }
         s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
         for (int kk = 0; kk < cntU; kk += 2) {
             s_issue<USE_V, BIG>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
@@ -2123,6 +2166,8 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 #endif
 #if IGD_EXP & 1024
     if (RANK && lane < 5) atomicAdd(&d_sect[lane], (u64)hist[321 + lane]);
+    if (RANK && lane == 6) atomicAdd(&d_sect[6], (u64)hist[321 + 5]);
+    if (RANK && lane == 7) atomicAdd(&d_sect[7], (u64)hist[321 + 6]);
     if (RANK && lane == 5) atomicAdd(&d_sect[5], __builtin_amdgcn_s_memtime() - t_kernel);
 #endif
     if (LDS_HITS) {
@@ -2626,6 +2671,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
         if (hipMemcpyFromSymbol(h, HIP_SYMBOL(d_sect), sizeof h) == hipSuccess)
             fprintf(stderr, "[igd sect] stage %.3f  A %.3f  later %.3f  B %.3f  prefix %.3f  of the waves' time in the unit loop (%llu ticks)\n",
                     (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], (unsigned long long)h[5]);
+        fprintf(stderr, "[igd sect] waiting for records %.3f, compare phases of all visited units %.3f\n", (double)h[6] / h[5], (double)h[7] / h[5]);
     }
 #endif
 #if IGD_EXP & 32
