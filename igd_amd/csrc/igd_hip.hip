@@ -557,23 +557,30 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
             const bool big = h1 - l1 >= 8;
             if (!big) for (int tt = l1; tt <= h1; tt++) firstQ[tt] = i;
             unsigned long long m = __ballot(big);
+            if (m == 0) continue;
+            // the budget is charged once for all long gaps of the wave's 64 queries (a returning atomic each made a small
+            // batch, whose every gap is long, wait 64 times in a row)
+            int charge = big && h1 - l1 >= 256 ? (h1 - l1) >> 8 : 0;
+            for (int o = 32; o > 0; o >>= 1) charge += __shfl_xor(charge, o);
+            bool over = false;
+            if (charge) {
+                int spent = 0;
+                if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], charge);
+                spent = __builtin_amdgcn_readfirstlane(spent);
+                if (spent + charge > (db.nT >> 8) + 16) {
+                    over = true;
+                    if (lane == 0) {
+                        ctl[CTL_UNSORTED] = epoch;
+                        if (promised) ctl[CTL_BROKEN] = epoch;
+                    }
+                }
+            }
             while (m) {
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
                 const int l2 = __builtin_amdgcn_readlane(l1, src), h2 = __builtin_amdgcn_readlane(h1, src);
                 const int v2 = __builtin_amdgcn_readlane(i, src);
-                if (h2 - l2 >= 256) {
-                    int spent = 0;
-                    if (lane == 0) spent = atomicAdd(&ctl[CTL_BUDGET + (epoch & 1)], (h2 - l2) >> 8);
-                    spent = __builtin_amdgcn_readfirstlane(spent);
-                    if (spent > (db.nT >> 8) + 16) {
-                        if (lane == 0) {
-                            ctl[CTL_UNSORTED] = epoch;
-                            if (promised) ctl[CTL_BROKEN] = epoch;
-                        }
-                        continue;
-                    }
-                }
+                if (over && h2 - l2 >= 256) continue;
                 for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) firstQ[tt] = v2;
             }
         }
