@@ -1848,13 +1848,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         const bool inLds = c0 < a.sbCap;           // the tile's query starts fit the wave's LDS array (a power of two)
         int nFirst = 0;
         SECT(0);
-        for (int p = 0, wcur = R.q; p < c0; p += IGD_WAVE) {
-            const int w = wcur;
-            wcur = (int)IGD_NEVER;
-            if (p + IGD_WAVE < c0) {                     // (untracked loads: see load_now)
-                const int i = p + IGD_WAVE + lane < c0 ? f0 + p + IGD_WAVE + lane : f0;
-                wcur = p + IGD_WAVE + lane < c0 ? ~load_now(a.qw0 + i) : (int)IGD_NEVER;
-            }
+        // one batch of <= 64 first-tile queries (word w per lane, IGD_NEVER past the tile's last query)
+        auto batchA = [&](const int w, const int p) {
             const bool there = p + lane < c0;
             const int qe2 = 65536 - (w & 0xFFFF);
             int qs2 = (int)((unsigned)w >> 16);
@@ -1887,6 +1882,28 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 }
             }
             if (inLds && there) sb[p + lane] = (unsigned short)qs2;
+        };
+        // The batches after the first are fetched one ahead: the load of batch k + 1 is issued before batch k is searched
+        // and its word first touched after (530 queries per tile -- one GPU's slab of an 8-GPU job -- are 9 batches, and
+        // a load waited for on the spot made each of them a memory round trip).  Two batches per pass of the loop, so
+        // that no loaded word is carried around it.
+        {
+            int wa = R.q;
+            for (int p = 0; p < c0; p += 2 * IGD_WAVE) {
+                const bool moreB = p + IGD_WAVE < c0, moreA = p + 2 * IGD_WAVE < c0;
+                // (unconditional, from an index clamped into the tile's queries: behind a branch the compiler waits for a
+                // load where the branch ends)
+                const int last = f0 + c0 - 1;
+                const int ib = f0 + p + IGD_WAVE + lane, ia = ib + IGD_WAVE;
+                const int rb = a.qw0[ib < last ? ib : last];
+                batchA(wa, p);
+                if (!moreB) break;
+                const int wb = p + IGD_WAVE + lane < c0 ? ~rb : (int)IGD_NEVER;
+                const int ra = a.qw0[ia < last ? ia : last];
+                batchA(wb, p + IGD_WAVE);
+                if (!moreA) break;
+                wa = p + 2 * IGD_WAVE + lane < c0 ? ~ra : (int)IGD_NEVER;
+            }
         }
         SECT(1);
         if (cl && !(IGD_EXP & 8))
