@@ -48,7 +48,7 @@ def test_dense_sorted_batches_take_the_rank_path_and_match_the_oracle(case, buil
     path, ctgs, span = _random_db(rng, workdir, "rk%d" % case, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
     orc, db = Oracle(path), Database(path)
     try:
-        n = 60000
+        n = 70000                                 # (>= 65536: k_query_bounds with four queries per thread)
         ichr, qs, qe = _dense_queries(rng, nctg, nbp, span, n)
         ntiles = sum(db.ntile)
         assert n / ntiles > 64                    # far beyond IGD_DENSE_MIN per tile
@@ -110,7 +110,7 @@ def test_every_query_reaching_into_later_tiles(build, workdir, monkeypatch):
     path, ctgs, span = _random_db(rng, workdir, "lt", nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
     orc, db = Oracle(path), Database(path)
     try:
-        for n in (50000, 3000):                  # dense (rank method in the full build) and sparse
+        for n in (70000, 3000):                  # dense (rank method in the full build; >= 65536: four queries per thread) and sparse
             ichr, qs, qe = _random_queries(rng, list(range(nctg)), nbp, span, n)
             lens = np.array([rng.choice([nbp, nbp + 17, 2 * nbp + 5, 3 * nbp - 1]) for _ in range(n)], np.int32)
             qe = (qs + lens).astype(np.int32)
