@@ -13,29 +13,34 @@
 //   1. group the queries by tile.  Two ways, chosen ON THE DEVICE per batch:
 //      a. queries already ordered by (contig, start) -- what a position-sorted BED gives:
 //         k_query_bounds finds, in one pass and without atomics, the first query of every
-//         tile (firstQ[]), verifies the order and leaves per query one word (first global tile,
-//         tile span); the scan kernel then reads the queries of tile t and of the up-to-3 tiles
-//         before it straight from the caller's arrays (a merge join: both sides stream);
+//         tile (firstQ[]), verifies the order and leaves per query its READY-MADE compare word for
+//         its first tile (qw0) and, for the 6 % that reach into later tiles, one more word, compacted
+//         per block of 1024 queries (later[]); the scan kernel then reads the words of tile t's
+//         queries, and of those of the up-to-3 tiles before it that reach it, with the tile's
+//         records (a merge join: both sides stream, nothing is computed per candidate);
 //      b. any other order: every (query, visited tile) pair is grouped by tile id without global
 //         atomics (k_split_local -> k_split_totals -> k_split_fine: LDS counting in two levels);
 //         these kernels return at once when (a) holds.
 //      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
-//   2. scan:   igd_scan_tiles -- one wavefront owns one <=320-record chunk ("unit") of one tile
-//      at a time.  It loads the unit's records once, coalesced, into 5 register slots (record
-//      r*64+lane) -- by default from a compact 6-byte tile-relative image (k_pack_units) -- keeps
-//      two units in flight, and runs through the tile's queries, whose parameters it computes 64
-//      at a time across the lanes.  Each slot has a summary word (component-wise max of its 64
-//      record words); the queries that pass against it -- one vector compare for all 64 -- are
-//      broadcast with v_readlane one at a time, and per query and slot the test
+//   2. scan:   igd_scan_sorted (a) / igd_scan_tiles (b) -- one wavefront owns one <=320-record chunk
+//      ("unit") of one tile at a time.  It loads the unit's records once, coalesced, into 5 register
+//      slots (record r*64+lane) -- by default from a compact 6-byte tile-relative image
+//      (k_pack_units) -- keeps two units in flight, and runs through the tile's queries 64 at a
+//      time across the lanes.  Each slot has a summary word (component-wise max of its 64 record
+//      words, kept in the unit's descriptor); the queries that pass against it -- one vector compare
+//      for all 64 -- are broadcast with v_readlane one at a time, and per query and slot the test
 //            lob <= start < qe  &&  end > qs  [&& value >= v]
 //      (lob = tile start for a non-first tile: the reference's tS prefix skip, :510-511; the
-//      upper bound start<qe is what its bisection computes, :479-487) costs three vector
-//      instructions and accumulates a per-record hit count; each record that was hit then does
-//      ONE ds_add_u64 into a per-workgroup LDS copy of hits[] (privatised counters).
+//      upper bound start<qe is what its bisection computes, :479-487) is one packed 16-bit max,
+//      one compare and one add-with-carry into a per-record hit count; the counts go into a
+//      per-workgroup LDS copy of hits[] (privatised counters).  Tiles with >= 32 queries are counted
+//      by ranks instead (two bisections per query/record: see "rank" at igd_scan_sorted).
 //   3. flush/reduce: each workgroup stores its LDS counters to its own slab row with plain
 //      coalesced stores; k_reduce_slabs sums the rows into the caller's int64 hits[].  The same
 //      launch walks, on the exact arrays, the few queries the scan leaves out (more than
-//      IGD_SHORT_TILES tiles long, or needing exact starts: see k_pack_units).
+//      IGD_SHORT_TILES tiles long, or needing exact starts: see k_pack_units), and shares out over
+//      all its waves the tiles that were listed as too heavy for the one wave that owns them
+//      (heavy_bucket_body / heavy_sorted_body: the skew valves).
 //   `-f` (igd_enum_queries: query-major, streamed out in chunks) and `-m` (igd_hitmap_tiles) are separate kernels on the exact arrays;
 //   Seqpare `-s` (igd_hip_seqpare) = the `-f` kernel emitting similarities + radix sorts into the
 //   greedy order (igd_sortscan.hpp) + a wave-per-group matching kernel (k_seq_greedy).
@@ -323,13 +328,13 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define CTL_UNSORTED 1
 #define CTL_BROKEN 2
 #define CTL_NOTSTART 3   // epoch of the last batch whose queries were ordered by tile but NOT by start inside a tile
-#define CTL_NHEAVY 10    // + (epoch & 1): tiles of the batch listed for igd_scan_heavy (bucket path)
+#define CTL_NHEAVY 10    // + (epoch & 1): tiles of the batch listed for heavy_bucket_body (bucket path)
 #define IGD_HEAVY_PAIRS 2048   // a tile with more (query, tile) pairs than this is shared out in slices of that many
 #define IGD_HEAVY_MAX 4096     // listed heavy tiles per batch (a further one stays with its own wave)
-#define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for igd_sorted_heavy (merge join)
+#define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for heavy_sorted_body (merge join)
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
-#define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to igd_sorted_heavy
+#define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body
 #define CTL_NLONG 4
 #define CTL_NFIX 6
 #define CTL_BUDGET 8
@@ -855,7 +860,7 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
             if (t0 + f0 + k < nT) {
                 pairPos[t0 + f0 + k] = (int32_t)(run + c);
                 int32_t pn = (int32_t)c;
-                if (heavy && c > IGD_HEAVY_PAIRS) {       // too many pairs for one wave: igd_scan_heavy shares the tile out
+                if (heavy && c > IGD_HEAVY_PAIRS) {       // too many pairs for one wave: heavy_bucket_body shares the tile out
                     const int at = atomicAdd(&ctlw[CTL_NHEAVY + (epoch & 1)], 1);
                     if (at < IGD_HEAVY_MAX) { heavy[at] = t0 + f0 + k; pn = -pn; }   // negative: "not yours" for igd_scan_tiles
                 }
@@ -1417,7 +1422,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
                     }
                 } else if (L.n > 0) {
                     Lr0 = a.pairN[L.tile];
-                    if (Lr0 < 0) Lr0 = 0;                 // listed for igd_scan_heavy
+                    if (Lr0 < 0) Lr0 = 0;                 // listed for heavy_bucket_body
                     Lr1 = a.pairPos[L.tile];
                 }
             }
@@ -1545,7 +1550,7 @@ struct SortArgs {
     const int32_t *ctl;
     int nq, v, epoch, mode, rule;
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
-    int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to igd_sorted_heavy
+    int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to heavy_sorted_body
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
@@ -1764,7 +1769,7 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
 
 // RANK = false: the lean build for batches that are sparse on average (the host decides by queries per tile): no rank
 // method in the kernel at all -- its registers would burden the pairwise path, which is what such a batch runs --
-// and a tile that is dense after all goes to igd_sorted_heavy from IGD_LEAN_FIRST first-tile queries on.
+// and a tile that is dense after all goes to heavy_sorted_body from IGD_LEAN_FIRST first-tile queries on.
 template <bool USE_V, bool CNT32, bool RANK>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
@@ -2114,7 +2119,7 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
                     L.f0 = firstQ[u.tile];
                     L.c0 = firstQ[u.tile + 1] - L.f0;
                     if (spill[u.tile] == a.epoch) L.cl = L.f0 - firstQ[u.tile - lb];
-                    // a tile with very many first-tile queries is shared out over all waves (igd_sorted_heavy); its own
+                    // a tile with very many first-tile queries is shared out over all waves (heavy_sorted_body); its own
                     // waves keep the later-tile candidates.  (<= 2^24 queries per batch: at most 2047 such tiles.)
                     if (L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST)) {
                         if (u.jf & 1) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
@@ -3227,7 +3232,7 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const size_t ldsS = (size_t)db->ldsSorted;
         const SortK K = make_sortk(db, a);
         // sparse on average (fewer than 8 queries per tile): the lean build, whose pairwise path is not burdened with the rank
-        // method's registers; tiles that are dense all the same go to igd_sorted_heavy
+        // method's registers; tiles that are dense all the same go to heavy_sorted_body
         const char *fr = getenv("IGD_HIP_RANK");          // tests: 0 lean, 1 full
         const int forceRank = fr && *fr ? atoi(fr) : -1;
         // ... and a batch that visits a fraction of the units (fewer queries than tiles) runs the full build too: it steps
@@ -4025,7 +4030,7 @@ __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, co
                 if (firstUnit) {
                     if (rankOK && c0 >= IGD_DENSE_MIN) nd = (u64)c0;
                 }
-            } else if (pairN[un.tile] != 0) {             // negative: the tile went to igd_scan_heavy
+            } else if (pairN[un.tile] != 0) {             // negative: the tile went to heavy_bucket_body
                 nu = 1; nr = (u64)un.n;
                 if (firstUnit) np = (u64)(pairN[un.tile] < 0 ? -pairN[un.tile] : pairN[un.tile]);
             }

@@ -39,7 +39,7 @@ def _dense_queries(rng, nctg, nbp, span, n):
 @pytest.mark.parametrize("case", [1, 2, 3, 5, 6])
 def test_dense_sorted_batches_take_the_rank_path_and_match_the_oracle(case, build, workdir, monkeypatch):
     """build: which igd_scan_sorted the engine launches -- auto (by queries per tile: the full build here), lean
-    (pairwise only; tiles with > 512 first-tile queries go to igd_sorted_heavy) or full (rank method from 32 on)."""
+    (pairwise only; tiles with > 512 first-tile queries go to the skew valve, heavy_sorted_body) or full (rank method from 32 on)."""
     from igd_amd import Database
     if build != "auto":
         monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")

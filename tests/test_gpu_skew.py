@@ -1,6 +1,6 @@
 """Skew: batches whose queries pile up in very few tiles.  The tile chunk is the unit of work, so without a valve
 such a batch is serialised on the waves that own those tiles (10^6 unordered queries inside ONE tile took 62 ms).
-Unordered batches: k_split_fine lists the heavy tiles and igd_scan_heavy shares them out in slices over all waves;
+Unordered batches: k_split_fine lists the heavy tiles and heavy_bucket_body shares them out in slices over all waves;
 ordered batches: the merge join's rank method is linear in the queries.  Counts must not change -- checked against the
 oracle on a sample and between the engine's paths on the whole batch -- and the time must stay in the milliseconds."""
 import os
