@@ -3553,7 +3553,14 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
     ENUM_PHASE("H2D + count + scan + qoff");
     const int64_t tot = qoff[nq];
     if (total) *total = tot;
-    if (tot == 0) return IGD_HIP_OK;
+    if (tot == 0) {
+        // no overlap at all: the sink still sees the batch's queries once (the command line tool prints a line per query)
+        if (sink && sink(ctx, 0, nq, qoff, nullptr) != 0) {
+            snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: stopped by the sink");
+            return IGD_HIP_ERR_ARG;
+        }
+        return IGD_HIP_OK;
+    }
     int64_t maxq = 0;
     for (int64_t i = 0; i < nq; i++) if (qoff[i + 1] - qoff[i] > maxq) maxq = qoff[i + 1] - qoff[i];
     if (maxq > db->enumChunkCap) {                         // one query larger than a chunk buffer: grow them

@@ -202,6 +202,36 @@ def test_cli_text_identical_to_oracle_cli(workdir):
         assert got == run_oracle_cli(args), extra
 
 
+def test_cli_f_prints_the_query_lines_of_a_batch_without_any_overlap(workdir):
+    """`-f` prints "Query c, s, e: " for every query that reaches a tile of its contig, also when the whole batch
+    finds nothing (src/igd_search.c:548 comes before the tile is looked at): the engine's sink is called once for such
+    a batch, too."""
+    rng = random.Random(7057)
+    nbp = 1 << 16
+    path, ctgs, span = _random_db(rng, workdir, "cli0", nbp, 1, 3, 2, 4, 1)
+    orc = Oracle(path)
+    try:
+        free = []
+        for c in range(len(ctgs)):
+            for s in range(0, nbp, 97):             # tile 0 exists on every contig of the database
+                one = (np.array([c], np.int32), np.array([s], np.int32), np.array([s + 1], np.int32))
+                if orc.search(*one, 0)[1] == 0:
+                    free.append((ctgs[c], s, s + 1))
+                if len(free) >= 30:
+                    break
+    finally:
+        orc.close()
+    assert free
+    qf = os.path.join(workdir, "cli0_q.bed")
+    write_bed(qf, free)
+    exe = os.path.join(ROOT, "bin", "igd")
+    args = ["search", path, "-q", qf, "-f"]
+    want = run_oracle_cli(args)
+    assert "Total overlaps: 0" in want and want.count("Query ") > 0     # the case this test is about
+    got = subprocess.run([exe] + args, stdout=subprocess.PIPE, check=True).stdout.decode()
+    assert got == want
+
+
 @pytest.mark.parametrize("case", [0, 1, 3, 5])
 def test_hitmap_matches_oracle(case, workdir):
     """`-m`: dataset x dataset matrix (getMap / getMap_v) on fuzzed databases, incl. a hot tile
