@@ -30,7 +30,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  same .igd and the same queries as BED text, 1 thread; falls back to the oracle
                  port (kind "port") when the prebuilt reference binary did not travel.
   extra_configs: short timed runs of configs 3 (`-v 500`), shuffled input, config 4's per-GPU share
-                 (1.25e7 queries on one GPU) and config 5 (`-f`) in the same process (N = 1 only).
+                 (1.25e7 queries on one GPU), one GPU's slab of the 8-GPU job, two small batches and config 5 (`-f`)
+                 in the same process (N = 1 only).
 The oracle / reference are used here ONLY for that baseline and to check the GPU totals.
 """
 import argparse
@@ -283,7 +284,11 @@ def extra_configs(db, dev, stream, args, box):
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100),
              ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100),
              ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30),
-             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30)]
+             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30),
+             ("small batch: 10^3 position-sorted queries per step (latency of one pass)",
+              synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200),
+             ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
+              0, 1, 200)]
     for name, (ichr, qs, qe), v, gflags, steps in cases:
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags)

@@ -37,8 +37,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         x = j["extra_configs"]
-        assert len(x) == 5 and not any("error" in e for e in x), x
-        assert all(e["value"] > 0 for e in x) and x[4]["roofline"]["bound"] == "pcie-d2h" and x[4]["overlaps"] > 0
+        assert len(x) == 7 and not any("error" in e for e in x), x
+        assert all(e["value"] > 0 for e in x) and x[6]["roofline"]["bound"] == "pcie-d2h" and x[6]["overlaps"] > 0
         c = j["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
         assert c["totals_match_gpu"] is True
