@@ -1770,7 +1770,7 @@ __device__ __forceinline__ void for_later_groups(const DbView &db, const SortArg
 // RANK = false: the lean build for batches that are sparse on average (the host decides by queries per tile): no rank
 // method in the kernel at all -- its registers would burden the pairwise path, which is what such a batch runs --
 // and a tile that is dense after all goes to heavy_sorted_body from IGD_LEAN_FIRST first-tile queries on.
-template <bool USE_V, bool CNT32, bool RANK>
+template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
                                           u64 *found = nullptr)
@@ -1926,8 +1926,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         SECT(2);
         // term B: #{first-tile q: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
         {
-            int top = 1, levels = 0;
-            while (top <= c0) { top <<= 1; levels++; }   // c0 < 2^31
+            const int levels = 32 - __builtin_clz((unsigned)c0), top = 1 << levels;   // top = 2^levels > c0 >= IGD_DENSE_MIN, c0 < 2^30
             int pos[IGD_SLOTS];
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
@@ -2152,11 +2151,11 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
             s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
             while (ka >= 0) {
                 s_issue<USE_V, BIG>(db, a, L, kb < 0 ? 0 : kb, kb >= 0, lane, B);
-                s_compute<USE_V, CNT32, RANK>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK);
                 ka = -1;
                 if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
                 s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
-                if (kb >= 0) s_compute<USE_V, CNT32, RANK>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK);
+                if (kb >= 0) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK);
                 kb = -1;
                 if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
 #if IGD_OPT_PRIO
@@ -2181,11 +2180,11 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
             s_issue<USE_V, BIG>(db, a, L, 1, 1 < cntU, lane, B);
             for (int kk = 0; kk < cntU; kk += 3) {
                 s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, C);
-                s_compute<USE_V, CNT32, RANK>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
                 s_issue<USE_V, BIG>(db, a, L, kk + 3, kk + 3 < cntU, lane, A);
-                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
+                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
                 s_issue<USE_V, BIG>(db, a, L, kk + 4, kk + 4 < cntU, lane, B);
-                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK);
+                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK);
 #if IGD_OPT_PRIO
                 done += 3;
                 if (done >= prioAt) {
@@ -2206,9 +2205,9 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32, RANK>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
+            s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
             s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
