@@ -1783,9 +1783,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     const int un = R.n;
     if (un == 0) return;                                 // placeholder of an empty tile
     const int f0 = R.f0;
-    uint32_t W[IGD_SLOTS];
-#pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) W[r] = (uint32_t)__builtin_amdgcn_readlane(L.w[r], kk);
     int cnt[IGD_SLOTS];
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) cnt[r] = 0;
@@ -1815,6 +1812,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #endif
     if (!RANK || !(rankOK && c0 >= IGD_DENSE_MIN)) {
         // ---- pairwise ---------------------------------------------------------------------------
+        uint32_t W[IGD_SLOTS];                           // the slots' summary words (read here: the rank method has no use for them)
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) W[r] = (uint32_t)__builtin_amdgcn_readlane(L.w[r], kk);
         if (USE_V) {
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) if (!keep[r]) R.a[r] = 0u;    // the word nothing matches
@@ -1844,7 +1844,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         SECT(5);                                         // waiting for the unit's records
 #endif
-        const int T = (int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp);
+#define IGD_TILE_START ((int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp))   /* only the seldom-taken branches need it */
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++)
             sl[r * IGD_WAVE + lane] = (unsigned short)(65535u - (R.a[r] & 0xFFFFu));   // lanes past the unit: 65535
@@ -1866,7 +1866,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                int t = load_now(KARG(a.q_qs) + (there ? f0 + p + lane : f0)) - T + 1;   // = qs' for a query of this tile; beyond it: clamped
+                int t = load_now(KARG(a.q_qs) + (there ? f0 + p + lane : f0)) - IGD_TILE_START + 1;   // = qs' for a query of this tile; beyond it: clamped
                 if (!there) t = 65535;
                 t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
                 qs2 = t;
@@ -1892,7 +1892,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         // and its word first touched after (530 queries per tile -- one GPU's slab of an 8-GPU job -- are 9 batches, and
         // a load waited for on the spot made each of them a memory round trip).  Two batches per pass of the loop, so
         // that no loaded word is carried around it.
-        {
+        if (c0 <= IGD_WAVE) batchA(R.q, 0);              // (the usual dense tile: nothing to fetch ahead)
+        else {
             int wa = R.q;
             for (int p = 0; p < c0; p += 2 * IGD_WAVE) {
                 const bool moreB = p + IGD_WAVE < c0, moreA = p + 2 * IGD_WAVE < c0;
@@ -1911,16 +1912,27 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             }
         }
         SECT(1);
-        if (cl && !(IGD_EXP & 8))
-            for_later_groups<true>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
+        auto laterA = [&](int w, bool covers) {
 #if IGD_EXP & 512
-                nLater += __popcll(__ballot(covers));
-                return;
+            nLater += __popcll(__ballot(covers));
+            return;
 #endif
-                const int pos = (IGD_EXP & 128) ? (w & 255) : lds_lower_bound(sl, 65536 - (w & 0xFFFF));
-                if (covers) atomicAdd(&hist[pos], 1u);
-                nLater += __popcll(__ballot(covers));
-            });
+            const int pos = (IGD_EXP & 128) ? (w & 255) : lds_lower_bound(sl, 65536 - (w & 0xFFFF));
+            if (covers) atomicAdd(&hist[pos], 1u);
+            nLater += __popcll(__ballot(covers));
+        };
+        if (cl && !(IGD_EXP & 8)) {
+            // nearly always the candidates' later block has one group of words, the one that came with the records, and the
+            // candidate range lies inside that block: no loop, no look-ups
+            const int sh = a.lbShift, fl = f0 - cl, base = ((f0 - 1) >> sh) << sh;
+            if (__builtin_amdgcn_readlane(R.lw, 63) == 0 && fl >= base) {
+                const int i = base + (int)((unsigned)R.lw >> 22);
+                bool covers;
+                const int w = later_word(db.nbp, R.lw, g, deadk, R.lw != 0 && i >= fl && i < f0, covers);
+                if (__ballot(covers)) laterA(w, covers);
+            } else
+                for_later_groups<true>(db, a, fl, f0, g, deadk, lane, R.lw, laterA);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         SECT(2);
@@ -1972,6 +1984,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 for (int r = 0; r < IGD_SLOTS; r++) pos[r] = (int)((P[r] - sb0) >> 1);
             } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
                 const int32_t *q_qs = KARG(a.q_qs);
+                const int T = IGD_TILE_START;
                 for (int step = top >> 1; step > 0; step >>= 1) {
                     int vq[IGD_SLOTS];
 #pragma unroll
@@ -2001,6 +2014,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
         if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;  // p = 320: queries beyond every record of a full unit
         SECT(4);
+#undef IGD_TILE_START
     }
     // CNT32 (the host has bounded every counter of a launch below 2^32): one 32-bit LDS atomic per slot, for all
     // lanes -- a lane without hits adds 0 (lanes past the unit: to counter 0), which costs LDS lanes but none of the
