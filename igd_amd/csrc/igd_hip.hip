@@ -1680,13 +1680,18 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
 }
 
 // later-tile word (k_query_bounds: later[]) -> compare word for this tile (IGD_NEVER when the query does not reach it)
-__device__ __forceinline__ int later_word(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
+// qe' of a later-tile word in this tile (meaningful where `covers`)
+__device__ __forceinline__ int later_end(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
 {
     const int k = (g - ((e >> 20) & 3)) & 3;             // tiles between the query's first tile and this one (1..3)
     // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); deadk bit k = tile j-k is empty
     covers = inRange && k != 0 && ((e >> 18) & 3) >= k && !((deadk >> k) & 1);
-    int rel = (e & 0x3FFFF) - __mul24(k, nbp);           // qe - T for this tile
-    rel = (rel < nbp ? rel : nbp) + 1;                   // qe'
+    const int rel = (e & 0x3FFFF) - __mul24(k, nbp);     // qe - T for this tile
+    return (rel < nbp ? rel : nbp) + 1;                  // qe'
+}
+__device__ __forceinline__ int later_word(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
+{
+    const int rel = later_end(nbp, e, g, deadk, inRange, covers);
     return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
 }
 
@@ -1928,8 +1933,13 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (__builtin_amdgcn_readlane(R.lw, 63) == 0 && fl >= base) {
                 const int i = base + (int)((unsigned)R.lw >> 22);
                 bool covers;
-                const int w = later_word(db.nbp, R.lw, g, deadk, R.lw != 0 && i >= fl && i < f0, covers);
-                if (__ballot(covers)) laterA(w, covers);
+                const int key = later_end(db.nbp, R.lw, g, deadk, R.lw != 0 && i >= fl && i < f0, covers);
+                const unsigned long long cm = __ballot(covers);
+                if (cm) {
+                    const int pos = (IGD_EXP & (128 | 512)) ? (key & 255) : lds_lower_bound(sl, key);
+                    if (covers && !(IGD_EXP & 512)) atomicAdd(&hist[pos], 1u);
+                    nLater += __popcll(cm);
+                }
             } else
                 for_later_groups<true>(db, a, fl, f0, g, deadk, lane, R.lw, laterA);
         }
@@ -2010,7 +2020,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             const bool prefix = (R.a[r] & 0xFFFFu) == 0xFFFFu;   // starts before the tile: later-tile queries do not count it
             cnt[r] += nFirst + (prefix ? 0 : nLater) - (carry + inc);
             carry += __builtin_amdgcn_readlane(inc, 63);
-            if (r * IGD_WAVE + lane >= un || !keep[r]) cnt[r] = 0;   // no record here / fails the value filter
+            if (R.a[r] == 0u || !keep[r]) cnt[r] = 0;    // no record here (loads past the unit's end return 0; a record word has e' >= 1) / fails the value filter
         }
         if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;  // p = 320: queries beyond every record of a full unit
         SECT(4);
