@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/pmc_scan.sh -- instruction mix of igd_scan_tiles (run on the GPU box): one rocprofv3 --pmc pass per group
-root=$PWD; out=$root/gpurun_out/pmc_scan; mkdir -p $out
+root=$PWD; out=$root/gpurun_out/pmc_scan; rm -rf $out; mkdir -p $out   # (a fresh directory: the summary below averages every file it finds)
 python tools/prep.py > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
