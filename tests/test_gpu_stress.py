@@ -112,3 +112,30 @@ def test_config4_share_of_queries_one_gpu():
         np.testing.assert_array_equal(acc, full)
     finally:
         db.close(); orc.close()
+
+
+def test_mid_size_batch_lean_build_long_queries(workdir):
+    """Between one and eight queries per tile on a database of tens of thousands of tiles: the lean build of
+    igd_scan_sorted fed by k_query_bounds with four queries per thread (>= 65536 queries), with queries up to six tiles
+    long -- later-tile words for one, two and three tiles, full later blocks, queries left to the exact walk -- and
+    unknown contigs; every count against the oracle, in the promised-order, device-decides and bucket modes."""
+    from igd_amd import Database, synth
+    path = os.path.join(workdir, "mid.igd")
+    nbp_log = 9
+    synth.make_db(path, files=24, per_file=8000, seed=5, nbp_log=nbp_log, genome=synth.SMALL)
+    db, orc = Database(path), Oracle(path)
+    try:
+        nT = int(sum(db.ntile))
+        n = max(70000, 3 * nT)
+        if not (nT <= n < 8 * nT):
+            pytest.skip("synthetic genome gives %d tiles: not the regime this test is about" % nT)
+        ichr, qs, qe = synth.make_queries(n, seed=11, genome=synth.SMALL, min_len=1, max_len=6 << nbp_log, sorted_=True,
+                                          unknown_every=97, extra_span=3 << nbp_log)
+        for v in (0, 400):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            for flags in (1, 0, 2):
+                got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                assert gtot == wtot, (v, flags)
+                np.testing.assert_array_equal(got, want, err_msg="v=%d flags=%d" % (v, flags))
+    finally:
+        db.close(); orc.close()
