@@ -2061,6 +2061,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #define IGD_WG_RANK 768         // threads per workgroup / waves per SIMD of the full (rank method) build
 #define IGD_WPE_RANK 6
 #endif
+#ifndef IGD_XCD_REMAP
+#define IGD_XCD_REMAP 0         // 1: an XCD (blockIdx & 7) takes a contiguous eighth of every round of units
+#endif
 #ifndef IGD_LEAN_DEPTH
 #define IGD_LEAN_DEPTH 2        // units in flight per wave in the lean build
 #endif
@@ -2103,7 +2106,12 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
     }
     if (LDS_HITS) __syncthreads();
     const int wavesPerWG = WGT / IGD_WAVE;
-    const int gwave = blockIdx.x * wavesPerWG + wid;
+#if IGD_XCD_REMAP
+    const int lblk = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#else
+    const int lblk = (int)blockIdx.x;
+#endif
+    const int gwave = lblk * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
     Raw2 A, B;
 #if IGD_EXP & 1024
