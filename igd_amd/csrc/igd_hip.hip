@@ -202,12 +202,12 @@ struct igd_hip_db {
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
-    int32_t *d_qw1;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
+    int32_t *d_later;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
     int ldsSorted;                // dynamic LDS of igd_scan_sorted: counters + the waves' rank-method areas
     int32_t maxTileCnt;           // records of the fullest tile
     int sbCap;                    // igd_scan_sorted, rank method: query starts of one tile a wave keeps in LDS
-    int32_t *d_blockLast;         // laterHdr[]: int2 per later block (entries, last tile covered as a later tile)
+    int32_t *d_laterHdr;         // laterHdr[]: int2 per later block (entries, last tile covered as a later tile)
     int lbShift;                  // log2(queries per later block) of the batch in flight
     int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
@@ -2780,7 +2780,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_qw1, db->d_spill, db->d_blockLast,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr,
                     db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
@@ -3181,14 +3181,14 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
         HIPCHK(hipDeviceSynchronize());
         if (db->d_fix) (void)hipFree(db->d_fix);
         if (db->d_qw) (void)hipFree(db->d_qw);
-        if (db->d_qw1) (void)hipFree(db->d_qw1);
-        if (db->d_blockLast) (void)hipFree(db->d_blockLast);
-        db->d_fix = nullptr; db->d_qw = nullptr; db->d_qw1 = nullptr; db->d_blockLast = nullptr;
+        if (db->d_later) (void)hipFree(db->d_later);
+        if (db->d_laterHdr) (void)hipFree(db->d_laterHdr);
+        db->d_fix = nullptr; db->d_qw = nullptr; db->d_later = nullptr; db->d_laterHdr = nullptr;
         db->wsQueries = 0;
         if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
         if ((rc = dalloc(&db->d_qw, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
-        if ((rc = dalloc(&db->d_qw1, (size_t)nq + 1024 + 64, nullptr)) != IGD_HIP_OK) return rc;
-        if ((rc = dalloc(&db->d_blockLast, 2 * ((size_t)nq / 256 + 2), nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_later, (size_t)nq + 1024 + 64, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_laterHdr, 2 * ((size_t)nq / 256 + 2), nullptr)) != IGD_HIP_OK) return rc;
         db->wsQueries = nq;
     }
     if (pairBytes == 0 || (nq <= db->wsBucket && pairBytes <= db->pairBytes)) return IGD_HIP_OK;
@@ -3262,8 +3262,8 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
 static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
 {
     SortArgs sa;
-    sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.later = db->d_qw1; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
-    sa.laterHdr = (const int2 *)db->d_blockLast; sa.lbShift = db->lbShift;
+    sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.later = db->d_later; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
+    sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
     sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
@@ -3368,8 +3368,8 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
 #define QB_GRID(VEC_) ((int)((nq + 256 * VEC_ - 1) / (256 * VEC_)) > fillBlocks ? (int)((nq + 256 * VEC_ - 1) / (256 * VEC_)) : fillBlocks)
 #define QB_LAUNCH(VEC_, FAST_)                                                                                                        \
     k_query_bounds<VEC_, FAST_><<<QB_GRID(VEC_), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, \
-        packed ? 1 : 0, db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_qw1, db->d_spill,                       \
-        (int2 *)db->d_blockLast, mode == 1 ? 1 : 0)
+        packed ? 1 : 0, db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,                       \
+        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
         if (vec) { if (fast) QB_LAUNCH(4, true); else QB_LAUNCH(4, false); }
         else { if (fast) QB_LAUNCH(1, true); else QB_LAUNCH(1, false); }
 #undef QB_LAUNCH
@@ -4161,7 +4161,7 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         if (path == 2) {
             const int64_t nb = (nq + ((int64_t)1 << db->lbShift) - 1) >> db->lbShift;
             std::vector<int32_t> hdr((size_t)nb * 2);
-            e = hipMemcpy(hdr.data(), db->d_blockLast, (size_t)nb * 8, hipMemcpyDeviceToHost);
+            e = hipMemcpy(hdr.data(), db->d_laterHdr, (size_t)nb * 8, hipMemcpyDeviceToHost);
             for (int64_t b = 0; b < nb; b++) nLaterWords += hdr[(size_t)b * 2];
         }
         out->query_bytes = path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
