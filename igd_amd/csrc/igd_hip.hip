@@ -92,7 +92,11 @@ typedef unsigned long long u64;
 #endif
 
 #ifndef IGD_EXP
-#define IGD_EXP 0      // measurement-only builds (WRONG counts): 1 no LDS flush, 2 no per-query compares, 4 no compares at all, 8 no later-tile queries, 32 time stamps, 1024 section timers of the rank method, 64/128/256 rank method without term B / bisections of term A / prefix sums
+#define IGD_EXP 0      // measurement-only builds (bits 1..512 and 8192 give WRONG counts): 1 no LDS flush, 2 no per-query compares,
+                       // 4 no compares at all, 8 no later-tile queries, 64/128/256 rank method without term B / the searches of
+                       // term A / prefix sums, 512 later-tile queries found but not searched, 8192 k_query_bounds without the
+                       // compaction of the later-tile words; 32 time stamps per wave (tools/stamps.py), 1024 section timers of the
+                       // rank method (printed by igd_hip_close)
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
