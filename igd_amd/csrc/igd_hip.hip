@@ -3399,7 +3399,8 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
     const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
                        (db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
-    const size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)(IGD_WLDS_BYTES + 2 * db->sbCap) : 0;
+    // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
+    const size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)IGD_WLDS_BYTES : 0;
     if (db->ldsHits) {
         a.out = db->d_slab;
         const SortK K = make_sortk(db, a);
@@ -3408,12 +3409,14 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         {   // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
+            SortK Kt = K;
+            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES;
             dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
             if (useV)
-                k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(K, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
             else
-                k_reduce_slabs<false><<<rg, 256, tailLds, st>>>(K, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
+                k_reduce_slabs<false><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
                                                                 db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
         }
     } else {
@@ -3425,8 +3428,10 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         {   // total is taken from the growth of sum(hits) here (k_sum_hits), not by the walk
             ScanArgs w = a;
             w.total = nullptr;
-            if (useV) k_exact_walk<true><<<1024, 256, tailLds, st>>>(K, w, db->d_fix, db->d_long, db->d_heavy, valves);
-            else k_exact_walk<false><<<1024, 256, tailLds, st>>>(K, w, db->d_fix, db->d_long, db->d_heavy, valves);
+            SortK Kt = K;
+            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES;
+            if (useV) k_exact_walk<true><<<1024, 256, tailLds, st>>>(Kt, w, db->d_fix, db->d_long, db->d_heavy, valves);
+            else k_exact_walk<false><<<1024, 256, tailLds, st>>>(Kt, w, db->d_fix, db->d_long, db->d_heavy, valves);
         }
         if (d_total) k_sum_hits<<<1, 256, 0, st>>>((const u64 *)d_hits, db->nFiles, (u64 *)d_total, +1);
     }
