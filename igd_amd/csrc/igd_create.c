@@ -439,9 +439,10 @@ int igdc_create(const igdc_create_opts *o)
         Q.files = files; Q.nf = nf; Q.parts = parts; Q.mode = o->mode; Q.linebuf = o->linebuf; Q.next = 0;
         const int nt = n_threads(nf);
         pthread_t th[64];
-        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, pool_run, &Q);
+        int up[64];                                         /* a worker that could not be started is simply missing: the pool is pulled from */
+        for (int t = 1; t < nt; t++) up[t] = pthread_create(&th[t], NULL, pool_run, &Q) == 0;
         pool_run(&Q);
-        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+        for (int t = 1; t < nt; t++) if (up[t]) pthread_join(th[t], NULL);
         int minC = COLCAP, maxC = 0;
         for (int32_t f = 0; f < nf; f++) {
             if (parts[f].failed) rc = 1;                   /* gzopen failed: the reference returns */
@@ -495,9 +496,10 @@ int igdc_create(const igdc_create_opts *o)
         }
         const int nt = n_threads(nparts);
         pthread_t th[64];
-        for (int t = 1; t < nt; t++) pthread_create(&th[t], NULL, gather_run, &G);
+        int up[64];
+        for (int t = 1; t < nt; t++) up[t] = pthread_create(&th[t], NULL, gather_run, &G) == 0;
         gather_run(&G);
-        for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+        for (int t = 1; t < nt; t++) if (up[t]) pthread_join(th[t], NULL);
         for (int32_t f = 0; f < nparts; f++) free(G.map[f]);
         free(G.map);
     }

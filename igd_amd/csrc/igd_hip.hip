@@ -53,6 +53,7 @@
 #include <limits.h>
 #include <vector>
 #include <thread>
+#include <mutex>
 #include <time.h>
 #include <unistd.h>
 
@@ -214,6 +215,8 @@ struct igd_hip_db {
     int32_t *d_laterHdr;         // laterHdr[]: int2 per later block (entries, last tile covered as a later tile)
     int lbShift;                  // log2(queries per later block) of the batch in flight
     int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
+    int forceRank;                // IGD_HIP_RANK at open (tests): 0 lean build, 1 full build, -1 the engine decides
+    bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
     int32_t *d_spBase;            // pairs per coarse bucket
@@ -339,6 +342,10 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
 #define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body
+// The merge join's list can never overflow: a batch has <= IGD_MAX_BATCH queries and a listed tile holds more than
+// IGD_LEAN_FIRST (full build: IGD_HEAVY_FIRST) of them as first-tile queries, each query in exactly one tile.
+#define IGD_HEAVYS_MAX ((int)(IGD_MAX_BATCH / IGD_LEAN_FIRST))
+static_assert(IGD_LEAN_FIRST <= IGD_HEAVY_FIRST, "the list of heavy_sorted_body is sized for the lean build's threshold");
 #define CTL_NLONG 4
 #define CTL_NFIX 6
 #define CTL_BUDGET 8
@@ -2158,7 +2165,8 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
                     L.c0 = firstQ[u.tile + 1] - L.f0;
                     if (spill[u.tile] == a.epoch) L.cl = L.f0 - firstQ[u.tile - lb];
                     // a tile with very many first-tile queries is shared out over all waves (heavy_sorted_body); its own
-                    // waves keep the later-tile candidates.  (<= 2^24 queries per batch: at most 2047 such tiles.)
+                    // waves keep the later-tile candidates.  Every unit of the tile takes the same decision from the same
+                    // count, its first unit lists it; the list holds IGD_HEAVYS_MAX tiles -- more than a batch can have.
                     if (L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST)) {
                         if (u.jf & 1) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
                         L.c0 = 0;
@@ -2293,8 +2301,9 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
     const DbView &db = K.db;
     const SortArgs &a = K.a;
     if (__builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch) return;
-    const int nH = __builtin_amdgcn_readlane(ctlv, CTL_NHEAVYS + (a.epoch & 1));
+    int nH = __builtin_amdgcn_readlane(ctlv, CTL_NHEAVYS + (a.epoch & 1));
     if (nH == 0) return;
+    if (nH > IGD_HEAVYS_MAX) nH = IGD_HEAVYS_MAX;        // (cannot happen: see IGD_HEAVYS_MAX)
     unsigned short *sl = (unsigned short *)wsm;
     unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
     unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
@@ -2302,11 +2311,20 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     const bool rankOK = __builtin_amdgcn_readlane(ctlv, CTL_NOTSTART) != a.epoch;
     long long base = 0;
+    // the listed tiles' ranges are looked up 64 at a time, one tile per lane (the lean build may list thousands: a chain of
+    // dependent loads per tile and wave would cost every wave milliseconds)
+    int lf0 = 0, lc0 = 0, lu0 = 0, lnu = 0;
     for (int h = 0; h < nH; h++) {
-        const int t = __builtin_amdgcn_readfirstlane(a.heavyS[h]);
-        const int f0 = __builtin_amdgcn_readfirstlane(a.firstQ[t]);
-        const int c0 = __builtin_amdgcn_readfirstlane(a.firstQ[t + 1]) - f0;
-        const int u0 = __builtin_amdgcn_readfirstlane(db.tileUnit0[t]), nu = __builtin_amdgcn_readfirstlane(db.tileUnit0[t + 1]) - u0;
+        if ((h & 63) == 0) {
+            lf0 = lc0 = lu0 = lnu = 0;
+            if (h + lane < nH) {
+                const int tl = a.heavyS[h + lane];
+                lf0 = a.firstQ[tl]; lc0 = a.firstQ[tl + 1] - lf0;
+                lu0 = db.tileUnit0[tl]; lnu = db.tileUnit0[tl + 1] - lu0;
+            }
+        }
+        const int f0 = __builtin_amdgcn_readlane(lf0, h & 63), c0 = __builtin_amdgcn_readlane(lc0, h & 63);
+        const int u0 = __builtin_amdgcn_readlane(lu0, h & 63), nu = __builtin_amdgcn_readlane(lnu, h & 63);
         const int ns = (c0 + IGD_HEAVY_SLICE - 1) / IGD_HEAVY_SLICE;
         const long long items = (long long)nu * ns;
         long long it = ((long long)gwave - base % nwaves + nwaves) % nwaves;     // this wave's first item of the tile
@@ -2812,13 +2830,17 @@ extern "C" int64_t igd_hip_resident_bytes(const igd_hip_db *db) { return db ? db
 // expensive, so one released buffer is kept for the next call.
 static void *g_pinCache = nullptr;
 static size_t g_pinCacheBytes = 0;
+static std::mutex g_pinLock;                              // engines of several devices run on threads of one process (igdc_search_multi)
 static void *pinned_take(size_t bytes, size_t *got)
 {
-    if (g_pinCache && g_pinCacheBytes >= bytes) {
-        void *p = g_pinCache;
-        *got = g_pinCacheBytes;
-        g_pinCache = nullptr; g_pinCacheBytes = 0;
-        return p;
+    {
+        std::lock_guard<std::mutex> lk(g_pinLock);
+        if (g_pinCache && g_pinCacheBytes >= bytes) {
+            void *p = g_pinCache;
+            *got = g_pinCacheBytes;
+            g_pinCache = nullptr; g_pinCacheBytes = 0;
+            return p;
+        }
     }
     void *p = nullptr;
     size_t want = bytes + bytes / 8 + 4096;
@@ -2830,11 +2852,13 @@ extern "C" void igd_hip_free(void *p)
 {
     if (!p) return;
     size_t *hdr = (size_t *)((char *)p - 64);            // size header in front of the payload
-    if (g_pinCache) {
-        if (g_pinCacheBytes >= hdr[0]) { (void)hipHostFree(hdr); return; }
-        (void)hipHostFree((char *)g_pinCache);
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pinLock);
+        if (g_pinCache && g_pinCacheBytes >= hdr[0]) drop = hdr;
+        else { drop = g_pinCache; g_pinCache = hdr; g_pinCacheBytes = hdr[0]; }
     }
-    g_pinCache = hdr; g_pinCacheBytes = hdr[0];
+    if (drop) (void)hipHostFree(drop);
 }
 extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_sorted"; }
 
@@ -2882,6 +2906,12 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     OPEN_PHASE("HIP runtime init");
     igd_hip_db *db = new igd_hip_db();   // value-initialised: every field zero
     db->device = device;
+    {   // the environment is read here, once: the per-batch entry points look at nothing but the handle
+        const char *fr = getenv("IGD_HIP_RANK");
+        db->forceRank = fr && *fr ? atoi(fr) : -1;
+        db->qbVec1 = getenv("IGD_HIP_QB_VEC1") != nullptr;
+        db->timing = tim;
+    }
     db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
     db->nRec = d->nRecords;
 
@@ -2978,7 +3008,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + sizeof(Unit) * units.size() + 8 * IGD_HEAVY_MAX +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + sizeof(Unit) * units.size() + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -2996,7 +3026,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_ctgBase, (size_t)d->nCtg + 1, acct));
     TRY(dalloc(&db->d_ctgNTile, (size_t)d->nCtg + 1, acct));
     TRY(dalloc(&db->d_tileUnit0, (size_t)nT + 1, acct));
-    TRY(dalloc(&db->d_heavy, 2 * IGD_HEAVY_MAX, acct));   // bucket path's list, merge join's list
+    TRY(dalloc(&db->d_heavy, IGD_HEAVY_MAX + IGD_HEAVYS_MAX, acct));   // bucket path's list, merge join's list
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -3120,11 +3150,14 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
     }
     if (db->ldsSorted > 64 * 1024) {
-        const void *sfn[] = {(const void *)igd_scan_sorted<false, true, false, false, true>, (const void *)igd_scan_sorted<true, true, false, false, true>,
-                             (const void *)igd_scan_sorted<false, true, true, false, true>, (const void *)igd_scan_sorted<true, true, true, false, true>,
-                             (const void *)igd_scan_sorted<false, true, false, false, false>, (const void *)igd_scan_sorted<true, true, false, false, false>,
+        // every instantiation launch_scan can pick: <USE_V, LDS_HITS, CNT32, BIG, RANK> (CNT32 implies LDS_HITS; BIG only
+        // exists as the full build without CNT32) -- without LDS counters the waves' rank-method areas alone are 75 KiB
+#define IGD_SORTED_FNS(V, LH) (const void *)igd_scan_sorted<V, LH, false, true, true>, (const void *)igd_scan_sorted<V, LH, false, false, false>, \
+                              (const void *)igd_scan_sorted<V, LH, false, false, true>
+        const void *sfn[] = {IGD_SORTED_FNS(false, true), IGD_SORTED_FNS(true, true), IGD_SORTED_FNS(false, false), IGD_SORTED_FNS(true, false),
                              (const void *)igd_scan_sorted<false, true, true, false, false>, (const void *)igd_scan_sorted<true, true, true, false, false>,
-                             (const void *)igd_scan_sorted<false, true, false, true, true>, (const void *)igd_scan_sorted<true, true, false, true, true>};
+                             (const void *)igd_scan_sorted<false, true, true, false, true>, (const void *)igd_scan_sorted<true, true, true, false, true>};
+#undef IGD_SORTED_FNS
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
     }
 #undef TRY
@@ -3299,14 +3332,13 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const SortK K = make_sortk(db, a);
         // sparse on average (fewer than 8 queries per tile): the lean build, whose pairwise path is not burdened with the rank
         // method's registers; tiles that are dense all the same go to heavy_sorted_body
-        const char *fr = getenv("IGD_HIP_RANK");          // tests: 0 lean, 1 full
-        const int forceRank = fr && *fr ? atoi(fr) : -1;
+        const int forceRank = db->forceRank;              // tests: 0 lean, 1 full (IGD_HIP_RANK, read at open)
         // ... and a batch that visits a fraction of the units (fewer queries than tiles) runs the full build too: it steps
         // through the visited units only (10^3 queries: 43.7 -> 13.4 us, 10^5: 44.3 -> 35.7 us; 3 x 10^5: 51.5 vs 53.5 us)
         const bool lean = forceRank >= 0 ? forceRank == 0 : ((int64_t)a.nq < 8ll * db->nT && (int64_t)a.nq >= (int64_t)db->nT);
         if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, ldsS, st>>>(K);
-        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG_LEAN, ldsS, st>>>(K);
+        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG_LEAN, LDS_HITS ? ldsS : 0, st>>>(K);   // (the lean build's only LDS is its counters)
         else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
     } else
@@ -3363,7 +3395,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
     if (mode != 2) {
         bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
-        if (getenv("IGD_HIP_QB_VEC1")) vec = false;   // A/B
+        if (db->qbVec1) vec = false;                  // A/B (IGD_HIP_QB_VEC1, read at open)
         const bool fast = packed && db->v.shift >= 0 && db->nCtg <= QB_CTG;
         // a small batch: one query per thread (more waves share the gaps between its queries), and enough workgroups for
         // the head and tail of firstQ[] -- 10^3 queries left 190 000 entries to ONE workgroup: 90 us
@@ -3504,7 +3536,7 @@ extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int3
     HIPCHK(hipMemsetAsync(db->d_total, 0, 8, st));
     for (int64_t q0 = 0; q0 < nq; q0 += IGD_MAX_BATCH) {
         int64_t m = nq - q0 < IGD_MAX_BATCH ? nq - q0 : IGD_MAX_BATCH;
-        const bool timing = getenv("IGD_TIMING") != nullptr;
+        const bool timing = db->timing;
         auto now = []() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
         double t0 = now();
         int rc = ensure_qstage(db, m);
@@ -3686,8 +3718,12 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
         qa = qb;
         if (nh > 0 || sink) k++;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(db->copyStream);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    {   // both streams are drained whatever happened: after a failed call an earlier chunk's copy may still be writing into
+        // `whole` or a pinned chunk buffer, which are released / reused right below
+        const hipError_t e1 = hipStreamSynchronize(db->copyStream), e2 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e1;
+        if (e == hipSuccess) e = e2;
+    }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess && sink && sinkRc == 0 && prevB > prevA) sinkRc = sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
     ENUM_PHASE("fill + D2H (+ sink)");
@@ -4135,6 +4171,9 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
     u64 *d_acc = nullptr;
     int64_t *d_h = nullptr;
     int rc;
+    // an order promise of the caller's own batches is settled first: the sync that closes this measurement clears the
+    // device's sticky report, and no broken batch may go unreported
+    if (db->promised && (rc = igd_hip_sync(db, db->stream)) != IGD_HIP_OK) return rc;
     if ((rc = dalloc(&d_acc, 4, nullptr)) != IGD_HIP_OK) return rc;
     if ((rc = dalloc(&d_h, (size_t)db->nFiles + 1, nullptr)) != IGD_HIP_OK) { (void)hipFree(d_acc); return rc; }
     hipStream_t st = db->stream;

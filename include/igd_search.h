@@ -10,10 +10,15 @@
  *   - get_overlaps/getOverlaps(/0) return 0 (the reference never increments its counter
  *     there, src/igd_search.c:533), get_overlaps_v/getOverlaps_v return the overlap count;
  *   - not thread-safe (process-wide state), like the reference.
- * New, and the only observable difference: the first search call uploads the whole tile
- * region to the GPU (instead of fseek/fread per tile, :469-476); if no HIP device can be
- * used the call prints the reason on stderr and aborts -- there is no CPU fallback.
- * GPU selection: environment variable IGD_DEVICE (default 0).
+ * New, and the only observable differences:
+ *   - query FILES (getOverlaps*, igd_search -q) run on the GPU: the first such call uploads the
+ *     whole tile region once (instead of fseek/fread per tile, :469-476).  Batches have no CPU
+ *     path: without a usable HIP device the call prints the reason on stderr and returns like
+ *     the reference's silent failures (0 / nothing added); igd_engine_status() keeps the code.
+ *     No library function ever ends the host process;
+ *   - single intervals (get_overlaps*, igd_search -r) are answered on the host from the
+ *     interval's own tiles, exactly as the reference reads them, while no engine is resident.
+ * GPU selection: environment variables IGD_DEVICE (default 0) / IGD_DEVICES=0,1,.. (query slabs).
  *
  * Seqpare: seqOverlaps (src/igd_search.c:354-451) is provided; its per-query helper seq_overlaps
  * (:253-352, fills an overlaps_t for ONE query) is not -- the matching needs all queries at once and

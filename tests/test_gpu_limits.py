@@ -1,0 +1,85 @@
+"""Capacity edges of the merge join (igd_scan_sorted) that ordinary batches never reach:
+  * more heavy tiles than the bucket path's list holds (4096): the lean build hands every tile with more than 512
+    first-tile queries to heavy_sorted_body -- its list must hold every tile a batch can produce;
+  * more dataset files than fit the workgroup's LDS counters (> 15360): the kernels then add to hits[] with global
+    atomics and the full build's rank-method areas alone exceed the 64 KiB a launch gets without opting in.
+Counts bit-exact against the oracle."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from helpers import Oracle, short_tmpdir
+
+pytestmark = pytest.mark.gpu
+PATH = "/tmp/igdb/rm1900x26316.igd"
+
+
+@pytest.fixture(scope="module")
+def workdir():
+    d = short_tmpdir("igl")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _roadmap():
+    from igd_amd import synth
+    if not (os.path.exists(PATH) and os.path.exists(PATH + ".done")):
+        os.makedirs(os.path.dirname(PATH), exist_ok=True)
+        synth.make_db(PATH, files=1900, per_file=26316, seed=1000, nbp_log=14, genome=synth.HG38)
+        open(PATH + ".done", "w").write("ok")
+    return PATH
+
+
+@pytest.mark.parametrize("build", ["lean", "full"])
+def test_more_dense_tiles_than_the_bucket_list_holds(build, monkeypatch):
+    """5000 tiles x 600 queries, position-sorted: under the lean build every one of them is listed for the skew valve."""
+    from igd_amd import Database
+    monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")
+    path = _roadmap()
+    rng = np.random.default_rng(77)
+    tiles, per = 5000, 600
+    first = rng.choice(15000, size=tiles, replace=False)            # tiles of chr1 (248 Mbp = 15 000 tiles of 16 384 bp)
+    qs = (np.repeat(first, per).astype(np.int64) * 16384 + rng.integers(0, 16384, tiles * per)).astype(np.int32)
+    qe = (qs + rng.integers(1, 2500, tiles * per)).astype(np.int32)
+    qe[::997] = qs[::997] - 3                                       # some inverted queries
+    ichr = np.zeros(tiles * per, np.int32)
+    order = np.argsort(qs, kind="stable")
+    ichr, qs, qe = ichr[order], qs[order], qe[order]
+    db, orc = Database(path), Oracle(path)
+    try:
+        want, wtot = orc.search(ichr, qs, qe, 0)
+        for flags in (1, 0):
+            got, gtot = db.search(ichr, qs, qe, 0, flags=flags)
+            assert gtot == wtot, (build, flags)
+            np.testing.assert_array_equal(got, want, err_msg="%s flags=%d" % (build, flags))
+        # ... and the next, ordinary batch on the same handle is not disturbed by what the list held
+        a, b, c = ichr[::50], qs[::50], qe[::50]
+        np.testing.assert_array_equal(db.search(a, b, c, 0, flags=1)[0], orc.search(a, b, c, 0)[0])
+    finally:
+        db.close(); orc.close()
+
+
+@pytest.mark.parametrize("build", ["auto", "lean", "full"])
+def test_more_files_than_lds_counters(build, workdir, monkeypatch):
+    from igd_amd import Database, synth
+    if build != "auto":
+        monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")
+    path = os.path.join(workdir, "manyfiles.igd")
+    if not os.path.exists(path):
+        synth.make_db(path, files=16000, per_file=40, seed=3, nbp_log=12, genome=synth.SMALL)
+    db, orc = Database(path), Oracle(path)
+    try:
+        assert db.nfiles == 16000
+        for n in (3000, 90000):                                     # sparse (pairwise) and dense (rank method in the full build)
+            ichr, qs, qe = synth.make_queries(n, seed=5, genome=synth.SMALL, min_len=1, max_len=9000, sorted_=True,
+                                              unknown_every=211)
+            for v in (0, 500):
+                want, wtot = orc.search(ichr, qs, qe, v)
+                for flags in (1, 0, 2):
+                    got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                    assert gtot == wtot, (build, n, v, flags)
+                    np.testing.assert_array_equal(got, want, err_msg="%s n=%d v=%d flags=%d" % (build, n, v, flags))
+    finally:
+        db.close(); orc.close()
