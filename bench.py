@@ -193,6 +193,21 @@ def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5, extra=()):
     return res
 
 
+def golden_counts(key):
+    """Oracle-computed (total, checksum) of a bench workload: tests/golden/bench_checksums.json, written by
+    tools/make_bench_checksums.py from the CPU oracle.  A data fixture -- nothing of oracle/ runs here."""
+    try:
+        w = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_checksums.json")))["workloads"].get(key)
+        return (w["total"], w["checksum"]) if w else None
+    except Exception:
+        return None
+
+
+def hits_checksum(hits_one):
+    import numpy as np
+    return int((hits_one.astype(np.uint64) * (np.arange(len(hits_one), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1))
+
+
 def pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/profile.sh:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -281,23 +296,33 @@ def extra_configs(db, dev, stream, args, box):
     shuf = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=False)
     dense = synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     slab8 = synth.make_queries_slab(8 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
-    cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100),
-             ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100),
-             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30),
-             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30),
+    cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100, "config2_sorted_q1000000_v500"),
+             ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100, "config2_sorted_q1000000_v0"),
+             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30, "config4_share_q12500000_v0"),
+             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30,
+              "config4_slab0_of_8_v0"),
              ("small batch: 10^3 position-sorted queries per step (latency of one pass)",
-              synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200),
+              synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, None),
              ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
-              0, 1, 200)]
-    for name, (ichr, qs, qe), v, gflags, steps in cases:
+              0, 1, 200, None)]
+    for name, (ichr, qs, qe), v, gflags, steps, gkey in cases:
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags)
             el, prof = job.run(steps, 3)
             rl = job.roofline(prof)
-            out.append({"workload": name, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
-                        "ms_per_step": 1e3 * el / steps, "kernel_ms": prof["scan_ms"], "roofline_frac": rl["frac"],
-                        "bytes_per_launch": rl["bytes_per_launch"], "algorithmic_frac": rl["algorithmic_frac"],
-                        "hits_per_step": int(job.d_hits.sum().item()) // steps})
+            hj = job.d_hits.cpu().numpy()
+            assert (hj % steps == 0).all(), "hits[] is not K times one batch"
+            ent = {"workload": name, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
+                   "ms_per_step": 1e3 * el / steps, "kernel_ms": prof["scan_ms"], "pipeline_ms": prof["pipeline_ms"],
+                   "roofline_frac": rl["frac"],
+                   "bytes_per_launch": rl["bytes_per_launch"], "algorithmic_frac": rl["algorithmic_frac"],
+                   "hits_per_step": int(hj.sum()) // steps, "hits_checksum": hits_checksum(hj // steps)}
+            g = golden_counts(gkey) if gkey else None
+            if g:                                           # the oracle's counts of the same workload (committed fixture)
+                ent["matches_oracle"] = (ent["hits_per_step"], ent["hits_checksum"]) == g
+                if not ent["matches_oracle"]:
+                    ent["error"] = "per-file counts differ from the oracle's (tests/golden/bench_checksums.json[%s])" % gkey
+            out.append(ent)
             del job
         except Exception as e:                              # a side measurement must not lose the line
             out.append({"workload": name, "error": str(e)})
@@ -426,9 +451,24 @@ def main():
                                       % (db.nfiles, args.steps)) if world > 1 else "none"},
             "roofline": rl,
             "hits_per_step_total": int(hits_one.sum()),
-            "hits_checksum": int((hits_one.astype(np.uint64) * (np.arange(len(hits_one), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1)),
+            "hits_checksum": hits_checksum(hits_one),
             "db_open_s": open_s,
         }
+        # the oracle's counts of the same workload (committed fixture): a fast kernel with other counts is not a result
+        gkey = None
+        if args.files == 1900 and args.per_file == 26316 and not args.queries:
+            if world == 1 and args.slab_of == 8:
+                gkey = "config4_slab0_of_8_v%d" % (args.v if mode == "v" else 0)
+            elif world == 1 and args.slab_of <= 1:
+                gkey = "config2_sorted_q1000000_v%d" % (args.v if mode == "v" else 0)
+        elif args.files == 1900 and args.per_file == 26316 and world == 1 and args.queries == CONFIG4_PER_GPU and not args.shuffled and args.slab_of <= 1:
+            gkey = "config4_share_q12500000_v%d" % (args.v if mode == "v" else 0)
+        g = golden_counts(gkey) if gkey else None
+        if g:
+            line["matches_oracle"] = (line["hits_per_step_total"], line["hits_checksum"]) == g
+            if not line["matches_oracle"]:
+                raise SystemExit("bench.py: per-file counts differ from the oracle's (tests/golden/bench_checksums.json[%s]): %s vs %s"
+                                 % (gkey, (line["hits_per_step_total"], line["hits_checksum"]), g))
         if world == 1 and not args.no_cpu:
             bed = os.path.join(args.dir, "q%d_%s.bed" % (Q, "shuf" if args.shuffled else "sorted"))
             if not os.path.exists(bed):

@@ -92,14 +92,20 @@ def test_wide_tiles_use_exact_arrays(workdir):
         db.close(); orc.close()
 
 
-def test_config4_share_of_queries_one_gpu():
-    """1.25e7 queries in ONE device batch (BASELINE config 4: 1e8 over 8 GPUs)."""
-    from igd_amd import Database, synth
+def _roadmap():
+    from igd_amd import synth
     path = "/tmp/igdb/rm1900x26316.igd"
     if not os.path.exists(path + ".done"):
         os.makedirs("/tmp/igdb", exist_ok=True)
         synth.make_db(path)
         open(path + ".done", "w").write("ok")
+    return path
+
+
+def test_config4_share_of_queries_one_gpu():
+    """1.25e7 queries in ONE device batch (BASELINE config 4: 1e8 over 8 GPUs)."""
+    from igd_amd import Database, synth
+    path = _roadmap()
     db, orc = Database(path), Oracle(path)
     try:
         Q = 12500000
@@ -110,6 +116,46 @@ def test_config4_share_of_queries_one_gpu():
             lo, hi = k * Q // 8, (k + 1) * Q // 8
             acc += db.search(ichr[lo:hi], qs[lo:hi], qe[lo:hi])[0]
         np.testing.assert_array_equal(acc, full)
+    finally:
+        db.close(); orc.close()
+
+
+def _golden(key):
+    import json
+    from helpers import GOLDEN
+    w = json.load(open(os.path.join(GOLDEN, "bench_checksums.json")))["workloads"][key]
+    return w["total"], w["checksum"]
+
+
+def _checksum(h):
+    return int((h.astype(np.uint64) * (np.arange(len(h), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1))
+
+
+@pytest.mark.parametrize("workload", ["config4_share_q12500000", "config4_slab0_of_8"])
+def test_dense_batches_whole_against_the_oracle(workload):
+    """The rank method at the scale bench.py runs it: config 4's per-GPU share (1.25e7 position-sorted queries, ~66 per
+    tile) and one GPU's slab of the 8-GPU job (~530 per tile on an eighth of the tiles) -- EVERY query of the batch
+    against the oracle (not a sample: a sample is sparse and takes the pairwise path), with and without the value filter,
+    under the order promise and with the device deciding; and against the committed oracle checksums bench.py uses."""
+    from igd_amd import Database, synth
+    path = _roadmap()
+    n = 12500000
+    if workload == "config4_share_q12500000":
+        ichr, qs, qe = synth.make_queries_slab(n, 0, n, seed=7, genome=synth.HG38)
+        a = synth.make_queries(n, seed=7, genome=synth.HG38, sorted_=True)       # what `bench.py --queries 12500000` runs
+        assert all(np.array_equal(x, y) for x, y in zip(a, (ichr, qs, qe)))
+        del a
+    else:
+        ichr, qs, qe = synth.make_queries_slab(8 * n, 0, n, seed=7, genome=synth.HG38)
+    db, orc = Database(path), Oracle(path)
+    try:
+        for v in (0, 500):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            assert (int(wtot), _checksum(want)) == _golden("%s_v%d" % (workload, v))
+            for flags in (1, 0):
+                got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                assert gtot == wtot, (workload, v, flags)
+                np.testing.assert_array_equal(got, want, err_msg="%s v=%d flags=%d" % (workload, v, flags))
     finally:
         db.close(); orc.close()
 
