@@ -206,6 +206,7 @@ struct igd_hip_db {
     int32_t nUnits;
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
+    int32_t *d_lpos;              // [nT+1] lpos[]: entries of its later block before query firstQ[t] (k_query_bounds)
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
     int32_t *d_later;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
@@ -402,35 +403,40 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 //              the image cannot express, listed as WALK_FIRST).  Stored inverted so that a bounds-checked
 //              buffer load past a tile's last query (which returns 0) reads as "never matches".
 //     later[]: the queries that also cover LATER tiles (6 % of the benchmark's), compacted per "later block" (the
-//              256 * VEC consecutive queries of one workgroup; region [B << lbShift, ...) of the array), in query
+//              WGT * VEC consecutive queries of one workgroup; region [B << lbShift, ...) of the array), in query
 //              order, one word each:  min(qe - T0, 4W) [bits 0..17] | min(span, 3) << 18 | (first global tile & 3) << 20
-//              | (index inside the block) << 22 -- all a later tile needs (there, qs' = 1 and
-//              qe' = min(qeRel - k W, W) + 1; k = (tile - first tile) follows from 2 bits).  Zeros follow the last entry
-//              up to the end of its group of 64 (an entry is never 0): the scan reads a block's first group blind,
-//              together with the unit's records, and goes on while the group it holds is full.
-//     laterHdr[B] = (entries of block B, last tile any of them covers): for the groups after the first and the
-//              blocks before the last -- a block none of whose queries reaches a tile is skipped unread.
+//              -- all a later tile needs (there, qs' = 1 and qe' = min(qeRel - k W, W) + 1; k = (tile - first tile)
+//              follows from 2 bits).  An entry is never 0.
+//     lpos[t]  = the number of entries of ITS block that come from queries before firstQ[t]: with firstQ[] itself that
+//              makes the later-tile candidates of a tile -- the entries of the queries [firstQ[t - 3], firstQ[t]) -- one
+//              run of words (two when the range crosses a block boundary) the scan reads without any search.
+//     laterHdr[B] = (entries of block B, last tile any of them covers).
 //     spill[t] = epoch for every tile t that some query covers as a later tile (k = 1..3): most units have
 //              none and never look at the queries of the tiles before theirs.
 //   exact arrays (packed == 0):
 //     qw0[i] = (global number of the first tile) << 4 | min(n2 - n1, 15), -1 when it visits nothing.
 // VEC queries per thread (4: the three query arrays are read, and the word arrays written, as dwordx4 -- a quarter of
 // the memory instructions and four independent chains per thread; 1: arrays that are not 16-byte aligned).
+// WGT threads per workgroup = WGT * VEC queries per later block: 1024 x 4 for the large batches, whose tiles have so many
+// queries that the candidate range of a tile (the queries of three tiles) would span several smaller blocks.
 // FAST: the usual case, decided by the host -- compact image, power-of-two tile size, contig tables that fit the LDS arrays --
-// compiled without the other cases' branches (a flat load picking between LDS and global tables, a division).
-template <int VEC, bool FAST>
-__global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
+// compiled without the other cases' branches (a flat load picking between LDS and global tables, a division), and with a
+// short path for the waves all of whose queries lie in ONE contig, in range and in order (every wave of a large sorted
+// batch but a few): keys and words from the wave's scalar contig base, nothing looked up or clamped per query.
+template <int VEC, bool FAST, int WGT>
+__global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
-                                                      int packed_, int32_t *__restrict__ firstQ,
+                                                      int packed_, int32_t *__restrict__ firstQ, int32_t *__restrict__ lpos,
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ later,
                                                       int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
+    constexpr int NW = WGT / IGD_WAVE;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
     // and the batch's state is looked up (a workgroup that then leaves at once has read 12 KiB for nothing).
-    const int i0 = (int)(blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    const int i0 = (int)(blockIdx.x * WGT + threadIdx.x) * VEC;
     int qc[VEC], qs_[VEC], qe_[VEC];
     if (VEC == 4) {
         int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
@@ -449,17 +455,24 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
+    __shared__ int sCnt[NW];
     const bool ldsTab = FAST || db.nCtg <= QB_CTG;
     const int packed = FAST ? 1 : packed_;
-    if (ldsTab) {
-        for (int c = threadIdx.x; c < db.nCtg; c += blockDim.x) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
-        __syncthreads();
-    }
+    // Has any wave found the batch unordered already?  ONE device-scope load per workgroup (an L1-cached one would keep
+    // returning the stale line): a load per wave -- 10^5 requests for the one address at 1.25e7 queries -- queued up at
+    // its memory channel for as long as the rest of the kernel takes.
+    __shared__ int sSeen;
+    int seen = 0;
+    if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
+    if (threadIdx.x < NW) sCnt[threadIdx.x] = 0;          // (a wave that leaves early counts as one without entries)
+    if (ldsTab)
+        for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
+    __syncthreads();
 #define QB_BASE(c) (FAST ? sBase[c] : (ldsTab ? sBase[c] : db.ctgBase[c]))
 #define QB_NTILE(c) (FAST ? sNTile[c] : (ldsTab ? sNTile[c] : db.ctgNTile[c]))
 #define QB_TILE(x) (FAST ? tile_shift(x, db.shift) : tile_of(db, x))
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * blockDim.x) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
+    const int t = blockIdx.x * WGT + threadIdx.x;
+    if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * WGT) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
     if (zeroTotal && t == 0) *zeroTotal = 0;
     if (t == 0) {                                           // next batch's list counters
         ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
@@ -470,10 +483,57 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
-    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here.  A device-scope
-    // load: an L1-cached one would keep returning the stale line and the whole unordered batch would be worked
-    // through, gap filling included (5 -> 50 us).
-    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch) return;
+    // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here (an unordered batch
+    // worked through to the end, gap filling included, took 50 instead of 5 us).
+    int w0v[VEC], w1v[VEC];
+    int key[VEC], lo[VEC];
+    bool quick = false;
+    if (FAST && VEC == 4) {
+        // ---- the short path: the wave's 256 queries and the one before them lie in one contig, inside its tiles, with
+        // non-negative starts in non-decreasing order, and none is inverted over its tile's start or longer than four tiles
+        const int W = db.nbp, sh = db.shift;
+        const int cu = __builtin_amdgcn_readfirstlane(qc[0]);
+        int a_[VEC], d_[VEC];
+        // (bitwise on purpose: one straight run of compares, no branch per term)
+        int ok = (i0 + 3 < nq) & (i0 > 0) & (pc == cu) & (ps >= 0);
+        int prev = ps;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            a_[v] = qs_[v] & (W - 1);
+            d_[v] = qe_[v] - (qs_[v] - a_[v]);              // qe - T0
+            ok &= (qc[v] == cu) & (qs_[v] >= prev) & ((unsigned)(d_[v] - 1) < (unsigned)(4 * W));   // 0 < qe - T0 <= 4W
+            prev = qs_[v];
+        }
+        if (__builtin_amdgcn_readfirstlane((unsigned)cu < (unsigned)db.nCtg ? 1 : 0)) {
+            const int cm = __builtin_amdgcn_readfirstlane(sNTile[cu]) - 1, cb = __builtin_amdgcn_readfirstlane(sBase[cu]);
+            ok &= (qs_[VEC - 1] >> sh) <= cm;               // (starts are ordered: the last one's tile bounds them all)
+            if (__ballot(ok != 0) == ~0ull) {
+                quick = true;
+                int pk = cb + (ps >> sh);
+#pragma unroll
+                for (int v = 0; v < VEC; v++) {
+                    const int n1 = qs_[v] >> sh;
+                    key[v] = cb + n1;
+                    lo[v] = pk + 1;
+                    pk = key[v];
+                    // ~query_word(): low half qe' - 1 = min(qe - T0, W), high half 65535 - qs' = 65534 - (qs - T0)
+                    w0v[v] = (d_[v] < W ? d_[v] : W) | ((65534 - a_[v]) << 16);
+                    w1v[v] = 0;
+                    if (d_[v] > W) {                        // reaches beyond its first tile -- unless that is the contig's last
+                        int n2 = (qe_[v] - 1) >> sh;
+                        if (n2 > cm) n2 = cm;
+                        const int sp = n2 - n1;             // 0..3 (d <= 4W)
+                        if (sp > 0) {
+                            w1v[v] = d_[v] | (sp << 18) | ((key[v] & 3) << 20);
+                            spill[key[v] + 1] = epoch;
+                            if (sp > 1) { spill[key[v] + 2] = epoch; if (sp > 2) spill[key[v] + 3] = epoch; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (!quick) {
     // predecessor of the thread's first query
     int prevKey = -1;
     if (i0 > 0 && i0 < nq) {
@@ -486,11 +546,8 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
             }
         } else prevKey = tile_key(db, pc, ps);
     }
-    int w0v[VEC], w1v[VEC];
-    const bool marked = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;   // by another wave, meanwhile
-    int lastTile = -1;                                      // last tile one of the thread's queries covers as a LATER tile
     // 1. keys and order of the thread's queries (query i0 + v fills firstQ[lo[v]..key[v]] = i0 + v)
-    int key[VEC], lo[VEC], cBase[VEC], cMT[VEC];
+    int cBase[VEC], cMT[VEC];
     bool unordered = false, notStart = false;
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
@@ -520,7 +577,7 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
         if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
                                                                             // the merge join still holds, the rank method does not
         if (bu) {
-            if (!marked && lane == __builtin_ctzll(bu)) {
+            if (lane == __builtin_ctzll(bu)) {
                 ctl[CTL_UNSORTED] = epoch;
                 if (promised) ctl[CTL_BROKEN] = epoch;      // sticky until the next igd_hip_sync (any promised batch since)
             }
@@ -553,14 +610,53 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
                     const int sp = span < IGD_SHORT_TILES - 1 ? span : IGD_SHORT_TILES - 1;
                     int rel = e0 - T0;                      // > W here, since the query reaches the next tile
                     if (rel > 4 * db.nbp) rel = 4 * db.nbp;
-                    w1v[v] = rel | (sp << 18) | ((g0 & 3) << 20) | ((int)(threadIdx.x * VEC + v) << 22);
+                    w1v[v] = rel | (sp << 18) | ((g0 & 3) << 20);
                     for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
-                    if (g0 + sp > lastTile) lastTile = g0 + sp;
                 }
             }
         }
     }
-    // 4. firstQ: short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
+    }
+#undef QB_BASE
+#undef QB_NTILE
+#undef QB_TILE
+    // 4. the workgroup's later-tile words are compacted in query order into its block of later[]: position of each
+    // query's (possible) entry = entries of the queries before it in the block.  (A wave that left above is not waited
+    // for by the barrier -- and nothing of an unordered batch's block is read.)
+    int pos[VEC];
+    int total = 0;
+    const bool blockLive = packed && (long long)blockIdx.x * (WGT * VEC) < nq;   // (workgroups past the queries only help filling firstQ[])
+#pragma unroll
+    for (int v = 0; v < VEC; v++) pos[v] = 0;
+    int c = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) c += w1v[v] != 0 ? 1 : 0;
+    const int inc = wave_inclusive_sum(c);
+    if (lane == 63) sCnt[threadIdx.x >> 6] = inc;
+    // Once any wave has found the batch unordered nothing this kernel produces is going to be read (the merge join is
+    // off, the bucket path keeps its own lists): workgroups that see the mark stop here, before they store anything (an
+    // unordered batch worked through to the end, gap filling included, took 50 instead of 5 us).
+    if (threadIdx.x == 0) sSeen = seen;
+    __syncthreads();
+    const bool marked = sSeen == epoch;
+    if (marked) return;
+    if (blockLive && !(IGD_EXP & 8192)) {
+        // entries of the waves before this one / of the whole block: one LDS read per lane and a wave scan (the numbers
+        // are the same for all lanes of a wave)
+        const int mine = lane < NW ? sCnt[lane] : 0;
+        const int run = wave_inclusive_sum(mine);
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        total = __builtin_amdgcn_readlane(run, NW - 1);
+        int off = inc - c + (wv > 0 ? __builtin_amdgcn_readlane(run, wv - 1) : 0);
+        int32_t *reg = later + (size_t)blockIdx.x * (WGT * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            pos[v] = off;
+            if (w1v[v] != 0) reg[off++] = w1v[v];
+        }
+        if (threadIdx.x == 0) laterHdr[blockIdx.x] = make_int2(total, 0);
+    }
+    // 5. firstQ (+ lpos): short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
     // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
     // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
     // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
@@ -569,9 +665,11 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
     if (!marked) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-            const int i = i0 + v, l1 = lo[v], h1 = key[v];
+            const int i = i0 + v, l1 = lo[v], h1 = key[v], p1 = pos[v];
+            const bool some = h1 >= l1;
+            if (quick && __ballot(some) == 0) continue;     // (a dense batch: most queries share their tile with the one before)
             const bool big = h1 - l1 >= 8;
-            if (!big) for (int tt = l1; tt <= h1; tt++) firstQ[tt] = i;
+            if (!big) for (int tt = l1; tt <= h1; tt++) { firstQ[tt] = i; lpos[tt] = p1; }
             unsigned long long m = __ballot(big);
             if (m == 0) continue;
             // the budget is charged once for all long gaps of the wave's 64 queries (a returning atomic each made a small
@@ -595,15 +693,12 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
                 const int src = __builtin_ctzll(m);
                 m &= m - 1;
                 const int l2 = __builtin_amdgcn_readlane(l1, src), h2 = __builtin_amdgcn_readlane(h1, src);
-                const int v2 = __builtin_amdgcn_readlane(i, src);
+                const int v2 = __builtin_amdgcn_readlane(i, src), p2 = __builtin_amdgcn_readlane(p1, src);
                 if (over && h2 - l2 >= 256) continue;
-                for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) firstQ[tt] = v2;
+                for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) { firstQ[tt] = v2; lpos[tt] = p2; }
             }
         }
     }
-#undef QB_BASE
-#undef QB_NTILE
-#undef QB_TILE
     if (VEC == 4) {
         if (i0 + 3 < nq) *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
         else {
@@ -612,41 +707,18 @@ __global__ __launch_bounds__(256, 7) void k_query_bounds(DbView db, const int32_
                 if (i0 + v < nq) qw0[i0 + v] = w0v[v];
         }
     } else if (i0 < nq) qw0[i0] = w0v[0];
-    if (packed && !(IGD_EXP & 8192) && (long long)blockIdx.x * (256 * VEC) < nq) {   // (workgroups past the queries only help filling firstQ[])
-        // the workgroup's later-tile words, compacted in query order into its block of later[].  (A wave that left above
-        // is not waited for by the barrier -- and nothing of an unordered batch's block is read.)
-        __shared__ int sCnt[4], sMax[4];
-        int c = 0;
-#pragma unroll
-        for (int v = 0; v < VEC; v++) c += w1v[v] != 0 ? 1 : 0;
-        const int inc = wave_inclusive_sum(c);
-        int mx = lastTile;
-        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(mx, o); mx = y > mx ? y : mx; }
-        if (lane == 63) { sCnt[threadIdx.x >> 6] = inc; sMax[threadIdx.x >> 6] = mx; }
-        __syncthreads();
-        int off = inc - c, total = 0, bmx = -1;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w < (int)(threadIdx.x >> 6)) off += sCnt[w];
-            total += sCnt[w];
-            bmx = sMax[w] > bmx ? sMax[w] : bmx;
-        }
-        int32_t *reg = later + (size_t)blockIdx.x * (256 * VEC);
-#pragma unroll
-        for (int v = 0; v < VEC; v++)
-            if (w1v[v] != 0) reg[off++] = w1v[v];
-        const int padEnd = ((total + 64) & ~63) < 256 * VEC ? ((total + 64) & ~63) : 256 * VEC;
-        if (total + (int)threadIdx.x < padEnd) reg[total + threadIdx.x] = 0;
-        if (threadIdx.x == 0) laterHdr[blockIdx.x] = make_int2(total, bmx);
-    }
     // head and tail of firstQ[] -- the tiles up to the first query's key and after the last one's, together all the
     // tiles a batch does not reach (7/8 of them for one GPU's slab of an 8-GPU job) -- are filled by the whole grid:
-    // left to the first / last query's own wave they took longer than everything else in this kernel
+    // left to the first / last query's own wave they took longer than everything else in this kernel.  lpos[] of the
+    // first three tiles after the last query's (all that a query can still reach) = the entries of the last block, if the
+    // queries end inside it: written by that block's own workgroup.
     if (nq > 0) {
         const int k0 = tile_key(db, ichr[0], qs[0]), kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
-        const int nth = gridDim.x * blockDim.x;
-        for (int tt = t; tt <= k0; tt += nth) firstQ[tt] = 0;
+        const int nth = gridDim.x * WGT;
+        for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; lpos[tt] = 0; }
         for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;
+        if ((int)blockIdx.x == (nq - 1) / (WGT * VEC) && (int)threadIdx.x < IGD_SHORT_TILES - 1 && kl + 1 + (int)threadIdx.x <= db.nT)
+            lpos[kl + 1 + threadIdx.x] = (nq % (WGT * VEC)) != 0 ? total : 0;
     }
 }
 
@@ -1555,8 +1627,9 @@ struct SortArgs {
     const int32_t *firstQ;       // [nT+1] first query of each tile
     const int32_t *spill;        // [nT]   == epoch: some query covers the tile as a later tile
     const int32_t *qw0, *later;  // per-query first-tile words; later-tile words, compacted per later block (k_query_bounds)
+    const int32_t *lpos;         // [nT+1] entries of its later block before query firstQ[t]
     const int2 *laterHdr;        // per later block: (entries, last tile covered as a later tile)
-    int lbShift;                 // log2(queries per later block): 10 (k_query_bounds<4>) or 8 (<1>)
+    int lbShift;                 // log2(queries per later block): 8, 10 or 12 (k_query_bounds<VEC, ., WGT>)
     const int32_t *q_qs;         // the caller's query starts (rank method: exceptions, and tiles with more queries than sbCap)
     const int32_t *ctl;
     int nq, v, epoch, mode, rule;
@@ -1581,14 +1654,24 @@ __device__ __forceinline__ T karg_load(unsigned off)
 #define KARG(field) karg_load<decltype(((SortK *)0)->field)>((unsigned)offsetof(SortK, field))
 
 // A unit's descriptor and query ranges, one unit per lane (broadcast with v_readlane when its turn comes)
-struct SRegs { int32_t offLo, offHi, n, g /* global tile */, jf, w[IGD_SLOTS], f0, c0, cl; };
+// la / ln: the tile's later-tile candidates -- the later[] entries of the queries of the (up to) 3 tiles before it -- as
+// k_query_bounds' lpos[] places them: nA words from index la on, then nB words from the start of the block that holds
+// query f0 (the range crossed a block boundary).  ln = nA | nB << 13 | (global tile & 3) << 26 | far << 28; far: more
+// than 64 words, or more than one boundary crossed -- such a unit walks the blocks (far_later); 0: no candidates.
+#define IGD_LN_A(ln) ((ln) & 8191)
+#define IGD_LN_B(ln) (((ln) >> 13) & 8191)
+#define IGD_LN_G2(ln) (((ln) >> 26) & 3)
+#define IGD_LN_FAR(ln) (((ln) >> 28) & 1)
+struct SRegs { int32_t offLo, offHi, n, jf, w[IGD_SLOTS], f0, c0, la, ln; };
 
 struct Raw2 {
     uint32_t a[IGD_SLOTS];       // s' | e' << 16 (inverted s', see k_pack_units)
     int32_t x[IGD_SLOTS];        // idx (| value << 16)
-    int32_t q;                   // first 64 first-tile words (already un-inverted)
-    int32_t lw;                  // first group of later-tile words of the block the tile's predecessors end in (0 = no entry)
-    int32_t c0, cl, f0, n;       // wave-uniform (SGPRs): the unit's query ranges and record count, kept from the issue
+    // The unit's candidates form ONE list: its nl later-tile entries first (not far: nl = nA + nB <= 64), then its c0
+    // first-tile queries; the first 64 of the list come with the records:
+    int32_t q;                   // lanes nl ..: first-tile words (already un-inverted; IGD_NEVER where there is none)
+    int32_t lw;                  // lanes 0 .. nl-1: later[] entries (0 where there is none)
+    int32_t c0, ln, f0, n;       // wave-uniform (SGPRs): the unit's query ranges and record count, kept from the issue
 };
 
 // Branch-free on purpose (see issue_unit): the same number of loads whatever the unit looks like, so that
@@ -1602,11 +1685,11 @@ template <bool USE_V, bool BIG>
 __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, const SRegs &L, int kk, bool valid, int lane, Raw2 &R)
 {
     const int kq = kk & 63;
-    int c0 = __builtin_amdgcn_readlane(L.c0, kq), cl = __builtin_amdgcn_readlane(L.cl, kq);
-    if (!valid) { c0 = 0; cl = 0; }
+    int c0 = __builtin_amdgcn_readlane(L.c0, kq), ln = __builtin_amdgcn_readlane(L.ln, kq);
+    if (!valid) { c0 = 0; ln = 0; }
     const int f0 = __builtin_amdgcn_readlane(L.f0, kq);
-    const int n = (c0 | cl) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
-    R.c0 = c0; R.cl = cl; R.f0 = f0; R.n = n;
+    const int n = (c0 | ln) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
+    R.c0 = c0; R.ln = ln; R.f0 = f0; R.n = n;
     const unsigned offLo = (unsigned)__builtin_amdgcn_readlane(L.offLo, kq);
     const int vo4 = lane * 4, vo2 = lane * 2;
     if (BIG) {
@@ -1646,14 +1729,22 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
             }
         }
     }
-    // the first 64 first-tile words (no memory access when there are none), and -- for the 29 % of the units that
-    // have later-tile candidates -- the first group of later-tile words of the block that holds the last of them
-    const int b0 = c0 < IGD_WAVE ? c0 : IGD_WAVE;
+    // The first 64 entries of the unit's candidate list (see Raw2): its later-tile entries in lanes 0 .. nl-1 -- one run
+    // of later[] words, or two when the candidate range crosses a block boundary; none for the 71 % of the units no query
+    // reaches as a later tile -- and behind them the first-tile words.  Lanes outside either run are out of the buffers'
+    // range: they read 0 (no memory access at all when a run is empty).
+    const int nA = IGD_LN_FAR(ln) ? 0 : IGD_LN_A(ln), nB = IGD_LN_FAR(ln) ? 0 : IGD_LN_B(ln);
+    const int nl = nA + nB;
+    const int b0 = c0 < IGD_WAVE - nl ? c0 : IGD_WAVE - nl;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, (f0 + b0) * 4, 0x00020000);
-    R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, vo4, f0 * 4, 0);             // past the last query: ~0 = IGD_NEVER
-    const int lb = (int)((unsigned)((f0 - 1) >> a.lbShift) << a.lbShift);
-    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void *)a.later, 0, cl ? (lb + IGD_WAVE) * 4 : 0, 0x00020000);
-    R.lw = (int)__builtin_amdgcn_raw_buffer_load_b32(rsL, vo4, lb * 4, 0);
+    int voq = vo4;
+    if (nl) voq = lane < nl ? 0x7FFFFF00 : vo4 - nl * 4;                               // (the later-tile lanes: far out of range)
+    R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, voq, f0 * 4, 0);             // before / past the tile's queries: ~0 = IGD_NEVER
+    const int la = nl ? __builtin_amdgcn_readlane(L.la, kq) : 0;
+    const int aB = (int)((unsigned)(f0 >> a.lbShift) << a.lbShift);                    // first entry of the block that holds query f0
+    const int thr = nB ? nA : IGD_WAVE;                                                // lanes from here on read the second run
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void *)a.later, 0, (nB ? aB + nB : la + nA) * 4, 0x00020000);
+    R.lw = (int)__builtin_amdgcn_raw_buffer_load_b32(rsL, vo4 + (lane < thr ? la : aB - nA) * 4, 0, 0);
 }
 
 // The queries of one batch of <= 64 candidates (word `P0` per lane, IGD_NEVER where there is none) against the
@@ -1691,18 +1782,19 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
 }
 
 // later-tile word (k_query_bounds: later[]) -> compare word for this tile (IGD_NEVER when the query does not reach it)
-// qe' of a later-tile word in this tile (meaningful where `covers`)
-__device__ __forceinline__ int later_end(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
+// qe' of a later-tile word in this tile (meaningful where `covers`).  g2 = the tile's global number & 3; an entry is
+// never 0, and a load outside the candidates' run returns 0.
+__device__ __forceinline__ int later_end(int nbp, int e, int g2, int deadk, bool inRange, bool &covers)
 {
-    const int k = (g - ((e >> 20) & 3)) & 3;             // tiles between the query's first tile and this one (1..3)
+    const int k = (g2 - (e >> 20)) & 3;                  // tiles between the query's first tile and this one (1..3)
     // rule NEST: a query whose FIRST tile is empty is dead (src/igd_search.c:468); deadk bit k = tile j-k is empty
-    covers = inRange && k != 0 && ((e >> 18) & 3) >= k && !((deadk >> k) & 1);
+    covers = inRange && e != 0 && k != 0 && ((e >> 18) & 3) >= k && !((deadk >> k) & 1);
     const int rel = (e & 0x3FFFF) - __mul24(k, nbp);     // qe - T for this tile
     return (rel < nbp ? rel : nbp) + 1;                  // qe'
 }
-__device__ __forceinline__ int later_word(int nbp, int e, int g, int deadk, bool inRange, bool &covers)
+__device__ __forceinline__ int later_word(int nbp, int e, int g2, int deadk, bool inRange, bool &covers)
 {
-    const int rel = later_end(nbp, e, g, deadk, inRange, covers);
+    const int rel = later_end(nbp, e, g2, deadk, inRange, covers);
     return covers ? (int)((unsigned)(65536 - rel) | (1u << 16)) : (int)IGD_NEVER;
 }
 
@@ -1730,56 +1822,28 @@ __device__ __forceinline__ int load_now(const int32_t *p)
     return v;
 }
 
-// The later-tile candidates of a unit: the later[] entries of the queries [fl, f0) of the (up to) 3 tiles before its
-// tile.  They sit in the later block that holds query f0 - 1 -- whose first group of 64 words `lw` came with the unit's
-// records -- and, when the range reaches back across a block boundary, in the blocks before it (read only if the
-// header says one of their queries reaches this tile).  Entries are in query order: the groups in front of the range
-// are skipped by bisection over the groups' last words, the scan ends with the first group that ends beyond it.
-// FN(word, covers) is called once per group that holds a covering query, with every lane's compare word.
+// A unit whose later-tile candidates do not come with its records (IGD_LN_FAR: more than 64 entries -- tiles behind a
+// very dense one -- or a candidate range that crosses more than one block boundary) walks them here: nA entries from
+// index la on, every entry of the blocks in between (their number: laterHdr[]), the first nB of the block that holds
+// query f0.  FN(entries) is called per batch of <= 64 (0 in the lanes past a run's end).
 template <bool KA, typename FN>
-__device__ __forceinline__ void for_later_groups(const DbView &db, const SortArgs &a, int fl, int f0, int g, int deadk, int lane,
-                                                 int lw, FN fn)
+__device__ __forceinline__ void far_later(const SortArgs &a, int la, int ln, int f0, int lane, FN fn)
 {
     const int sh = a.lbShift;
-    const int nbp = db.nbp;
-    const int blo = fl >> sh;
-    int e = lw;
-    for (int b = (f0 - 1) >> sh;;) {
-        const int base = b << sh;
-        int gi = 0, ng = 0;                               // ng: groups of the block (looked up when the first one is full)
-        for (;;) {
-            const int e63 = __builtin_amdgcn_readlane(e, 63);
-            const bool full = e63 != 0;
-            if (full && base + (int)((unsigned)e63 >> 22) < fl) {
-                // the whole group lies in front of the range: find the first group that does not
-                const int32_t *later = KA ? KARG(a.later) : a.later;   // (kernel-argument loads stay in the branches that need them)
-                if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
-                int lo = gi + 1, hi = ng;                 // the answer is in [lo, hi]; hi = ng: no such group
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const int x = KA ? __builtin_amdgcn_readfirstlane(load_now(later + base + mid * 64 + 63)) : later[base + mid * 64 + 63];
-                    if (x != 0 && base + (int)((unsigned)x >> 22) < fl) lo = mid + 1; else hi = mid;
-                }
-                if (lo >= ng) break;
-                gi = lo;
-                e = KA ? load_now(later + base + gi * 64 + lane) : later[base + gi * 64 + lane];
-                continue;
-            }
-            const int i = base + (int)((unsigned)e >> 22);
-            bool covers;
-            const int w = later_word(nbp, e, g, deadk, e != 0 && i >= fl && i < f0, covers);
-            if (__ballot(covers)) fn(w, covers);
-            if (!full || base + (int)((unsigned)e63 >> 22) >= f0) break;
-            if (ng == 0) ng = ((KA ? __builtin_amdgcn_readfirstlane(load_now(&KARG(a.laterHdr)[b].x)) : a.laterHdr[b].x) + 63) >> 6;
-            if (++gi >= ng) break;
-            e = KA ? load_now(KARG(a.later) + base + gi * 64 + lane) : a.later[base + gi * 64 + lane];
+    const int bA = la >> sh, bB = f0 >> sh;
+    const int32_t *later = KA ? KARG(a.later) : a.later;
+    const int2 *hdr = KA ? KARG(a.laterHdr) : a.laterHdr;
+    for (int b = bA; b <= bB; b++) {
+        const int from = b == bA ? la : (b << sh);
+        int cnt;
+        if (b == bA) cnt = IGD_LN_A(ln);
+        else if (b == bB) cnt = IGD_LN_B(ln);
+        else cnt = KA ? __builtin_amdgcn_readfirstlane(load_now(&hdr[b].x)) : hdr[b].x;
+        for (int p = 0; p < cnt; p += IGD_WAVE) {
+            const int at = from + (p + lane < cnt ? p + lane : 0);
+            const int e = KA ? load_now(later + at) : later[at];
+            fn(p + lane < cnt ? e : 0);
         }
-        if (b <= blo) return;                             // (nearly always: the range lies in one block)
-        const int2 *hdr = KA ? KARG(a.laterHdr) : a.laterHdr;
-        do {
-            if (--b < blo) return;
-        } while ((KA ? __builtin_amdgcn_readfirstlane(load_now(&hdr[b].y)) : hdr[b].y) < g);
-        e = KA ? load_now(KARG(a.later) + (b << sh) + lane) : a.later[(b << sh) + lane];
     }
 }
 
@@ -1791,8 +1855,8 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
                                           u64 *found = nullptr)
 {
-    const int c0 = R.c0, cl = R.cl;
-    if ((c0 | cl) == 0) return;                          // nobody asks about this unit
+    const int c0 = R.c0, ln = R.ln;
+    if ((c0 | ln) == 0) return;                          // nobody asks about this unit
 #if IGD_EXP & 1024
     const u64 t_unit = __builtin_amdgcn_s_memtime();
 #endif
@@ -1812,12 +1876,16 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             R.x[r] &= 0xFFFF;
         }
     }
-    // later tiles: the unit's global tile number and which of the 3 tiles before it are empty (rule NEST)
-    int g = 0, deadk = 0;
-    if (cl) {
-        g = __builtin_amdgcn_readlane(L.g, kk);
+    // later tiles: how many entries lead the candidate list (0: none, or a `far` unit, which walks them separately), the
+    // low bits of the unit's global tile number and which of the 3 tiles before it are empty (rule NEST)
+    const bool far = IGD_LN_FAR(ln) && !(IGD_EXP & 8);
+    const int nl = (IGD_LN_FAR(ln) || (IGD_EXP & 8) != 0) ? 0 : IGD_LN_A(ln) + IGD_LN_B(ln);
+    int g2 = 0, deadk = 0;
+    if (ln) {
+        g2 = IGD_LN_G2(ln);
         deadk = a.rule == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
     }
+    const int nE = nl + c0;                              // entries of the candidate list
 #if IGD_EXP & 4
     {
 #pragma unroll
@@ -1835,23 +1903,31 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) if (!keep[r]) R.a[r] = 0u;    // the word nothing matches
         }
-        for (int p = 0, w = R.q; p < c0; p += IGD_WAVE) {
+        int w = R.q;
+        if (nl) {                                        // the first nl lanes of the first batch hold later-tile entries
+            bool covers;
+            const int lw = later_word(db.nbp, R.lw, g2, deadk, lane < nl, covers);
+            nLater = __popcll(__ballot(covers));
+            w = lane < nl ? lw : w;
+        }
+        for (int p = 0; p < nE; p += IGD_WAVE) {
             // the next 64 words are on their way while these are compared (a dense tile is a chain of such batches)
-            const int wn = (p + IGD_WAVE + lane < c0) ? ~a.qw0[f0 + p + IGD_WAVE + lane] : (int)IGD_NEVER;
+            const int wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
             match_words(R, cnt, W, w);
             w = wn;
         }
-        if (cl && !(IGD_EXP & 8)) {
-            for_later_groups<RANK>(db, a, f0 - cl, f0, g, deadk, lane, R.lw, [&](int w, bool covers) {
+        if (far)
+            far_later<RANK>(a, __builtin_amdgcn_readlane(L.la, kk), ln, f0, lane, [&](int e) {
+                bool covers;
+                const int lw = later_word(db.nbp, e, g2, deadk, true, covers);
                 nLater += __popcll(__ballot(covers));
-                match_words(R, cnt, W, w);
+                match_words(R, cnt, W, lw);
             });
-            // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
-            // query, none of which may count them (the reference's tS skip, :510-511)
-            if (nLater != 0) {
+        // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
+        // query, none of which may count them (the reference's tS skip, :510-511)
+        if (nLater != 0) {
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
-            }
+            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
         }
     } else {
         // ---- rank ---------------------------------------------------------------------------------
@@ -1869,20 +1945,32 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         const bool inLds = c0 < a.sbCap;           // the tile's query starts fit the wave's LDS array (a power of two)
         int nFirst = 0;
         SECT(0);
-        // one batch of <= 64 first-tile queries (word w per lane, IGD_NEVER past the tile's last query)
-        auto batchA = [&](const int w, const int p) {
-            const bool there = p + lane < c0;
+        // One batch of <= 64 entries of the candidate list, entry p + lane in each lane: word w for a first-tile query
+        // (IGD_NEVER where the lane has none), later[] entry e for a later-tile one (first batch only: WITH_LATER).
+        // Term A: every covering query bisects the unit's starts with its end and adds 1 to the histogram there.
+        auto batchA = [&](const int w, const int e, const int p, const bool withLater) {
+            const int idx = p + lane - nl;               // which of the tile's own queries (first batch: < 0 in the later-tile lanes)
+            const bool there = idx >= 0 && idx < c0;
             const int qe2 = 65536 - (w & 0xFFFF);
             int qs2 = (int)((unsigned)w >> 16);
-            const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;
-            const int pos = (IGD_EXP & 128) ? (qe2 & 255) : lds_lower_bound(sl, qe2);
-            if (good) atomicAdd(&hist[pos], 1u);
+            const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;   // (IGD_NEVER wherever the lane has no first-tile query)
+            int key = qe2;
+            bool add = good;
+            if (withLater) {
+                bool covers;
+                const int le = later_end(db.nbp, e, g2, deadk, lane < nl, covers);
+                key = covers ? le : key;
+                add = add || covers;
+                nLater += __popcll(__ballot(covers));
+            }
+            const int pos = (IGD_EXP & 128) ? (key & 255) : lds_lower_bound(sl, key);
+            if (add) atomicAdd(&hist[pos], 1u);
             nFirst += __popcll(__ballot(good));
             // the exceptions: masked-out (IGD_NEVER) or inverted queries.  They stay in the ordered list of starts that
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
             unsigned long long x = __ballot(there && !good);
             if (x) {
-                int t = load_now(KARG(a.q_qs) + (there ? f0 + p + lane : f0)) - IGD_TILE_START + 1;   // = qs' for a query of this tile; beyond it: clamped
+                int t = load_now(KARG(a.q_qs) + (there ? f0 + idx : f0)) - IGD_TILE_START + 1;   // = qs' for a query of this tile; beyond it: clamped
                 if (!there) t = 65535;
                 t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
                 qs2 = t;
@@ -1902,58 +1990,44 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                     }
                 }
             }
-            if (inLds && there) sb[p + lane] = (unsigned short)qs2;
+            if (inLds && there) sb[idx] = (unsigned short)qs2;
         };
         // The batches after the first are fetched one ahead: the load of batch k + 1 is issued before batch k is searched
         // and its word first touched after (530 queries per tile -- one GPU's slab of an 8-GPU job -- are 9 batches, and
         // a load waited for on the spot made each of them a memory round trip).  Two batches per pass of the loop, so
         // that no loaded word is carried around it.
-        if (c0 <= IGD_WAVE) batchA(R.q, 0);              // (the usual dense tile: nothing to fetch ahead)
+        if (nE <= IGD_WAVE) batchA(R.q, R.lw, 0, nl != 0);   // (the usual dense tile: nothing to fetch ahead)
         else {
             int wa = R.q;
-            for (int p = 0; p < c0; p += 2 * IGD_WAVE) {
-                const bool moreB = p + IGD_WAVE < c0, moreA = p + 2 * IGD_WAVE < c0;
+            for (int p = 0; p < nE; p += 2 * IGD_WAVE) {
+                const bool moreB = p + IGD_WAVE < nE, moreA = p + 2 * IGD_WAVE < nE;
                 // (unconditional, from an index clamped into the tile's queries: behind a branch the compiler waits for a
                 // load where the branch ends)
                 const int last = f0 + c0 - 1;
-                const int ib = f0 + p + IGD_WAVE + lane, ia = ib + IGD_WAVE;
+                const int ib = f0 + p + IGD_WAVE + lane - nl, ia = ib + IGD_WAVE;
                 const int rb = a.qw0[ib < last ? ib : last];
-                batchA(wa, p);
+                if (p == 0) batchA(wa, R.lw, 0, nl != 0); else batchA(wa, 0, p, false);
                 if (!moreB) break;
-                const int wb = p + IGD_WAVE + lane < c0 ? ~rb : (int)IGD_NEVER;
+                const int wb = p + IGD_WAVE + lane < nE ? ~rb : (int)IGD_NEVER;
                 const int ra = a.qw0[ia < last ? ia : last];
-                batchA(wb, p + IGD_WAVE);
+                batchA(wb, 0, p + IGD_WAVE, false);
                 if (!moreA) break;
-                wa = p + 2 * IGD_WAVE + lane < c0 ? ~ra : (int)IGD_NEVER;
+                wa = p + 2 * IGD_WAVE + lane < nE ? ~ra : (int)IGD_NEVER;
             }
         }
         SECT(1);
-        auto laterA = [&](int w, bool covers) {
-#if IGD_EXP & 512
-            nLater += __popcll(__ballot(covers));
-            return;
-#endif
-            const int pos = (IGD_EXP & 128) ? (w & 255) : lds_lower_bound(sl, 65536 - (w & 0xFFFF));
-            if (covers) atomicAdd(&hist[pos], 1u);
-            nLater += __popcll(__ballot(covers));
-        };
-        if (cl && !(IGD_EXP & 8)) {
-            // nearly always the candidates' later block has one group of words, the one that came with the records, and the
-            // candidate range lies inside that block: no loop, no look-ups
-            const int sh = a.lbShift, fl = f0 - cl, base = ((f0 - 1) >> sh) << sh;
-            if (__builtin_amdgcn_readlane(R.lw, 63) == 0 && fl >= base) {
-                const int i = base + (int)((unsigned)R.lw >> 22);
+        if (far)
+            far_later<true>(a, __builtin_amdgcn_readlane(L.la, kk), ln, f0, lane, [&](int e) {
                 bool covers;
-                const int key = later_end(db.nbp, R.lw, g, deadk, R.lw != 0 && i >= fl && i < f0, covers);
-                const unsigned long long cm = __ballot(covers);
-                if (cm) {
-                    const int pos = (IGD_EXP & (128 | 512)) ? (key & 255) : lds_lower_bound(sl, key);
-                    if (covers && !(IGD_EXP & 512)) atomicAdd(&hist[pos], 1u);
-                    nLater += __popcll(cm);
-                }
-            } else
-                for_later_groups<true>(db, a, fl, f0, g, deadk, lane, R.lw, laterA);
-        }
+                const int key = later_end(db.nbp, e, g2, deadk, true, covers);
+#if IGD_EXP & 512
+                nLater += __popcll(__ballot(covers));
+                return;
+#endif
+                const int pos = (IGD_EXP & 128) ? (key & 255) : lds_lower_bound(sl, key);
+                if (covers) atomicAdd(&hist[pos], 1u);
+                nLater += __popcll(__ballot(covers));
+            });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         SECT(2);
@@ -2145,7 +2219,7 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 
     for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
         SRegs L;
-        L.offLo = L.offHi = L.n = L.g = L.jf = L.f0 = L.c0 = L.cl = 0;
+        L.offLo = L.offHi = L.n = L.jf = L.f0 = L.c0 = L.la = L.ln = 0;
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = 0;
         {
@@ -2155,7 +2229,7 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
                 const int32_t *firstQ = KARG(a.firstQ), *spill = KARG(a.spill);
                 const UnitRegs u = load_unit_regs(units + mi);
                 L.offLo = u.offLo; L.offHi = u.offHi; L.jf = u.jf;
-                L.n = u.n; L.g = u.tile;
+                L.n = u.n;
 #pragma unroll
                 for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = u.w[r];
                 if (u.n > 0) {
@@ -2163,7 +2237,23 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
                     const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
                     L.f0 = firstQ[u.tile];
                     L.c0 = firstQ[u.tile + 1] - L.f0;
-                    if (spill[u.tile] == a.epoch) L.cl = L.f0 - firstQ[u.tile - lb];
+                    if (spill[u.tile] == a.epoch) {
+                        // some query reaches this tile as a later tile: where the entries of the queries [fl, f0) lie
+                        const int fl = firstQ[u.tile - lb];
+                        if (fl < L.f0) {
+                            const int32_t *lpos = KARG(a.lpos);
+                            const int sh = a.lbShift;
+                            const int pA = lpos[u.tile - lb], pB = lpos[u.tile];
+                            const int bA = fl >> sh, bB = L.f0 >> sh;
+                            int nA = pB - pA, nB = 0;
+                            if (bA != bB) { nA = KARG(a.laterHdr)[bA].x - pA; nB = pB; }
+                            const int far = (bB - bA > 1 || nA + nB > IGD_WAVE) ? 1 : 0;
+                            if (nA | nB | far) {
+                                L.la = (bA << sh) + pA;
+                                L.ln = nA | (nB << 13) | ((u.tile & 3) << 26) | (far << 28);
+                            }
+                        }
+                    }
                     // a tile with very many first-tile queries is shared out over all waves (heavy_sorted_body); its own
                     // waves keep the later-tile candidates.  Every unit of the tile takes the same decision from the same
                     // count, its first unit lists it; the list holds IGD_HEAVYS_MAX tiles -- more than a batch can have.
@@ -2177,13 +2267,13 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
         int cntU = (int)(((long long)db.nUnits - ub + nwaves - 1) / nwaves);
         if (cntU > IGD_WAVE) cntU = IGD_WAVE;
 #if IGD_EXP & 32
-        if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.cl)); t_desc = __builtin_amdgcn_s_memtime(); }
+        if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.ln)); t_desc = __builtin_amdgcn_s_memtime(); }
 #endif
         if (RANK) {
             // The full build also serves batches that visit a fraction of the units (one GPU's slab of config 4: one unit
             // in eight): the wave steps through the units somebody asks about only -- an unvisited one still cost its
             // dozen zero-size loads, which queue up behind everybody's real ones.
-            unsigned long long m = __ballot((L.c0 | L.cl) != 0 && L.n > 0);
+            unsigned long long m = __ballot((L.c0 | L.ln) != 0 && L.n > 0);
             const int visited = __popcll(m);
             int qd = (visited + 3) >> 2, at = qd, level = 3, nd = 0;
 #if IGD_OPT_PRIO
@@ -2332,12 +2422,12 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
             const int u = u0 + (int)(it % nu), sc = (int)(it / nu);
             const UnitRegs ur = load_unit_regs(db.units + u);                     // the same unit in every lane
             SRegs L;
-            L.offLo = ur.offLo; L.offHi = ur.offHi; L.n = ur.n; L.g = ur.tile; L.jf = ur.jf;
+            L.offLo = ur.offLo; L.offHi = ur.offHi; L.n = ur.n; L.jf = ur.jf;
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = ur.w[r];
             L.f0 = f0 + sc * IGD_HEAVY_SLICE;
             L.c0 = c0 - sc * IGD_HEAVY_SLICE < IGD_HEAVY_SLICE ? c0 - sc * IGD_HEAVY_SLICE : IGD_HEAVY_SLICE;
-            L.cl = 0;
+            L.la = 0; L.ln = 0;
             Raw2 A;
             s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
             s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
@@ -2802,7 +2892,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos,
                     db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
@@ -3029,6 +3119,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_heavy, IGD_HEAVY_MAX + IGD_HEAVYS_MAX, acct));   // bucket path's list, merge join's list
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
+    TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_spill, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
@@ -3224,7 +3315,7 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
         db->wsQueries = 0;
         if ((rc = dalloc(&db->d_fix, (size_t)nq * 2, nullptr)) != IGD_HIP_OK) return rc;   // a query can be both long and WALK_FIRST
         if ((rc = dalloc(&db->d_qw, (size_t)nq + 64, nullptr)) != IGD_HIP_OK) return rc;
-        if ((rc = dalloc(&db->d_later, (size_t)nq + 1024 + 64, nullptr)) != IGD_HIP_OK) return rc;
+        if ((rc = dalloc(&db->d_later, (size_t)nq + 4096 + 64, nullptr)) != IGD_HIP_OK) return rc;   // whole later blocks (<= 4096 queries)
         if ((rc = dalloc(&db->d_laterHdr, 2 * ((size_t)nq / 256 + 2), nullptr)) != IGD_HIP_OK) return rc;
         db->wsQueries = nq;
     }
@@ -3300,7 +3391,7 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
 {
     SortArgs sa;
     sa.firstQ = a.firstQ; sa.spill = db->d_spill; sa.qw0 = db->d_qw; sa.later = db->d_later; sa.q_qs = a.q_qs; sa.ctl = a.ctl;
-    sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift;
+    sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift; sa.lpos = db->d_lpos;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
     sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
@@ -3401,16 +3492,20 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         // the head and tail of firstQ[] -- 10^3 queries left 190 000 entries to ONE workgroup: 90 us
         if (nq < 65536) vec = false;
         const int fillBlocks = (int)((db->nT >> 10) < 256 ? (db->nT >> 10) + 1 : 256);
-#define QB_GRID(VEC_) ((int)((nq + 256 * VEC_ - 1) / (256 * VEC_)) > fillBlocks ? (int)((nq + 256 * VEC_ - 1) / (256 * VEC_)) : fillBlocks)
-#define QB_LAUNCH(VEC_, FAST_)                                                                                                        \
-    k_query_bounds<VEC_, FAST_><<<QB_GRID(VEC_), 256, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule, \
-        packed ? 1 : 0, db->d_firstQ, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,                       \
+        // large batches: later blocks of 4096 queries (workgroups of 1024 threads), so that the candidate range of a tile --
+        // the queries of three tiles -- spans at most two blocks even at hundreds of queries per tile
+        const bool wide = vec && nq >= ((int64_t)1 << 22);
+#define QB_GRID(PER_) ((int)((nq + (PER_) - 1) / (PER_)) > fillBlocks ? (int)((nq + (PER_) - 1) / (PER_)) : fillBlocks)
+#define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
+    k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
+        packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
-        if (vec) { if (fast) QB_LAUNCH(4, true); else QB_LAUNCH(4, false); }
-        else { if (fast) QB_LAUNCH(1, true); else QB_LAUNCH(1, false); }
+        if (wide) { if (fast) QB_LAUNCH(4, true, 1024); else QB_LAUNCH(4, false, 1024); }
+        else if (vec) { if (fast) QB_LAUNCH(4, true, 256); else QB_LAUNCH(4, false, 256); }
+        else { if (fast) QB_LAUNCH(1, true, 256); else QB_LAUNCH(1, false, 256); }
 #undef QB_LAUNCH
 #undef QB_GRID
-        db->lbShift = vec ? 10 : 8;
+        db->lbShift = wide ? 12 : vec ? 10 : 8;
     }
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
