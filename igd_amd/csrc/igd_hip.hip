@@ -105,9 +105,6 @@ typedef unsigned long long u64;
 #ifndef IGD_OPT_PRIO
 #define IGD_OPT_PRIO 1 // igd_scan_sorted: waves lower their issue priority as they get through their share
 #endif
-#ifndef IGD_OPT_CNT32
-#define IGD_OPT_CNT32 1 // igd_scan_sorted: 32-bit LDS counters when the host can bound them
-#endif
 #if IGD_EXP & 1024
 // diagnostic build: the waves' time (s_memtime ticks) in the sections of the rank method, summed over all launches
 __device__ u64 d_sect[8];
@@ -202,6 +199,7 @@ struct igd_hip_db {
     int64_t *d_tileOff;
     int32_t *d_tileCnt, *d_tileBd, *d_ctgBase, *d_ctgNTile, *d_tileUnit0;
     int32_t *d_heavy;             // [IGD_HEAVY_MAX] tiles of the batch with more pairs than a wave should take alone
+    int32_t *d_far;               // [nUnits + 1] units the lean build of igd_scan_sorted leaves to far_units_body
     Unit *d_units;
     int32_t nUnits;
     int64_t resident;
@@ -340,6 +338,7 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define IGD_HEAVY_PAIRS 2048   // a tile with more (query, tile) pairs than this is shared out in slices of that many
 #define IGD_HEAVY_MAX 4096     // listed heavy tiles per batch (a further one stays with its own wave)
 #define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for heavy_sorted_body (merge join)
+#define CTL_NFAR 14      // + (epoch & 1): units the lean build of igd_scan_sorted leaves to far_units_body
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
 #define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body
@@ -480,6 +479,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
     }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
@@ -749,6 +749,7 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
         ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
     }
     if (gate != 0 && ctl[CTL_UNSORTED] != gate) return;
     if (i >= nq) return;
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
             ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
         ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
         }
     }
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
@@ -1635,6 +1637,7 @@ struct SortArgs {
     int nq, v, epoch, mode, rule;
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
     int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to heavy_sorted_body
+    int32_t *farList;            // [nUnits] units the lean build leaves to far_units_body (unit number | its tile is in heavyS << 31)
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
@@ -1822,6 +1825,26 @@ __device__ __forceinline__ int load_now(const int32_t *p)
     return v;
 }
 
+// Where the later-tile candidates of a tile lie in later[] (SRegs::la / ln): the entries of the queries [fl, f0) of the
+// (up to) lb tiles before it, from lpos[] and the block headers.  Only for a tile some query reaches (spill[]).
+template <bool KA>
+__device__ __forceinline__ void later_range(const SortArgs &a, int tile, int lb, int fl, int f0, int &la, int &ln)
+{
+    la = 0; ln = 0;
+    if (fl >= f0) return;
+    const int32_t *lpos = KA ? KARG(a.lpos) : a.lpos;
+    const int sh = a.lbShift;
+    const int pA = lpos[tile - lb], pB = lpos[tile];
+    const int bA = fl >> sh, bB = f0 >> sh;
+    int nA = pB - pA, nB = 0;
+    if (bA != bB) { nA = (KA ? KARG(a.laterHdr) : a.laterHdr)[bA].x - pA; nB = pB; }
+    const int far = (bB - bA > 1 || nA + nB > IGD_WAVE) ? 1 : 0;
+    if (nA | nB | far) {
+        la = (bA << sh) + pA;
+        ln = nA | (nB << 13) | ((tile & 3) << 26) | (far << 28);
+    }
+}
+
 // A unit whose later-tile candidates do not come with its records (IGD_LN_FAR: more than 64 entries -- tiles behind a
 // very dense one -- or a candidate range that crosses more than one block boundary) walks them here: nA entries from
 // index la on, every entry of the blocks in between (their number: laterHdr[]), the first nB of the block that holds
@@ -1853,7 +1876,7 @@ __device__ __forceinline__ void far_later(const SortArgs &a, int la, int ln, int
 template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
-                                          u64 *found = nullptr)
+                                          u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u)
 {
     const int c0 = R.c0, ln = R.ln;
     if ((c0 | ln) == 0) return;                          // nobody asks about this unit
@@ -1878,7 +1901,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     }
     // later tiles: how many entries lead the candidate list (0: none, or a `far` unit, which walks them separately), the
     // low bits of the unit's global tile number and which of the 3 tiles before it are empty (rule NEST)
-    const bool far = IGD_LN_FAR(ln) && !(IGD_EXP & 8);
+    const bool far = RANK && IGD_LN_FAR(ln) && !(IGD_EXP & 8);   // (the lean build lists its far units: far_units_body)
     const int nl = (IGD_LN_FAR(ln) || (IGD_EXP & 8) != 0) ? 0 : IGD_LN_A(ln) + IGD_LN_B(ln);
     int g2 = 0, deadk = 0;
     if (ln) {
@@ -2111,19 +2134,48 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         SECT(4);
 #undef IGD_TILE_START
     }
-    // CNT32 (the host has bounded every counter of a launch below 2^32): one 32-bit LDS atomic per slot, for all
-    // lanes -- a lane without hits adds 0 (lanes past the unit: to counter 0), which costs LDS lanes but none of the
-    // compare / exec-mask instructions that skipping them would.  Otherwise: one 64-bit LDS (or global) atomic per
-    // record that was hit.
+    // CNT32 (the workgroup's LDS counters are 32-bit): one 32-bit LDS atomic per slot, for all lanes -- a lane without
+    // hits adds 0 (lanes past the unit: to counter 0), which costs LDS lanes but none of the compare / exec-mask
+    // instructions that skipping them would.  No counter can wrap: a unit adds at most (its candidate queries) x (its
+    // records) to any of them, every wave keeps the sum of that bound over its units, and the unit that would take the
+    // wave beyond its share of 2^32 (and any `far` unit, whose candidates are not counted beforehand) adds to the caller's
+    // 64-bit hits[] with global atomics instead -- as do the builds without LDS counters (one atomic per record hit).
+    bool direct = !CNT32;
+    // (the lean build needs no guard: the host has bounded what its units -- <= IGD_LEAN_FIRST + 64 candidates each, the
+    // far ones are not its own -- can add up to: launch_scan)     // the lean build: the host has bounded what its units -- <= IGD_LEAN_FIRST + 64
+                                                         // candidates each, far ones apart -- can add up to (launch_scan)
+    if (CNT32 && RANK) {
+        // candidates of the unit: its own queries + its later-tile entries (a far unit: at most the two runs it knows
+        // plus every entry of the blocks between them)
+        long long cand = nE;
+        if (IGD_LN_FAR(ln)) {
+            const int bA = __builtin_amdgcn_readlane(L.la, kk) >> a.lbShift, bB = f0 >> a.lbShift;
+            cand += IGD_LN_A(ln) + IGD_LN_B(ln) + (bB - bA > 1 ? (long long)(bB - bA - 1) << a.lbShift : 0);
+        }
+        const long long bound = cand * un;                // (cand <= 2^25, un <= 320)
+        direct = bound > (long long)(budget - *spent);
+        if (!direct) *spent += (unsigned)bound;
+    }
+    if (!direct) {
 #pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) {
-        const int c = cnt[r];
+        for (int r = 0; r < IGD_SLOTS; r++) {
 #if IGD_EXP & 1
-        asm volatile("" ::"v"(c), "v"(R.x[r]));
-        continue;
+            asm volatile("" ::"v"(cnt[r]), "v"(R.x[r]));
+            continue;
 #endif
-        if (CNT32) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)c);
-        else if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
+            // lean build: every lane adds, 0 included (no compare / exec masking -- that build is bound by instruction issue);
+            // full build: lanes without hits stay out -- the lanes past a unit's end all name counter 0, and the dozens
+            // of them in a unit's last slot would queue up for ONE address in an LDS the rank method keeps busy
+            if (!RANK || cnt[r]) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
+        }
+    } else {
+        u64 *gh = CNT32 ? KARG(hitsOut) : hits;          // (CNT32: the slab rows hold 32-bit counts, this unit's go to hits[] itself)
+        if (CNT32) found = KARG(totalOut);
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const int c = cnt[r];
+            if (c) atomicAdd((u64 *)((char *)gh + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
+        }
     }
 #if IGD_EXP & 1024
     if (lane == 0) atomicAdd(&hist[321 + 6], (unsigned)(__builtin_amdgcn_s_memtime() - t_unit));   // all of the unit's compare phase
@@ -2157,7 +2209,10 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #define IGD_WPE_LEAN IGD_WPE
 #endif
 template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK>
-__global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RANK : IGD_WPE_LEAN) void igd_scan_sorted(SortK K)
+// (waves per SIMD pinned from both sides: with only the lower bound the compiler budgets the scalar registers for 10 waves --
+// 80 -- although the vector registers already hold the kernel at 8, and spills a dozen of them)
+__global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN)
+__attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IGD_WPE_RANK : IGD_WPE_LEAN))) void igd_scan_sorted(SortK K)
 {
     constexpr int WGT = RANK ? IGD_WG_RANK : IGD_WG_LEAN;
     const DbView &db = K.db;
@@ -2199,6 +2254,8 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
     const int gwave = lblk * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
     Raw2 A, B;
+    unsigned spent = 0u;                                 // CNT32: what this wave's units may have added to any one LDS counter
+    const unsigned budget = 0xFFFFFFFFu / (unsigned)(WGT / IGD_WAVE);
 #if IGD_EXP & 1024
     const u64 t_kernel = __builtin_amdgcn_s_memtime();
 #endif
@@ -2237,29 +2294,22 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
                     const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
                     L.f0 = firstQ[u.tile];
                     L.c0 = firstQ[u.tile + 1] - L.f0;
-                    if (spill[u.tile] == a.epoch) {
-                        // some query reaches this tile as a later tile: where the entries of the queries [fl, f0) lie
-                        const int fl = firstQ[u.tile - lb];
-                        if (fl < L.f0) {
-                            const int32_t *lpos = KARG(a.lpos);
-                            const int sh = a.lbShift;
-                            const int pA = lpos[u.tile - lb], pB = lpos[u.tile];
-                            const int bA = fl >> sh, bB = L.f0 >> sh;
-                            int nA = pB - pA, nB = 0;
-                            if (bA != bB) { nA = KARG(a.laterHdr)[bA].x - pA; nB = pB; }
-                            const int far = (bB - bA > 1 || nA + nB > IGD_WAVE) ? 1 : 0;
-                            if (nA | nB | far) {
-                                L.la = (bA << sh) + pA;
-                                L.ln = nA | (nB << 13) | ((u.tile & 3) << 26) | (far << 28);
-                            }
-                        }
-                    }
+                    // some query reaches this tile as a later tile: where the entries of the queries [fl, f0) lie
+                    if (spill[u.tile] == a.epoch) later_range<true>(a, u.tile, lb, firstQ[u.tile - lb], L.f0, L.la, L.ln);
                     // a tile with very many first-tile queries is shared out over all waves (heavy_sorted_body); its own
                     // waves keep the later-tile candidates.  Every unit of the tile takes the same decision from the same
                     // count, its first unit lists it; the list holds IGD_HEAVYS_MAX tiles -- more than a batch can have.
-                    if (L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST)) {
+                    const bool heavy = L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST);
+                    if (heavy) {
                         if (u.jf & 1) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
                         L.c0 = 0;
+                    }
+                    // the lean build keeps nothing but 32-bit LDS counters: a far unit -- whose later-tile candidates nobody
+                    // has counted -- is left, whole, to far_units_body in the batch's last launch (the full build bounds what
+                    // every unit can add and sends the unit that would overflow a counter to the global hits[] itself)
+                    if (!RANK && IGD_LN_FAR(L.ln)) {
+                        KARG(a.farList)[atomicAdd(&KARG(a.ctlw)[CTL_NFAR + (a.epoch & 1)], 1)] = (int)mi | (heavy ? (int)0x80000000 : 0);
+                        L.c0 = 0; L.ln = 0;
                     }
                 }
             }
@@ -2285,11 +2335,11 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
             s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
             while (ka >= 0) {
                 s_issue<USE_V, BIG>(db, a, L, kb < 0 ? 0 : kb, kb >= 0, lane, B);
-                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 ka = -1;
                 if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
                 s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
-                if (kb >= 0) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK);
+                if (kb >= 0) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 kb = -1;
                 if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
 #if IGD_OPT_PRIO
@@ -2314,11 +2364,11 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
             s_issue<USE_V, BIG>(db, a, L, 1, 1 < cntU, lane, B);
             for (int kk = 0; kk < cntU; kk += 3) {
                 s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, C);
-                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 s_issue<USE_V, BIG>(db, a, L, kk + 3, kk + 3 < cntU, lane, A);
-                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
+                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 s_issue<USE_V, BIG>(db, a, L, kk + 4, kk + 4 < cntU, lane, B);
-                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK);
+                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
 #if IGD_OPT_PRIO
                 done += 3;
                 if (done >= prioAt) {
@@ -2339,9 +2389,9 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK);
+            s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
             s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
@@ -2367,8 +2417,10 @@ __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN, RANK ? IGD_WPE_RA
         __syncthreads();
         const int nFiles = KARG(db.nFiles);
         u64 *row = KARG(a.out) + (size_t)blockIdx.x * nFiles;
-        if (CNT32) for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = (u64)((unsigned int *)hits)[f];
-        else for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = hits[f];
+        if (CNT32) {                                     // 32-bit rows: half the bytes written here and read back by k_reduce_slabs
+            unsigned int *row32 = (unsigned int *)KARG(a.out) + (size_t)blockIdx.x * nFiles;
+            for (int f = threadIdx.x; f < nFiles; f += WGT) row32[f] = ((unsigned int *)hits)[f];
+        } else for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = hits[f];
     }
 #if IGD_EXP & 32
     if (KARG(a.stamps) && lane == 0) {
@@ -2433,6 +2485,43 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
             s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
         }
         base += items;
+    }
+}
+
+// far_units_body: the units the lean build of igd_scan_sorted listed (far: more later-tile candidates than come with a
+// unit's records -- tiles behind very dense ones; that build has neither the walk over the blocks nor 64-bit counters in
+// its registers).  One wave per listed unit: its later-tile candidates (far_later) and, unless its tile went to
+// heavy_sorted_body, its first-tile queries, added to hits[] and the batch total with global atomics.
+template <bool USE_V, bool BIG>
+__device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__ d_hits, u64 *__restrict__ d_total,
+                                               unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv)
+{
+    const DbView &db = K.db;
+    const SortArgs &a = K.a;
+    if (__builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch) return;
+    const int nF = __builtin_amdgcn_readlane(ctlv, CTL_NFAR + (a.epoch & 1));
+    if (nF == 0) return;
+    unsigned short *sl = (unsigned short *)wsm;
+    unsigned int *hist = (unsigned int *)(sl + IGD_WLDS_S);
+    unsigned short *sb = (unsigned short *)(hist + IGD_WLDS_H);
+    for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
+    for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
+    const bool rankOK = __builtin_amdgcn_readlane(ctlv, CTL_NOTSTART) != a.epoch;
+    for (int i = gwave; i < nF && i < db.nUnits; i += nwaves) {
+        const int ent = __builtin_amdgcn_readfirstlane(a.farList[i]);
+        const UnitRegs ur = load_unit_regs(db.units + (ent & 0x7fffffff));        // the same unit in every lane
+        SRegs L;
+        L.offLo = ur.offLo; L.offHi = ur.offHi; L.n = ur.n; L.jf = ur.jf;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = ur.w[r];
+        const int lj = ur.jf >> 4;
+        const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
+        L.f0 = a.firstQ[ur.tile];
+        L.c0 = ent < 0 ? 0 : a.firstQ[ur.tile + 1] - L.f0;
+        later_range<false>(a, ur.tile, lb, a.firstQ[ur.tile - lb], L.f0, L.la, L.ln);
+        Raw2 A;
+        s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
+        s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
     }
 }
 
@@ -2512,7 +2601,10 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     if (valves & 2) {
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
         if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
-        else heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+        else {
+            heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+            far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);   // (the lean build does not exist for BIG images)
+        }
     }
 }
 
@@ -2532,7 +2624,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
                                                       u64 *__restrict__ hits, u64 *__restrict__ total,
                                                       const int32_t *__restrict__ ctl, int brokenIf,
                                                       ScanArgs wa, const int2 *__restrict__ fixList,
-                                                      const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves)
+                                                      const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves,
+                                                      int rows32 /* != 0: igd_scan_sorted of epoch `rows32` wrote 32-bit rows (unless the batch went to the bucket path) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u64 red[4];
@@ -2540,8 +2633,20 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     const int ctlv = (threadIdx.x & 63) < 16 ? ctl[threadIdx.x & 63] : 0;
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
-    if (f < nFiles)
-        for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s += slab[(size_t)g * nFiles + f];
+    if (f < nFiles) {
+        // (both kinds of rows are read before the control words say which kind this batch left: the loads are in flight
+        // together, and a row of either kind lies inside the slab)
+        u64 s64 = 0;
+        unsigned long long s32 = 0;
+        if (rows32) {
+            const unsigned int *slab32 = (const unsigned int *)slab;
+            for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s32 += slab32[(size_t)g * nFiles + f];
+            if (__builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == rows32)   // the bucket path's batch: 64-bit rows
+                for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s64 += slab[(size_t)g * nFiles + f];
+            s = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == rows32 ? s64 : s32;
+        } else
+            for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s += slab[(size_t)g * nFiles + f];
+    }
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
     if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
@@ -2889,7 +2994,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     if (t_arenaOwner == db) t_arenaOwner = nullptr;
     (void)hipSetDevice(db->device);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
-                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos,
@@ -3081,7 +3186,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
         {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
-            const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 8) + 15) & ~(size_t)15) : 0;
+            const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 4) + 15) & ~(size_t)15) : 0;   // (32-bit counters: CNT32)
             int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;   // the full build: 2 workgroups per CU
             db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
             for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
@@ -3098,7 +3203,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + sizeof(Unit) * units.size() + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -3118,6 +3223,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_tileUnit0, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_heavy, IGD_HEAVY_MAX + IGD_HEAVYS_MAX, acct));   // bucket path's list, merge join's list
     TRY(dalloc(&db->d_units, units.size(), acct));
+    TRY(dalloc(&db->d_far, units.size() + 1, acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -3241,13 +3347,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
     }
     if (db->ldsSorted > 64 * 1024) {
-        // every instantiation launch_scan can pick: <USE_V, LDS_HITS, CNT32, BIG, RANK> (CNT32 implies LDS_HITS; BIG only
-        // exists as the full build without CNT32) -- without LDS counters the waves' rank-method areas alone are 75 KiB
-#define IGD_SORTED_FNS(V, LH) (const void *)igd_scan_sorted<V, LH, false, true, true>, (const void *)igd_scan_sorted<V, LH, false, false, false>, \
-                              (const void *)igd_scan_sorted<V, LH, false, false, true>
-        const void *sfn[] = {IGD_SORTED_FNS(false, true), IGD_SORTED_FNS(true, true), IGD_SORTED_FNS(false, false), IGD_SORTED_FNS(true, false),
-                             (const void *)igd_scan_sorted<false, true, true, false, false>, (const void *)igd_scan_sorted<true, true, true, false, false>,
-                             (const void *)igd_scan_sorted<false, true, true, false, true>, (const void *)igd_scan_sorted<true, true, true, false, true>};
+        // every instantiation launch_scan can pick: <USE_V, LDS_HITS, CNT32 = LDS_HITS, BIG, RANK> -- without LDS counters the
+        // waves' rank-method areas alone are 75 KiB
+#define IGD_SORTED_FNS(V, LH) (const void *)igd_scan_sorted<V, LH, LH, true, true>, (const void *)igd_scan_sorted<V, LH, LH, false, false>, \
+                              (const void *)igd_scan_sorted<V, LH, LH, false, true>
+        const void *sfn[] = {IGD_SORTED_FNS(false, true), IGD_SORTED_FNS(true, true), IGD_SORTED_FNS(false, false), IGD_SORTED_FNS(true, false)};
 #undef IGD_SORTED_FNS
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
     }
@@ -3394,7 +3498,7 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift; sa.lpos = db->d_lpos;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
-    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX;
+    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far;
     sa.stamps = nullptr;
 #if IGD_EXP & 32
     {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -3414,10 +3518,6 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
 {
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
     if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
-        // 32-bit workgroup counters when nothing can reach 2^32: a record is counted at most once per candidate query of
-        // its unit, a query is a candidate in <= IGD_SHORT_TILES tiles, i.e. in <= 4 * (units per tile) units of <= 320 records
-        const int64_t unitsPerTile = (db->maxTileCnt + IGD_CHUNK - 1) / IGD_CHUNK;
-        const bool cnt32 = IGD_OPT_CNT32 && LDS_HITS && (int64_t)a.nq * IGD_SHORT_TILES * (unitsPerTile > 0 ? unitsPerTile : 1) * IGD_CHUNK < (1ll << 32);
         const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
         const SortK K = make_sortk(db, a);
@@ -3426,12 +3526,15 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const int forceRank = db->forceRank;              // tests: 0 lean, 1 full (IGD_HIP_RANK, read at open)
         // ... and a batch that visits a fraction of the units (fewer queries than tiles) runs the full build too: it steps
         // through the visited units only (10^3 queries: 43.7 -> 13.4 us, 10^5: 44.3 -> 35.7 us; 3 x 10^5: 51.5 vs 53.5 us)
-        const bool lean = forceRank >= 0 ? forceRank == 0 : ((int64_t)a.nq < 8ll * db->nT && (int64_t)a.nq >= (int64_t)db->nT);
-        if (big) igd_scan_sorted<USE_V, LDS_HITS, false, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-        else if (lean && cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, ldsS, st>>>(K);
-        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, false, false, false><<<db->grid, IGD_WG_LEAN, LDS_HITS ? ldsS : 0, st>>>(K);   // (the lean build's only LDS is its counters)
-        else if (cnt32) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-        else igd_scan_sorted<USE_V, LDS_HITS, false, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        bool lean = forceRank >= 0 ? forceRank == 0 : ((int64_t)a.nq < 8ll * db->nT && (int64_t)a.nq >= (int64_t)db->nT);
+        // the lean build's 32-bit workgroup counters need no run-time guard when even a workgroup whose every unit is as
+        // dense as that build lets one be stays below 2^32 (any database below ~10^9 records); otherwise: the full build
+        const int64_t wavesLean = (int64_t)db->grid * (IGD_WG_LEAN / IGD_WAVE);
+        if (((int64_t)db->nUnits + wavesLean - 1) / wavesLean * (IGD_WG_LEAN / IGD_WAVE) * (IGD_LEAN_FIRST + IGD_WAVE) * IGD_CHUNK >= (1ll << 32)) lean = false;
+        // <USE_V, LDS_HITS, CNT32, BIG, RANK>: workgroups with LDS counters keep them in 32 bits (igd_scan_sorted guards the range itself)
+        if (big) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, LDS_HITS ? ldsS : 0, st>>>(K);   // (the lean build's only LDS is its counters)
+        else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
@@ -3539,12 +3642,13 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
             SortK Kt = K;
             Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES;
             dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
+            const int rows32 = (mode != 2 && packed) ? db->epoch : 0;      // the merge join's kernel leaves 32-bit rows (CNT32)
             if (useV)
                 k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                               db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
+                                                               db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves, rows32);
             else
                 k_reduce_slabs<false><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves);
+                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves, rows32);
         }
     } else {
         a.out = (u64 *)d_hits;
@@ -4309,7 +4413,7 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         }
         out->query_bytes = path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
                          : path == 1 ? 12ll * nq : 8ll * (int64_t)acc[2];
-        out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * 8 : 8ll * db->nFiles;
+        out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * (path == 2 ? 4 : 8) : 8ll * db->nFiles;   // (merge join: 32-bit rows)
         out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;
     }
     (void)hipFree(d_acc); (void)hipFree(d_h);
