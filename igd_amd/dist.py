@@ -19,7 +19,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    # IGD_DIST_FORCE=1: a process group also for ONE rank -- the collective path (librccl next to libigd_hip.so in one
+    # process, an int64 SUM all-reduce on the engine's stream) can then be exercised on a single-GPU box
+    force = os.environ.get("IGD_DIST_FORCE", "") not in ("", "0")
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
@@ -34,6 +37,22 @@ def init_from_env(backend=None):
 def allreduce_hits(hits_tensor):
     """In-place SUM all-reduce of the per-rank hits vector (int64).  No-op for world size 1."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("IGD_DIST_FORCE", "") not in ("", "0")):
         dist.all_reduce(hits_tensor, op=dist.ReduceOp.SUM)
     return hits_tensor
+
+
+def ranks_seen():
+    """World size as the process group reports it (1 without one): goes into the bench line of an N > 1 run."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def gather_strings(text):
+    """Every rank's string on every rank (device ordinal / bus id of each rank for the bench line)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [text]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, text)
+    return out

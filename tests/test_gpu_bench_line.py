@@ -90,3 +90,91 @@ def test_bench_two_ranks_config4_slabs_and_allreduce(launcher):
         assert j["hits_per_step_total"] == total and j["hits_checksum"] == chk
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_rccl_world_size_one_int64_sum_on_the_engines_stream():
+    """librccl loads next to libigd_hip.so in ONE process, the "nccl" backend initialises on device 0 and an int64 SUM
+    all-reduce of a hits vector runs on the non-default stream the engine's kernels were enqueued on -- everything the
+    N > 1 job needs from RCCL except a second GPU.  In a child process: the process group must not leak into pytest."""
+    d = short_tmpdir("igb")
+    try:
+        code = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from igd_amd import Database, synth
+from igd_amd.dist import allreduce_hits, init_from_env
+path = os.path.join(%r, "s.igd")
+synth.make_db(path, files=1900, per_file=60, seed=1000, genome=synth.SMALL)
+rank, world, local = init_from_env()
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+db = Database(path, device=0)
+assert db.nfiles == 1900
+ichr, qs, qe = synth.make_queries(50000, seed=7, genome=synth.SMALL, sorted_=True)
+want, wtot = db.search(ichr, qs, qe)
+st = torch.cuda.Stream(device=dev)
+torch.cuda.synchronize(dev)
+with torch.cuda.stream(st):
+    d_q = [torch.from_numpy(a).to(dev) for a in (ichr, qs, qe)]
+    hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        db.search_dev(d_q[0].data_ptr(), d_q[1].data_ptr(), d_q[2].data_ptr(), len(qs), hits.data_ptr(), None,
+                      stream=st.cuda_stream, flags=1)
+    allreduce_hits(hits)                       # RCCL: int64[1900] SUM on `st`
+    st.synchronize()
+db.sync(st.cuda_stream)
+assert np.array_equal(hits.cpu().numpy(), 3 * want), "all-reduced hits differ"
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps and "libigd_hip.so" in maps
+dist.barrier(); dist.destroy_process_group(); db.close()
+print("RCCL-OK", int(hits.sum().item()))
+''' % (ROOT, d)
+        env = dict(os.environ, IGD_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29950 + os.getpid() % 40), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("IGD_DIST_BACKEND", None)
+        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=env)
+        assert p.returncode == 0 and b"RCCL-OK" in p.stdout, (p.stdout.decode()[-500:], p.stderr.decode()[-1500:])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_bench_one_rank_forced_through_the_collective_path():
+    """bench.py with WORLD_SIZE=1 and IGD_DIST_FORCE=1: process group over RCCL, barriers, the all-reduce of hits[] inside
+    the timed region and the MAX of the elapsed times -- the N > 1 code path on one GPU -- and the line says so."""
+    d = short_tmpdir("igb")
+    try:
+        env = dict(os.environ, IGD_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(29900 + os.getpid() % 40), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("IGD_DIST_BACKEND", None)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--files", "40", "--per-file", "3000", "--queries", "20000",
+                            "--steps", "3", "--warmup", "1", "--dir", d, "--no-extra", "--no-cpu"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        j = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][0])
+        assert j["n_gpus"] == 1 and j["n_ranks_seen"] == 1 and j["dist_backend"] == "nccl"
+        assert "all-reduce" in j["config"]["collective"] and len(j["devices"]) == 1 and "cuda:0" in j["devices"][0]
+        assert j["hits_per_step_total"] > 0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_bench_fails_fast_when_a_rank_dies():
+    """`bench.py --gpus 2` where rank 1 dies at start-up (IGD_BENCH_DIE_RANK): the launcher stops rank 0 -- which would sit in
+    the rendezvous / a barrier until the collective's timeout -- and exits non-zero within seconds, naming the rank."""
+    import time
+    d = short_tmpdir("igb")
+    try:
+        env = dict(os.environ, IGD_BENCH_ONE_GPU="1", IGD_DIST_BACKEND="gloo", IGD_BENCH_DIE_RANK="1")
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        t = time.time()
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", "40", "--per-file", "3000",
+                            "--queries", "15000", "--steps", "3", "--warmup", "1", "--dir", d],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+        assert p.returncode != 0 and time.time() - t < 120
+        assert b"rank 1 failed" in p.stderr, p.stderr.decode()[-800:]
+        assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
