@@ -153,6 +153,108 @@ def ensure_db(path, files, per_file, rank, barrier):
         time.sleep(0.2)
 
 
+def cpu_info():
+    """CPU model and core counts of the host the baselines run on (state N and the CPU model)."""
+    model, phys = None, set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except Exception:
+        pass
+    return {"cpu_model": model, "physical_cores": len(phys) or None, "logical_cpus": os.cpu_count(),
+            "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+
+
+def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
+    """Wall time of the PRODUCT command line -- load the .igd, upload, parse, kernels, print -- on the headline's files,
+    next to the reference CLI's seconds in cpu_baseline (report it separately): best of `repeats`."""
+    exe = os.path.join(ROOT, "bin", "igd")
+    out = {"command": "bin/igd search <db> -q <the headline's 10^6-query BED> [..]", "repeats": repeats}
+    for name, extra in (("q", []), ("q_v500", ["-v", "500"]), ("q_f", ["-f"])):
+        best, ok = None, None
+        for _ in range(repeats if name != "q_f" else 3):
+            t = time.perf_counter()
+            p = subprocess.run([exe, "search", igd_path, "-q", bed_path] + extra,
+                               stdout=subprocess.DEVNULL if name == "q_f" else subprocess.PIPE, stderr=subprocess.DEVNULL)
+            dt = time.perf_counter() - t
+            if p.returncode != 0:
+                best = None
+                break
+            best = dt if best is None else min(best, dt)
+            if name == "q":
+                tot = [int(l.split(":")[1]) for l in p.stdout.decode().splitlines()[-2:] if l.startswith("Total:")]
+                ok = bool(tot) and tot[0] == expect_total
+        out[name + "_seconds"] = best
+        if ok is not None:
+            out["q_total_matches_gpu"] = ok
+    return out
+
+
+def cpu_baseline_allcores_large(exe, igd_path, genome, queries, expect_total, workdir):
+    """The host's cores on a batch large enough that starting the processes is a small part of the wall time: config 4's
+    per-GPU share (1.25e7 position-sorted queries) cut into 256 contiguous shards, one reference process per shard, P of
+    them at a time (ONE xargs -P: the benchmark process itself -- torch loaded -- forks slowly) for P = 16, 32, 64 and the
+    number of physical cores; the best P is the reported value, the whole table is kept (on the pool's hosts more processes
+    than ~32 at a time run SLOWER: they share one page cache / one container's CPU quota)."""
+    from igd_amd import synth
+    ichr, qs, qe = queries
+    n = len(qs)
+    info = cpu_info()
+    allowed = info["cpus_allowed"] or info["logical_cpus"] or 1
+    nshards = 256
+    shards = []
+    for r in range(nshards):
+        lo, hi = n * r // nshards, n * (r + 1) // nshards
+        path = os.path.join(workdir, "ac%d_%d.bed" % (r, nshards))
+        synth.write_bed(path, genome, ichr[lo:hi], qs[lo:hi], qe[lo:hi])
+        shards.append(path)
+    listing = ("\n".join(shards) + "\n").encode()
+
+    def run(k, what):
+        t = time.perf_counter()
+        subprocess.run(["xargs", "-P", str(k), "-I", "{}", "sh", "-c", what], input=listing, check=True, stderr=subprocess.DEVNULL)
+        return time.perf_counter() - t
+
+    table, best = [], None
+    for k in sorted(set(min(allowed, x) for x in (16, 32, 64, info["physical_cores"] or 64))):
+        dt = min(run(k, "'%s' search '%s' -q {} > {}.out" % (exe, igd_path)) for _ in range(2))
+        total = 0
+        for sh in shards:
+            for line in open(sh + ".out").read().splitlines()[-2:]:
+                if line.startswith("Total:"):
+                    total += int(line.split(":")[1])
+        row = {"processes_at_a_time": k, "seconds": dt, "value": n / dt, "spawn_seconds": min(run(k, "true {}") for _ in range(2)),
+               "totals_match_oracle_fixture": total == expect_total}
+        table.append(row)
+        if best is None or dt < best["seconds"]:
+            best = row
+    for sh in shards:
+        for f in (sh, sh + ".out"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    return {"value": best["value"], "unit": "query-intervals/s", "cores": best["processes_at_a_time"], "processes": nshards,
+            "seconds": best["seconds"], "queries": n, "spawn_seconds": best["spawn_seconds"],
+            "spawn_fraction": best["spawn_seconds"] / best["seconds"], "totals_match_oracle_fixture": best["totals_match_oracle_fixture"],
+            "by_processes_at_a_time": table, "host": info,
+            "sample": "config 4's per-GPU share (%d position-sorted queries) cut into %d contiguous shards, one `%s search -q` process "
+                      "per shard, P at a time under one xargs -P; wall time from start to the last exit, best of 2 per P; value = the "
+                      "best P; spawn_seconds = the same xargs starting `true`" % (n, nshards, os.path.basename(exe))}
+
+
 def cpu_baseline_allcores(exe, igd_path, bed_path, nq, expect_total, extra, repeats=3):
     """the reference has no threads and keeps its state in globals, so the faithful way to
     use more cores is one process per contiguous shard of the query file; wall time = slowest shard."""
@@ -218,7 +320,7 @@ def cpu_baseline(igd_path, bed_path, nq, expect_total, repeats=5, extra=()):
             if line.startswith("Total:"):
                 total = int(line.split(":")[1])
     ok = (total == expect_total)
-    res = {"value": nq / best, "unit": "query-intervals/s", "cores": 1, "kind": kind,
+    res = {"value": nq / best, "unit": "query-intervals/s", "cores": 1, "kind": kind, "exe": exe, "host": cpu_info(),
            "sample": "all %d queries of the workload as BED text through `%s search -q%s`, "
                      "end to end (parse+search+print), best of %d, page cache warm; Total %s GPU (%s)"
                      % (nq, os.path.basename(exe), " " + " ".join(extra) if extra else "", repeats, "==" if ok else "!=", total),
@@ -300,6 +402,33 @@ class Job:
         prof = self.db.profile_end()
         return t1 - t0, prof
 
+    def run_cold(self, steps=12, dirty=False):
+        """The same batch with the last-level cache emptied before every launch: what ONE `igd search` sees (the timed
+        loop re-streams the same 319 MB image against a 256 MiB Infinity Cache).  Between two launches, on the same
+        stream and outside the kernel's event pair, 512 MiB of other memory is read."""
+        import torch
+        evict = torch.zeros(128 << 20, dtype=torch.int32, device=self.dev)     # 512 MiB
+        sink = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        def flush():
+            nonlocal sink
+            if dirty:
+                evict.add_(1)                               # read AND written: the cache is left full of dirty lines, whose
+            else:                                           # write-back then runs while the kernel under test does
+                sink += evict.sum()                         # read only: clean lines
+        for _ in range(2):
+            flush()
+            self.step()
+        torch.cuda.synchronize(self.dev)
+        self.db.profile_begin(steps, every=1)
+        for _ in range(steps):
+            flush()
+            self.step()
+        torch.cuda.synchronize(self.dev)
+        self.db.sync(self.stream)
+        prof = self.db.profile_end()
+        del evict
+        return prof
+
     def roofline(self, prof, traffic_key=None):
         db = self.db
         p = (self.d_ichr.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr())
@@ -342,7 +471,28 @@ def extra_configs(db, dev, stream, args, box):
               synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, None),
              ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
               0, 1, 200, None)]
-    for name, (ichr, qs, qe), v, gflags, steps, gkey in cases:
+    # stress shapes: queries piled up in one / ten tiles of the same database (the skew valves' work) ...
+    rng = np.random.default_rng(5)
+    for span in (1, 10):
+        ps = np.sort((50000000 + rng.integers(0, 16384 * span, Q)).astype(np.int32))
+        cases.append(("stress: 10^6 position-sorted queries inside %d tile%s of chr1 (skew valve)" % (span, "" if span == 1 else "s"),
+                      (np.zeros(Q, np.int32), ps, (ps + rng.integers(100, 2000, Q)).astype(np.int32)), 0, 1, 10, None))
+    dbs = [db] * len(cases)
+    # ... and a clustered database (half of the intervals around 2000 hot spots: tiles of 10^3 .. 10^4 records, many chunks each)
+    cl = None
+    try:
+        from igd_amd import Database
+        clp = os.path.join(args.dir, "cl300x40000.igd")
+        if not os.path.exists(clp + ".done"):
+            synth.make_db(clp, files=300, per_file=40000, seed=77, genome=synth.HG38, clustered=True)
+            open(clp + ".done", "w").write("ok")
+        cl = Database(clp, device=dev.index or 0)
+        cases.append(("stress: clustered database (300 files x 40 000 intervals, half around 2000 hot spots: %d tile records) "
+                      "+ 10^6 position-sorted queries" % cl.nrecords, base, 0, 1, 30, None))
+        dbs.append(cl)
+    except Exception as e:
+        out.append({"workload": "stress: clustered database", "error": str(e)})
+    for (name, (ichr, qs, qe), v, gflags, steps, gkey), db in zip(cases, dbs):
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags)
             el, prof = job.run(steps, 3)
@@ -363,6 +513,9 @@ def extra_configs(db, dev, stream, args, box):
             del job
         except Exception as e:                              # a side measurement must not lose the line
             out.append({"workload": name, "error": str(e)})
+    db = dbs[0]
+    if cl is not None:
+        cl.close()
     # config 5: -f through the C API (count + scan + chunked fill + pinned D2H, result in host memory)
     try:
         ichr, qs, qe = base
@@ -519,12 +672,40 @@ def main():
             if not line["matches_oracle"]:
                 raise SystemExit("bench.py: per-file counts differ from the oracle's (tests/golden/bench_checksums.json[%s]): %s vs %s"
                                  % (gkey, (line["hits_per_step_total"], line["hits_checksum"]), g))
+        if world == 1:
+            try:                                            # the headline batch with the last-level cache emptied before every launch
+                cold = job.run_cold()
+                rl["cold"] = {"kernel_ms": cold["scan_ms"], "pipeline_ms": cold["pipeline_ms"], "launches_timed": cold["launches"],
+                              "achieved": rl["bytes_per_launch"] / (cold["scan_ms"] * 1e-3) / 1e9 if cold["scan_ms"] > 0 else None,
+                              "frac": rl["bytes_per_launch"] / (cold["scan_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if cold["scan_ms"] > 0 else None,
+                              "how": "512 MiB of other memory read (not written: clean lines) on the same stream between two launches, outside "
+                                     "the kernel's HIP-event pair: no launch finds the image in the 256 MiB Infinity Cache"}
+                cd = job.run_cold(dirty=True)
+                rl["cold_after_writes"] = {"kernel_ms": cd["scan_ms"], "pipeline_ms": cd["pipeline_ms"], "launches_timed": cd["launches"],
+                                           "frac": rl["bytes_per_launch"] / (cd["scan_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if cd["scan_ms"] > 0 else None,
+                                           "how": "as `cold`, but the 512 MiB are read AND written (what a memset would leave): the "
+                                                  "cache is full of dirty lines and their write-back competes with the kernel's reads"}
+            except Exception as e:
+                rl["cold"] = {"error": str(e)}
         if world == 1 and not args.no_cpu:
             bed = os.path.join(args.dir, "q%d_%s.bed" % (Q, "shuf" if args.shuffled else "sorted"))
             if not os.path.exists(bed):
                 synth.write_bed(bed, synth.HG38, ichr, qs, qe)
             extra = ["-v", str(args.v)] if mode == "v" else []
             line["cpu_baseline"] = cpu_baseline(igd_path, bed, Q, int(hits_one.sum()), extra=extra)
+            try:
+                line["cli_end_to_end"] = cli_end_to_end(igd_path, bed, int(hits_one.sum()))
+                line["cli_end_to_end"]["reference_q_seconds"] = line["cpu_baseline"].get("seconds") if not extra else None
+            except Exception as e:
+                line["cli_end_to_end"] = {"error": str(e)}
+            if args.files == 1900 and args.per_file == 26316 and not args.no_extra and line["cpu_baseline"].get("kind") == "reference":
+                try:
+                    g = golden_counts("config4_share_q12500000_v0")
+                    line["cpu_baseline"]["all_cores_large"] = cpu_baseline_allcores_large(
+                        line["cpu_baseline"]["exe"], igd_path, synth.HG38,
+                        synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), g[0] if g else -1, args.dir)
+                except Exception as e:
+                    line["cpu_baseline"]["all_cores_large"] = {"error": str(e)}
         if world == 1 and not args.no_extra:
             line["extra_configs"] = extra_configs(db, dev, stream, args, box)
         print(json.dumps(line), flush=True)

@@ -36,9 +36,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert 0 < r["frac"] <= 1.0 and r["bytes_per_launch"] == r["bytes_breakdown"]["total"] > 0
         assert abs(r["achieved"] - r["bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
+        c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 7 and not any("error" in e for e in x), x
-        assert all(e["value"] > 0 for e in x) and x[6]["roofline"]["bound"] == "pcie-d2h" and x[6]["overlaps"] > 0
+        assert len(x) == 10 and not any("error" in e for e in x), x
+        assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
+        assert sum(e["workload"].startswith("stress:") for e in x) == 3
+        assert r["cold"]["kernel_ms"] > 0 and 0 < r["cold"]["frac"] <= 1.0
+        e2e = j["cli_end_to_end"]
+        assert e2e["q_seconds"] > 0 and e2e["q_v500_seconds"] > 0 and e2e["q_f_seconds"] > 0 and e2e["q_total_matches_gpu"] is True
+        assert c["host"]["cpu_model"] and c["host"]["logical_cpus"] >= 1
         c = j["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]
         assert c["totals_match_gpu"] is True
