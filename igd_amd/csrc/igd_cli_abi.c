@@ -596,8 +596,9 @@ int64_t getOverlaps_f1(char *qFile) { return file_enumerate(qFile); }        /* 
 int64_t getOverlaps_f0(char *qFile) { return file_enumerate(qFile); }        /* :227-250 */
 
 typedef struct { int32_t k; const iGD_t *G; } emit_ctx;
-static void emit_line(void *ctx, int32_t idx, int32_t start, int32_t end)
+static void emit_line(void *ctx, int32_t idx, int32_t start, int32_t end, int32_t in_tile, int32_t tile)
 {
+    (void)in_tile; (void)tile;
     emit_ctx *E = (emit_ctx *)ctx;
     printf("%i\t %i\t %i\t %s\n", E->k++, start, end, E->G->finfo[idx].fileName);          /* :577,:610 */
 }
@@ -628,6 +629,48 @@ static int32_t one_enumerate(char *chrm, int32_t qs, int32_t qe)
     int64_t total = enumerate_and_print(&q, &name);
     igdc_queries_free(&q);
     return (int32_t)total;
+}
+
+/* seq_overlaps, src/igd_search.c:253-352: Seqpare's per-query helper -- every overlap of ONE interval appended to the
+ * caller's list with its similarity st / (qlen + rlen - st) in single precision (the reference's order of operations) and
+ * the reference's identity of a record: (index inside its tile, FIRST tile of the query) -- idx_t = n1 also for records
+ * met in later tiles (:291,:337).  One interval: answered on the host from the interval's own tiles, like get_overlaps;
+ * rule NEST (everything is nested in `if(tmpi>0)`, :266), 16-byte records (the reference reads gdata_t unconditionally).
+ * The list grows by the reference's EXPAND rule (src/igd_base.h:262-265), so `mm` matches as well. */
+typedef struct { overlaps_t *olp; float qlen; int32_t qs, qe, n1; int failed; } seq_ctx;
+static void emit_seq(void *ctx, int32_t idx, int32_t start, int32_t end, int32_t in_tile, int32_t tile)
+{
+    seq_ctx *S = (seq_ctx *)ctx;
+    overlaps_t *o = S->olp;
+    (void)tile;
+    if (S->failed) return;
+    if (o->nn == o->mm) {
+        const int32_t m = o->mm ? o->mm + (2 + o->mm / 8) : 16;
+        overlap_t *p = (overlap_t *)realloc(o->olist, sizeof(overlap_t) * (size_t)m);
+        if (!p) { S->failed = 1; return; }
+        o->olist = p; o->mm = m;
+    }
+    const float st = (float)((S->qe < end ? S->qe : end) - (S->qs > start ? S->qs : start));
+    const float rlen = (float)(end - start);
+    overlap_t *p = &o->olist[o->nn++];
+    p->idx_g = in_tile; p->idx_f = idx; p->idx_t = S->n1;
+    p->sm = st / (S->qlen + rlen - st);
+}
+
+void seq_overlaps(char *chrm, int32_t qs, int32_t qe, overlaps_t *olp)
+{
+    const int32_t ichr = get_id(chrm);
+    if (ichr < 0 || !olp || !g_core || !cur_igd()) return;                  /* :257-258 */
+    const iGD_t *G = cur_igd();
+    if (G->gType == 0) return;                                              /* 12-byte records: the reference would misread them */
+    int fd = g_core_path ? open(g_core_path, O_RDONLY) : (fP ? dup(fileno(fP)) : -1);
+    if (fd < 0) return;
+    seq_ctx S;
+    S.olp = olp; S.qlen = (float)(qe - qs); S.qs = qs; S.qe = qe; S.n1 = qs / G->nbp; S.failed = 0;
+    g_core->nFiles = G->nFiles > 0 ? G->nFiles : INT32_MAX;  /* (no hits[] is indexed here; a caller may not have read the index file) */
+    (void)igdc_walk_one(g_core, fd, ichr, qs, qe, 0, 0, IGD_HIP_RULE_NEST, NULL, emit_seq, &S);
+    g_core->nFiles = G->nFiles;
+    close(fd);
 }
 
 int32_t get_overlaps_f1(char *chrm, int32_t qs, int32_t qe) { return one_enumerate(chrm, qs, qe); } /* :537-620 */

@@ -252,7 +252,7 @@ int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32
             if (r[1] < qe && (int64_t)r[1] >= lob && r[2] > qs && (!use_v || r[3] >= v)) {
                 if (r[0] < 0 || r[0] >= db->nFiles) continue;              /* the reference indexes hits[] unchecked (:491) */
                 if (hits) hits[r[0]]++;
-                if (emit) emit(ctx, r[0], r[1], r[2]);
+                if (emit) emit(ctx, r[0], r[1], r[2], i, j);
                 total++;
             }
         }

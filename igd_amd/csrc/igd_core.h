@@ -79,7 +79,8 @@ int igdc_devices_from_env(int *devices, int max);
  * hits are the records with lob <= start < qe && end > qs [&& value >= v], lob = the tile's start in later tiles.
  * `emit` (may be NULL) is called per overlap in the reference's -f order (tiles ascending, record index descending).
  * Returns the number of overlaps, or -1 on an I/O error. */
-typedef void (*igdc_emit_fn)(void *ctx, int32_t idx, int32_t start, int32_t end);
+/* one overlap: dataset, start, end, and where the record sits -- its index inside tile `tile` of the contig */
+typedef void (*igdc_emit_fn)(void *ctx, int32_t idx, int32_t start, int32_t end, int32_t in_tile, int32_t tile);
 int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32_t qe, int32_t v, int use_v, int rule,
                       int64_t *hits, igdc_emit_fn emit, void *ctx);
 

@@ -54,6 +54,19 @@ typedef struct {
     int64_t **tIdx;   /* byte offset of every tile in the file   */
 } iGD_t;
 
+/* One overlap as Seqpare records it, and a growing list of them (reference: src/igd_base.h:108-119). */
+typedef struct {
+    int32_t idx_t;    /* FIRST tile of the query (also for records met in later tiles, src/igd_search.c:291,:337) */
+    int32_t idx_g;    /* index of the record inside its tile      */
+    int32_t idx_f;    /* dataset of the record                    */
+    float   sm;       /* similarity overlap / (|q| + |r| - overlap), single precision */
+} overlap_t;
+
+typedef struct {
+    int32_t    nn, mm;   /* entries used / allocated               */
+    overlap_t *olist;    /* realloc'ed by seq_overlaps              */
+} overlaps_t;
+
 /* Process-wide state of the CLI flavour (reference: src/igd_base.h:135-140; defined in
  * src/igd.c:14-19, here in igd_cli_abi.c so that a plain `-ligd` link works, and a program
  * that defines them itself still links: ELF resolves to the executable's copy). */

@@ -20,9 +20,9 @@
  *     interval's own tiles, exactly as the reference reads them, while no engine is resident.
  * GPU selection: environment variables IGD_DEVICE (default 0) / IGD_DEVICES=0,1,.. (query slabs).
  *
- * Seqpare: seqOverlaps (src/igd_search.c:354-451) is provided; its per-query helper seq_overlaps
- * (:253-352, fills an overlaps_t for ONE query) is not -- the matching needs all queries at once and
- * runs on the GPU.
+ * Seqpare: seqOverlaps (src/igd_search.c:354-451) runs on the GPU -- the matching needs all queries at
+ * once; its per-query helper seq_overlaps (:253-352, appends ONE interval's overlaps and similarities to
+ * the caller's overlaps_t) is a single interval and answered on the host like get_overlaps.
  */
 #ifndef __IGD_SEARCH_H__
 #define __IGD_SEARCH_H__
@@ -52,6 +52,7 @@ int64_t getMap(uint32_t **hitmap);                                              
 int64_t getMap_v(uint32_t **hitmap, int32_t v);                                        /* :829-886 */
 
 /* `-s`: Seqpare similarity of the query file with every dataset; sm[nFiles] --------- */
+void seq_overlaps(char *chrm, int32_t qs, int32_t qe, overlaps_t *olp);                 /* :253-352 */
 void seqOverlaps(char *qFile, double *sm);                                             /* :354-451 */
 
 /* `igd search <db.igd> [-q file | -r chr s e | -m] [-v N] [-f] [-o name] [-c]`        :889-1079 */

@@ -691,6 +691,21 @@ static void sq_overlaps(orc_db *db, const char *chrm, int32_t qs, int32_t qe, sq
     }
 }
 
+/* seq_overlaps for ONE interval, for the tests: up to `cap` entries {idx_t, idx_g, idx_f, float bits of sm} into out[4 * k];
+ * returns the number of overlaps (which may exceed cap). */
+int64_t orc_seq_overlaps(orc_db *db, const char *chrm, int32_t qs, int32_t qe, int32_t *out, int64_t cap)
+{
+    sq_ovl *L = NULL;
+    int32_t nn = 0, mm = 0;
+    sq_overlaps(db, chrm, qs, qe, &L, &nn, &mm);
+    for (int32_t k = 0; k < nn && k < cap; k++) {
+        out[4 * k] = L[k].idx_t; out[4 * k + 1] = L[k].idx_g; out[4 * k + 2] = L[k].idx_f;
+        memcpy(&out[4 * k + 3], &L[k].sm, 4);
+    }
+    free(L);
+    return nn;
+}
+
 static void sq_stable_sort_iv(sq_iv *a, int64_t n)          /* by start, ties keep their order */
 {
     if (n < 2) return;

@@ -109,6 +109,8 @@ int64_t orc_getMap(orc_db *db, int use_v, int32_t v, uint32_t *hitmap, FILE *pro
 /* ---- Seqpare similarity (`search -q f.bed -s`), SURVEY 8f row f4 -------------------------- */
 /* seqOverlaps src/igd_search.c:354-451 over seq_overlaps :253-352: sm[nFiles].  0 / -1 (file). */
 int orc_seqOverlaps(orc_db *db, const char *qfile, double *sm);
+/* seq_overlaps :253-352 for one interval: {idx_t, idx_g, idx_f, bits of sm} x min(n, cap) into out; returns n */
+int64_t orc_seq_overlaps(orc_db *db, const char *chrm, int32_t qs, int32_t qe, int32_t *out, int64_t cap);
 
 /* ---- `igd create`, SURVEY 8f row f4 (igd_oracle_create.c) ------------------------------ */
 enum { ORC_CREATE_GLOB = 0, ORC_CREATE_LIST = 1, ORC_CREATE_GTYPE0 = 2, ORC_CREATE_BED4 = 3 };

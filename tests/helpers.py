@@ -317,3 +317,19 @@ def parse_hits_table(text, nfiles):
         if len(parts) == 4 and parts[0].strip().isdigit():
             hits[int(parts[0])] = int(parts[2])
     return hits, total
+
+
+def build_r_call_harness(outdir):
+    """igdr_abi.c WITH its `.Call` entry points (-DIGDR_HAVE_R) against the mock of R's C API (tests/mock_r: not R), linked
+    with the harness tests/c/r_call_main.c and the product's engine library.  Returns the executable's path."""
+    exe = os.path.join(outdir, "r_call_main")
+    src = os.path.join(ROOT, "igd_amd", "csrc")
+    lib = os.path.join(ROOT, "igd_amd", "lib")
+    cmd = ["gcc", "-O1", "-g", "-std=gnu99", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror=implicit-function-declaration",
+           "-Werror=incompatible-pointer-types", "-DIGDR_HAVE_R",
+           "-I" + os.path.join(ROOT, "tests", "mock_r"), "-I" + os.path.join(ROOT, "include"), "-I" + src, "-I" + os.path.join(ROOT, "tools"),
+           "-o", exe, os.path.join(ROOT, "tests", "c", "r_call_main.c"), os.path.join(ROOT, "tests", "mock_r", "mock_r.c"),
+           os.path.join(src, "igdr_abi.c"), os.path.join(src, "igd_core.c"), os.path.join(src, "igd_create.c"),
+           "-L" + lib, "-ligd_hip", "-lz", "-lpthread", "-Wl,-rpath," + lib]
+    subprocess.check_call(cmd)
+    return exe

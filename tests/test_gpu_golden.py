@@ -147,6 +147,23 @@ def test_r_flavour_c_entry_points():
     o.close()
 
 
+def test_r_call_entry_points_run_against_a_mock_of_the_r_api():
+    """Every `.Call` entry point of the R flavour, compiled against the MOCK of R's C API (tests/mock_r: not R -- the image
+    has no R) and called by tests/c/r_call_main.c the way IGDr.R calls them: handle object + finalizer, search_1r and
+    search_nr (one GPU batch) against the plain-C get_overlaps32, the get_* accessors, get_binData's columns, and an R
+    error -- not a crash -- for a call on a freed handle."""
+    import shutil
+    import subprocess
+    from helpers import build_r_call_harness, short_tmpdir
+    d = short_tmpdir("igr")
+    try:
+        exe = build_r_call_harness(d)
+        p = subprocess.run([exe, os.path.join(GOLDEN, "smallrand", "db.igd"), "gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0 and b"R-CALL-OK" in p.stdout and b"search_nr" in p.stdout, (p.stdout.decode(), p.stderr.decode()[-800:])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 @pytest.mark.parametrize("case", ["edge", "quirk", "branch", "smallrand"])
 def test_cli_hitmap_file_identical_to_reference(case):
     """`igd search db.igd -m [-v N] -o file` writes the bytes the reference wrote (f3)."""

@@ -387,3 +387,71 @@ def test_r_flavour_search_1_needs_no_gpu(N):
         assert R.igd_engine_status() == 0
     finally:
         o.close()
+
+
+def test_r_call_entry_points_compile_against_a_mock_of_the_r_api():
+    """The ten `.Call` functions of the R flavour (igdr_abi.c -DIGDR_HAVE_R: IGDr/src/igd_search.c:307-355,
+    IGDr/src/igd_base.c:382-461) cannot be built against R here -- the image has none -- so they are compiled, with
+    implicit declarations and pointer mismatches as errors, against a MOCK of the few R C-API names they use
+    (tests/mock_r, plainly labelled: not R) and linked with a harness that calls every one of them
+    (tests/c/r_call_main.c; run on the GPU box: tests/test_gpu_golden.py).  Here, without a GPU: iGD_new must raise an R
+    error that names the reason -- not crash, not end the process on its own."""
+    from helpers import build_r_call_harness
+    d = short_tmpdir("igr")
+    try:
+        exe = build_r_call_harness(d)
+        p = subprocess.run([exe, os.path.join(GOLDEN, "smallrand", "db.igd")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode == 3 and b"mock Rf_error outside a guarded call" in p.stderr and b"GPU engine" in p.stderr, \
+            (p.returncode, p.stdout.decode(), p.stderr.decode()[-800:])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def test_seq_overlaps_one_interval_on_the_host_equals_the_oracle():
+    """seq_overlaps (src/igd_search.h:19, src/igd_search.c:253-352): the per-query helper of Seqpare appends one interval's
+    overlaps -- (first tile of the query, index in tile, dataset, single-precision similarity) in the reference's order --
+    to the caller's overlaps_t, growing it by the reference's EXPAND rule.  One interval: host path, no GPU.  In a child
+    process (the CLI flavour keeps process-wide state)."""
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from helpers import Oracle, orc
+from igd_amd import _native as N
+db = %r
+L = N.cli()
+assert L.get_igdinfo(db.encode())
+class Ov(C.Structure):
+    _fields_ = [("nn", C.c_int32), ("mm", C.c_int32), ("olist", C.c_void_p)]
+L.seq_overlaps.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(Ov)]
+L.seq_overlaps.restype = None
+o = Oracle(db)
+lib = orc()
+lib.orc_seq_overlaps.restype = C.c_int64
+lib.orc_seq_overlaps.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64]
+import random
+rng = random.Random(5)
+ov = Ov(0, 0, None)
+want_all = []
+names = o.ctg_names() + ["chrNope"]
+nbp = o.nbp
+for k in range(400):
+    c = rng.choice(names).encode()
+    s = rng.randrange(0, 40 * nbp)
+    e = s + rng.choice([0, 1, 50, nbp // 3, nbp, 3 * nbp + 7, -20])
+    buf = (C.c_int32 * (4 * 100000))()
+    n = lib.orc_seq_overlaps(o.h, c, s, e, buf, 100000)
+    want_all += list(buf[: 4 * n])
+    L.seq_overlaps(c, s, e, C.byref(ov))
+got = np.ctypeslib.as_array(C.cast(ov.olist, C.POINTER(C.c_int32)), shape=(4 * ov.nn,)) if ov.nn else np.zeros(0, np.int32)
+assert ov.nn * 4 == len(want_all) and ov.nn > 500, (ov.nn, len(want_all))
+assert np.array_equal(got, np.array(want_all, np.int32)), "entries differ"
+m = 0
+for _ in range(10**6):                     # capacity by the reference's EXPAND rule (src/igd_base.h:262-265)
+    if m >= ov.nn and m >= 16: break
+    m = m + (2 + m // 8) if m else 16
+assert ov.mm >= ov.nn
+print("seq-ok", ov.nn)
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "smallrand", "db.igd"))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0 and b"seq-ok" in p.stdout, (p.stdout.decode(), p.stderr.decode()[-1500:])
