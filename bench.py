@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache runs of the headline batch (profiling runs: their launches would be averaged in)")
     ap.add_argument("--slab-of", type=int, default=0, metavar="G",
                     help="N=1 only: this GPU's step is slab 0 of a G-GPU config-4 job (G x --queries position-sorted queries) -- "
                          "what one of G GPUs would run, measured without the other G-1")
@@ -672,7 +673,7 @@ def main():
             if not line["matches_oracle"]:
                 raise SystemExit("bench.py: per-file counts differ from the oracle's (tests/golden/bench_checksums.json[%s]): %s vs %s"
                                  % (gkey, (line["hits_per_step_total"], line["hits_checksum"]), g))
-        if world == 1:
+        if world == 1 and not args.no_cold:
             try:                                            # the headline batch with the last-level cache emptied before every launch
                 cold = job.run_cold()
                 rl["cold"] = {"kernel_ms": cold["scan_ms"], "pipeline_ms": cold["pipeline_ms"], "launches_timed": cold["launches"],

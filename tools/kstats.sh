@@ -2,7 +2,7 @@
 # tools/kstats.sh [bench args] -- per-kernel average times of one bench run (GPU box)
 python tools/prep.py > /dev/null 2>&1
 root=$PWD; cd /tmp && export TMPDIR=/tmp; rm -rf /tmp/ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $root/bench.py --no-cpu --steps 20 --warmup 3 "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python3 $root/bench.py --no-cpu --no-cold --steps 20 --warmup 3 "$@" > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob
 for f in glob.glob("/tmp/ks/*/*_kernel_stats.csv"):

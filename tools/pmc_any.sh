@@ -6,7 +6,7 @@ python tools/prep.py > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_LDS SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" "SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_GDS SQ_INSTS_FLAT" "TCC_REQ_sum TCC_HIT_sum" "TCC_ATOMIC_sum TCC_WRITE_sum" "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag -- python3 $root/bench.py --no-cpu --no-extra --steps 6 --warmup 2 "$@" > $out/$tag.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag -- python3 $root/bench.py --no-cpu --no-extra --no-cold --steps 6 --warmup 2 "$@" > $out/$tag.log 2>&1 || true
 done
 cd $root
 python3 - $out "$pat" <<'PY' | tee $out/summary.txt

@@ -5,7 +5,7 @@ python tools/prep.py > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   tag=$(echo $grp | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag -- python3 $root/bench.py --no-cpu --no-extra --steps 10 --warmup 2 "$@" > $out/$tag.log 2>&1 || true
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag -- python3 $root/bench.py --no-cpu --no-extra --no-cold --steps 10 --warmup 2 "$@" > $out/$tag.log 2>&1 || true
 done
 cd $root
 python3 - $out <<'PY'

@@ -15,9 +15,9 @@ out=$root/gpurun_out/profile_$tag
 mkdir -p $out
 python3 bench.py --no-extra "$@" > $out/bench.json 2> $out/bench.err || true
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu --no-extra "$@" > $out/stats.log 2>&1 || true
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu --no-extra --steps 10 --warmup 2 "$@" > $out/fetch.log 2>&1 || true
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu --no-extra --steps 10 --warmup 2 "$@" > $out/write.log 2>&1 || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py --no-cpu --no-extra --no-cold "$@" > $out/stats.log 2>&1 || true
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu --no-extra --no-cold --steps 10 --warmup 2 "$@" > $out/fetch.log 2>&1 || true
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu --no-extra --no-cold --steps 10 --warmup 2 "$@" > $out/write.log 2>&1 || true
 cd $root
 cp $out/stats/*/*_kernel_stats.csv $out/kernel_stats.csv 2>/dev/null || true
 cp $out/fetch/*/*_counter_collection.csv $out/pmc_fetch.csv 2>/dev/null || true
