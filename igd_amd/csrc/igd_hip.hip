@@ -1971,6 +1971,30 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         // One batch of <= 64 entries of the candidate list, entry p + lane in each lane: word w for a first-tile query
         // (IGD_NEVER where the lane has none), later[] entry e for a later-tile one (first batch only: WITH_LATER).
         // Term A: every covering query bisects the unit's starts with its end and adds 1 to the histogram there.
+        // the exceptions of a batch (lanes x: first-tile queries whose word is IGD_NEVER or inverted; idx: which of the tile's
+        // queries, -1 in lanes that hold none): qs2 <- their true start, their contribution to term B undone, an inverted
+        // query's own hits added
+        auto batchFix = [&](const int w, int &qs2, const int idx, unsigned long long x) {
+            int t = load_now(KARG(a.q_qs) + (idx >= 0 ? f0 + idx : f0)) - IGD_TILE_START + 1;   // = qs' for a query of this tile; beyond it: clamped
+            if (idx < 0) t = 65535;
+            t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+            qs2 = t;
+            while (x) {
+                const int src = __builtin_ctzll(x);
+                x &= ~(1ull << src);
+                const int s_ = __builtin_amdgcn_readlane(qs2, src), wq = __builtin_amdgcn_readlane(w, src);
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    igd_u16x2 rec, qw;
+                    __builtin_memcpy(&rec, &R.a[r], 4);
+                    __builtin_memcpy(&qw, &wq, 4);
+                    const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);
+                    uint32_t mxw;
+                    __builtin_memcpy(&mxw, &mx, 4);
+                    cnt[r] += (s_ > (int)(R.a[r] >> 16) ? 1 : 0) + (mxw == R.a[r] ? 1 : 0);   // undo term B; an inverted query's own hits
+                }
+            }
+        };
         auto batchA = [&](const int w, const int e, const int p, const bool withLater) {
             const int idx = p + lane - nl;               // which of the tile's own queries (first batch: < 0 in the later-tile lanes)
             const bool there = idx >= 0 && idx < c0;
@@ -1991,52 +2015,46 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             nFirst += __popcll(__ballot(good));
             // the exceptions: masked-out (IGD_NEVER) or inverted queries.  They stay in the ordered list of starts that
             // term B bisects -- with their TRUE start, so that it stays ordered -- and are taken out again one by one
-            unsigned long long x = __ballot(there && !good);
-            if (x) {
-                int t = load_now(KARG(a.q_qs) + (there ? f0 + idx : f0)) - IGD_TILE_START + 1;   // = qs' for a query of this tile; beyond it: clamped
-                if (!there) t = 65535;
-                t = t < 1 ? 1 : (t > 65535 ? 65535 : t);
-                qs2 = t;
-                while (x) {
-                    const int src = __builtin_ctzll(x);
-                    x &= ~(1ull << src);
-                    const int s_ = __builtin_amdgcn_readlane(qs2, src), wq = __builtin_amdgcn_readlane(w, src);
-#pragma unroll
-                    for (int r = 0; r < IGD_SLOTS; r++) {
-                        igd_u16x2 rec, qw;
-                        __builtin_memcpy(&rec, &R.a[r], 4);
-                        __builtin_memcpy(&qw, &wq, 4);
-                        const igd_u16x2 mx = __builtin_elementwise_max(rec, qw);
-                        uint32_t mxw;
-                        __builtin_memcpy(&mxw, &mx, 4);
-                        cnt[r] += (s_ > (int)(R.a[r] >> 16) ? 1 : 0) + (mxw == R.a[r] ? 1 : 0);   // undo term B; an inverted query's own hits
-                    }
-                }
-            }
+            const unsigned long long x = __ballot(there && !good);
+            if (x) batchFix(w, qs2, there ? idx : -1, x);
             if (inLds && there) sb[idx] = (unsigned short)qs2;
         };
         // The batches after the first are fetched one ahead: the load of batch k + 1 is issued before batch k is searched
         // and its word first touched after (530 queries per tile -- one GPU's slab of an 8-GPU job -- are 9 batches, and
         // a load waited for on the spot made each of them a memory round trip).  Two batches per pass of the loop, so
         // that no loaded word is carried around it.
-        if (nE <= IGD_WAVE) batchA(R.q, R.lw, 0, nl != 0);   // (the usual dense tile: nothing to fetch ahead)
+        // A batch that lies wholly inside the tile's own queries (no later-tile lanes, no lanes past the last query -- all
+        // batches but the first and the last of a tile with hundreds of queries): nothing to mask, nothing to select
+        auto batchIn = [&](const int w, const int p) {
+            const int idx = p + lane - nl;
+            const int qe2 = 65536 - (w & 0xFFFF);
+            int qs2 = (int)((unsigned)w >> 16);
+            const bool good = (unsigned)w != IGD_NEVER && qe2 >= qs2;
+            const int pos = (IGD_EXP & 128) ? (qe2 & 255) : lds_lower_bound(sl, qe2);
+            if (good) atomicAdd(&hist[pos], 1u);
+            const unsigned long long gm = __ballot(good);
+            nFirst += __popcll(gm);
+            if (gm != ~0ull) batchFix(w, qs2, idx, ~gm);   // masked-out or inverted queries: rare
+            if (inLds) sb[idx] = (unsigned short)qs2;
+        };
+        // The batches after the first are fetched one ahead -- the load of batch k + 1 is issued before batch k is searched
+        // and its word first touched after (530 queries per tile -- one GPU's slab of an 8-GPU job -- are 9 batches, and a
+        // load waited for on the spot made each of them a memory round trip) -- by a bounds-checked load that costs no
+        // vector instruction: per-lane offset lane * 4, the batch's first word in the scalar offset, and the lanes past the
+        // tile's last query read 0 = ~IGD_NEVER.  (The later-tile entries all sit in the first batch: nl <= 64.)
+        if (nE <= IGD_WAVE) batchA(R.q, R.lw, 0, nl != 0);   // (nothing to fetch ahead)
         else {
-            int wa = R.q;
-            for (int p = 0; p < nE; p += 2 * IGD_WAVE) {
-                const bool moreB = p + IGD_WAVE < nE, moreA = p + 2 * IGD_WAVE < nE;
-                // (unconditional, from an index clamped into the tile's queries: behind a branch the compiler waits for a
-                // load where the branch ends)
-                const int last = f0 + c0 - 1;
-                const int ib = f0 + p + IGD_WAVE + lane - nl, ia = ib + IGD_WAVE;
-                const int rb = a.qw0[ib < last ? ib : last];
-                if (p == 0) batchA(wa, R.lw, 0, nl != 0); else batchA(wa, 0, p, false);
-                if (!moreB) break;
-                const int wb = p + IGD_WAVE + lane < nE ? ~rb : (int)IGD_NEVER;
-                const int ra = a.qw0[ia < last ? ia : last];
-                batchA(wb, 0, p + IGD_WAVE, false);
-                if (!moreA) break;
-                wa = p + 2 * IGD_WAVE + lane < nE ? ~ra : (int)IGD_NEVER;
+            const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, (f0 + c0) * 4, 0x00020000);
+            const int vo4 = lane * 4;
+            int wn = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rsq, vo4, (f0 + IGD_WAVE - nl) * 4, 0);
+            batchA(R.q, R.lw, 0, nl != 0);
+            int p = IGD_WAVE;
+            for (; p + IGD_WAVE <= nE; p += IGD_WAVE) {
+                const int w = wn;
+                wn = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rsq, vo4, (f0 + p + IGD_WAVE - nl) * 4, 0);   // (past the end: size-0 access)
+                batchIn(w, p);       // (two of these side by side, their searches advancing in the same steps: no faster)
             }
+            if (p < nE) batchA(wn, 0, p, false);
         }
         SECT(1);
         if (far)
