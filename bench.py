@@ -629,7 +629,8 @@ def main():
     hits_job = job.d_hits.cpu().numpy()      # K identical batches per rank, summed over ranks
     assert args.steps > 0 and (hits_job % args.steps == 0).all(), "hits[] is not K times one batch"
     hits_one = hits_job // args.steps        # one batch per rank, summed over ranks
-    tkey = "%s/%s/q%d%s" % (mode, "shuffled" if args.shuffled else "sorted", Q, "/exact" if args.exact_arrays else "")
+    tkey = "%s/%s/q%d%s%s" % (mode, "shuffled" if args.shuffled else "sorted", Q, "/exact" if args.exact_arrays else "",
+                              "/slab0of%d" % args.slab_of if (world == 1 and args.slab_of > 1) else "")
     rl = job.roofline(prof, tkey if world == 1 else None)     # outside the timed region
 
     if rank == 0:

@@ -8,7 +8,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 keys = {"sorted": "hits/sorted/q1000000", "shuffled": "hits/shuffled/q1000000", "v500": "v/sorted/q1000000",
-        "dense": "hits/sorted/q12500000", "exact": "hits/sorted/q1000000/exact", "auto": None}
+        "dense": "hits/sorted/q12500000", "slab8": "hits/sorted/q12500000/slab0of8", "exact": "hits/sorted/q1000000/exact", "auto": None}
 traffic = {}
 for tag, key in keys.items():
     src = os.path.join(root, "gpurun_out", "profile_" + tag)
@@ -26,6 +26,12 @@ for tag, key in keys.items():
             traffic[key] = t
     except Exception:
         pass
+for tag in ("sorted", "dense", "slab8"):                  # instruction mix of the scan kernel / of k_query_bounds (tools/pmc_any.sh)
+    for kern in ("scan", "qb"):
+        src = os.path.join(root, "gpurun_out", "pmc_%s_%s" % (kern, tag), "summary.txt")
+        if os.path.exists(src):
+            os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)
+            shutil.copy(src, os.path.join(dst, "pmc", "instruction_mix_%s_%s.txt" % (kern, tag)))
 for f in ("misc.json",):
     if os.path.exists(os.path.join(root, "gpurun_out", f)):
         shutil.copy(os.path.join(root, "gpurun_out", f), os.path.join(dst, f))
