@@ -3621,12 +3621,15 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
-        if (wide) { if (fast) QB_LAUNCH(4, true, 1024); else QB_LAUNCH(4, false, 1024); }
+#ifndef IGD_QB_WIDE
+#define IGD_QB_WIDE 1024
+#endif
+        if (wide) { if (fast) QB_LAUNCH(4, true, IGD_QB_WIDE); else QB_LAUNCH(4, false, IGD_QB_WIDE); }
         else if (vec) { if (fast) QB_LAUNCH(4, true, 256); else QB_LAUNCH(4, false, 256); }
         else { if (fast) QB_LAUNCH(1, true, 256); else QB_LAUNCH(1, false, 256); }
 #undef QB_LAUNCH
 #undef QB_GRID
-        db->lbShift = wide ? 12 : vec ? 10 : 8;
+        db->lbShift = wide ? (IGD_QB_WIDE == 1024 ? 12 : IGD_QB_WIDE == 512 ? 11 : 10) : vec ? 10 : 8;
     }
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
