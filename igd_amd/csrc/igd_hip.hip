@@ -1717,14 +1717,19 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
         const int end = (int)offLo + n;                   // < 2^30 records: byte offsets fit 32 bits
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, (int)((unsigned)end * 4u), 0x00020000);
         if (USE_V) {
-            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, (int)((unsigned)end * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, n ? (int)((unsigned)(end + IGD_CHUNK) * 4u) : 0, 0x00020000);   // (see below)
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
                 R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
             }
         } else {
-            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, (int)((unsigned)end * 2u), 0x00020000);
+            // (the dataset numbers are NOT cut off at the unit's end: the lanes past it -- whose record words are 0, so they
+            // count nothing -- then name the datasets of the records that follow instead of all naming dataset 0.  Their
+            // "+ 0" LDS atomics queued up for that ONE counter: on a database of small tiles -- 30 records: four and a half
+            // of a unit's five slots empty -- the waves spent 81 % of their cycles waiting for the LDS.  The arrays are
+            // padded by a chunk; a unit nobody asks about still touches no memory)
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, n ? (int)((unsigned)(end + IGD_CHUNK) * 2u) : 0, 0x00020000);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), IGD_NT_AUX);
@@ -3399,6 +3404,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             return rc2;
         }
         hipError_t e = hipMemset(db->d_ctl, 0, 16 * 4);
+        // the chunk of padding behind the dataset numbers is READ (igd_scan_sorted lets the lanes past the last unit's end
+        // name whatever datasets follow): it has to hold valid numbers
+        if (e == hipSuccess) e = hipMemsetAsync(db->d_px + n, 0, IGD_CHUNK * sizeof(uint16_t), db->stream);
+        if (e == hipSuccess && db->d_pxv) e = hipMemsetAsync(db->d_pxv + n, 0, IGD_CHUNK * sizeof(uint32_t), db->stream);
         if (e == hipSuccess) {
             k_pack_units<<<256 * 8, 256, 0, db->stream>>>(v, db->d_units, db->d_pse, db->d_px, db->d_pxv, db->d_ctl);
             e = hipStreamSynchronize(db->stream);
