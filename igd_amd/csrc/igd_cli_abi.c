@@ -262,6 +262,8 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
     igdc_queries q = J.q;
     phase(threaded ? "database -> GPU  ||  read + parse queries" : "read + parse queries", &t0);
     int64_t total = 0;
+    if (q.unsorted && igdc_queries_group_contigs(&q, g_core->nCtg))       /* a sorted BED, chromosomes in another order */
+        phase("contig runs put into the database's order", &t0);
     if (q.n > 0) {
         igd_hip_db *dev = engine();
         t0 = now_s();

@@ -473,6 +473,52 @@ int igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe)
     return 0;
 }
 
+/* A position-sorted BED whose chromosomes come in another order than the database numbers its contigs (`sort -k1,1
+ * -k2,2n` puts chr10 before chr2; the database numbers contigs by first appearance in its input files): every contig is
+ * ONE run of lines ordered by start, only the runs are out of order.  Counts are sums over queries, so the runs may be
+ * put into contig order -- one pass to check, one to copy -- and the batch takes the merge join instead of the bucket
+ * path (whose grouping kernels, built for scattered queries, are at their worst on long sorted runs: 334 vs 68 us per
+ * 10^6 queries).  Returns 1 when the queries were reordered (q->unsorted cleared), 0 when they are left alone.
+ * Not for `-f` / Seqpare, whose output follows the query order. */
+int igdc_queries_group_contigs(igdc_queries *q, int32_t nCtg)
+{
+    if (!q || !q->unsorted || q->n < 2 || nCtg <= 0) return 0;
+    int64_t *cnt = (int64_t *)calloc((size_t)nCtg + 1, sizeof(int64_t));
+    if (!cnt) return 0;
+    int ok = 1;
+    for (int64_t i = 0; i < q->n && ok; i++) {
+        const int32_t c = q->ichr[i];
+        if (c < 0 || c >= nCtg) { ok = 0; break; }
+        if (i > 0 && c == q->ichr[i - 1]) { if (q->qs[i] < q->qs[i - 1]) ok = 0; }
+        else if (cnt[c] != 0) ok = 0;                     /* the contig's second run */
+        cnt[c]++;
+    }
+    int32_t *a = NULL, *b = NULL, *d = NULL;
+    if (ok) {
+        a = (int32_t *)malloc(sizeof(int32_t) * (size_t)q->n);
+        b = (int32_t *)malloc(sizeof(int32_t) * (size_t)q->n);
+        d = (int32_t *)malloc(sizeof(int32_t) * (size_t)q->n);
+        if (!a || !b || !d) ok = 0;
+    }
+    if (ok) {
+        int64_t at = 0;
+        for (int32_t c = 0; c < nCtg; c++) { const int64_t k = cnt[c]; cnt[c] = at; at += k; }   /* first slot of each contig */
+        for (int64_t i = 0; i < q->n;) {                  /* run by run */
+            const int32_t c = q->ichr[i];
+            int64_t j = i;
+            while (j < q->n && q->ichr[j] == c) j++;
+            memcpy(a + cnt[c], q->ichr + i, sizeof(int32_t) * (size_t)(j - i));
+            memcpy(b + cnt[c], q->qs + i, sizeof(int32_t) * (size_t)(j - i));
+            memcpy(d + cnt[c], q->qe + i, sizeof(int32_t) * (size_t)(j - i));
+            i = j;
+        }
+        free(q->ichr); free(q->qs); free(q->qe);
+        q->ichr = a; q->qs = b; q->qe = d; q->cap = q->n; q->unsorted = 0;
+    } else { free(a); free(b); free(d); }
+    free(cnt);
+    return ok;
+}
+
 void igdc_queries_free(igdc_queries *q)
 {
     free(q->ichr); free(q->qs); free(q->qe);

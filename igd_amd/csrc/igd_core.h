@@ -105,6 +105,9 @@ typedef struct {
  * database are dropped here (the reference drops them in get_overlaps, :456-457). */
 int  igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out);
 void igdc_queries_free(igdc_queries *q);
+/* every contig ONE run ordered by start, only the runs out of contig order (a sorted BED with another chromosome order
+ * than the database's): put the runs into contig order, clear q->unsorted, return 1; otherwise 0.  Hits-only searches. */
+int  igdc_queries_group_contigs(igdc_queries *q, int32_t nCtg);
 int  igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe);
 
 #ifdef __cplusplus

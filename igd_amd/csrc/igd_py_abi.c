@@ -117,6 +117,7 @@ int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
     if (!iGD || !iGD->core) return 0;
     igdc_queries q;
     if (igdc_read_queries(iGD->core, qFile, 0, &q) != 0) return 0;
+    (void)igdc_queries_group_contigs(&q, iGD->core->nCtg);    /* a sorted BED with another chromosome order than the database's */
     if (q.n > 0) {
         int rc = igd_hip_search_ex(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
                                    IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);

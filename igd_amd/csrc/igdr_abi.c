@@ -133,6 +133,7 @@ void getOverlaps(char **igdFile, char **qFile, int64_t *hits)
     if (!h) return;
     igdc_queries q;
     if (igdc_read_queries(h->core, *qFile, 0, &q) == 0) {
+        (void)igdc_queries_group_contigs(&q, h->core->nCtg);  /* a sorted BED with another chromosome order than the database's */
         if (q.n > 0) {
             int rc = igd_hip_search_ex(h->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
                                        IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);

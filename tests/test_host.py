@@ -455,3 +455,44 @@ print("seq-ok", ov.nn)
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(GOLDEN, "smallrand", "db.igd"))
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0 and b"seq-ok" in p.stdout, (p.stdout.decode(), p.stderr.decode()[-1500:])
+
+
+def test_contig_runs_of_a_sorted_bed_are_put_into_the_databases_order(N):
+    """igdc_queries_group_contigs: a BED sorted by (chromosome, start) whose chromosomes come in another order than the
+    database numbers them is ONE ordered run per contig -- the runs are permuted into contig order (same multiset of
+    queries, now ordered by (contig, start): the merge join's input); anything else -- a contig in two runs, a start out
+    of order -- is left exactly as it was."""
+    L = N.cli()
+
+    class Q(C.Structure):
+        _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("ichr", N.i32p), ("qs", N.i32p), ("qe", N.i32p), ("unsorted", C.c_int32)]   # igd_core.h
+    L.igdc_queries_push.argtypes = [C.POINTER(Q), C.c_int32, C.c_int32, C.c_int32]
+    L.igdc_queries_group_contigs.argtypes = [C.POINTER(Q), C.c_int32]
+    L.igdc_queries_group_contigs.restype = C.c_int
+    L.igdc_queries_free.argtypes = [C.POINTER(Q)]
+    rng = random.Random(11)
+
+    def build(rows):
+        q = Q()
+        for c, s, e in rows:
+            assert L.igdc_queries_push(C.byref(q), c, s, e) == 0
+        return q
+
+    def rows_of(q):
+        return [(q.ichr[i], q.qs[i], q.qe[i]) for i in range(q.n)]
+
+    runs = {c: sorted((rng.randrange(0, 10**6), rng.randrange(1, 5000)) for _ in range(rng.randrange(1, 40))) for c in range(6)}
+    order = [3, 0, 5, 1, 4, 2]                                       # e.g. chr1 chr10 chr11 chr2 ... against natural numbering
+    rows = [(c, s, s + l) for c in order for s, l in runs[c]]
+    q = build(rows)
+    assert q.unsorted == 1
+    assert L.igdc_queries_group_contigs(C.byref(q), 6) == 1 and q.unsorted == 0
+    got = rows_of(q)
+    assert got == [(c, s, s + l) for c in range(6) for s, l in runs[c]] and sorted(got) == sorted(rows)
+    L.igdc_queries_free(C.byref(q))
+    # a contig in two runs / a start out of order inside a run / already ordered: untouched
+    for bad in (rows + [(3, 7, 9)], [(1, 50, 60), (1, 40, 70), (0, 1, 2)], [(0, 1, 2), (1, 1, 2)]):
+        q = build(bad)
+        before, flag = rows_of(q), q.unsorted
+        assert L.igdc_queries_group_contigs(C.byref(q), 6) == 0 and rows_of(q) == before and q.unsorted == flag
+        L.igdc_queries_free(C.byref(q))
