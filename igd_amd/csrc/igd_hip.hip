@@ -913,17 +913,33 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
     }
     __syncthreads();
     if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < SPF_WG / IGD_WAVE; k++) t += wsum[k]; baseSh = t; }
-    for (int w0 = threadIdx.x; w0 < nWG; w0 += SPF_WG * SP_ROWS) {
-        uint32_t e[SP_ROWS];
+    // Every (workgroup of k_split_local, this bucket) segment of pairs is walked: short ones by the thread that looked
+    // them up, long ones (>= 64 pairs: queries that come in sorted runs put a workgroup's 4096 queries into one or two
+    // buckets, and ONE thread walked them all -- 5 x the time of scattered queries) by the whole wave.
+    auto walk = [&](auto fn) {
+        for (int wb = 0; wb < nWG; wb += SPF_WG * SP_ROWS) {
+            const int w0 = wb + (int)threadIdx.x;
+            uint32_t e[SP_ROWS];
 #pragma unroll
-        for (int r = 0; r < SP_ROWS; r++) { const int w = w0 + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
+            for (int r = 0; r < SP_ROWS; r++) { const int w = w0 + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
 #pragma unroll
-        for (int r = 0; r < SP_ROWS; r++) {
-            const size_t at = (size_t)(w0 + r * SPF_WG) * SP_CAP + (e[r] & 0xFFFFu);
-            const int c = (int)(e[r] >> 16);
-            for (int j = 0; j < c; j++) atomicAdd(&cnt[reg[at + j].t - t0], 1u);
+            for (int r = 0; r < SP_ROWS; r++) {
+                const unsigned at = (unsigned)(w0 + r * SPF_WG) * (unsigned)SP_CAP + (e[r] & 0xFFFFu);   // (< 2^24 queries x 4 pairs: fits 32 bits)
+                const int c = (int)(e[r] >> 16);
+                const bool longSeg = c >= IGD_WAVE;
+                if (!longSeg) for (int j = 0; j < c; j++) fn(reg[(size_t)at + j]);
+                unsigned long long m = __ballot(longSeg);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const unsigned at2 = (unsigned)__builtin_amdgcn_readlane((int)at, src);
+                    const int c2 = __builtin_amdgcn_readlane(c, src);
+                    for (int j = lane; j < c2; j += IGD_WAVE) fn(reg[(size_t)at2 + j]);
+                }
+            }
         }
-    }
+    };
+    walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
     __syncthreads();
     {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
         const int per = F / SPF_WG, f0 = threadIdx.x * per;
@@ -955,21 +971,10 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
         }
     }
     __syncthreads();
-    for (int w0 = threadIdx.x; w0 < nWG; w0 += SPF_WG * SP_ROWS) {
-        uint32_t e[SP_ROWS];
-#pragma unroll
-        for (int r = 0; r < SP_ROWS; r++) { const int w = w0 + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
-#pragma unroll
-        for (int r = 0; r < SP_ROWS; r++) {
-            const size_t at = (size_t)(w0 + r * SPF_WG) * SP_CAP + (e[r] & 0xFFFFu);
-            const int c = (int)(e[r] >> 16);
-            for (int j = 0; j < c; j++) {
-                const SpTuple tu = reg[at + j];
-                const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
-                pairs[pos] = make_int2(tu.s, tu.e);
-            }
-        }
-    }
+    walk([&](const SpTuple &tu) {
+        const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
+        pairs[pos] = make_int2(tu.s, tu.e);
+    });
 }
 
 // step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol).  The
