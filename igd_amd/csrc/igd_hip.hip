@@ -3553,12 +3553,15 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
         const SortK K = make_sortk(db, a);
-        // sparse on average (fewer than 8 queries per tile): the lean build, whose pairwise path is not burdened with the rank
+        // sparse on average (fewer than 28 queries per tile): the lean build, whose pairwise path is not burdened with the rank
         // method's registers; tiles that are dense all the same go to heavy_sorted_body
         const int forceRank = db->forceRank;              // tests: 0 lean, 1 full (IGD_HIP_RANK, read at open)
         // ... and a batch that visits a fraction of the units (fewer queries than tiles) runs the full build too: it steps
         // through the visited units only (10^3 queries: 43.7 -> 13.4 us, 10^5: 44.3 -> 35.7 us; 3 x 10^5: 51.5 vs 53.5 us)
-        bool lean = forceRank >= 0 ? forceRank == 0 : ((int64_t)a.nq < 8ll * db->nT && (int64_t)a.nq >= (int64_t)db->nT);
+        // (the rank method starts at 32 queries per tile; below an average of ~28 the full build mostly runs its pairwise path,
+        // at 6 instead of 8 waves per SIMD -- measured lean / full, same box: 8 per tile 79.8 / 92.7 us, 16: 104 / 122,
+        // 21: 119 / 137, 32: 154 / 147)
+        bool lean = forceRank >= 0 ? forceRank == 0 : ((int64_t)a.nq < 28ll * db->nT && (int64_t)a.nq >= (int64_t)db->nT);
         // the lean build's 32-bit workgroup counters need no run-time guard when even a workgroup whose every unit is as
         // dense as that build lets one be stays below 2^32 (any database below ~10^9 records); otherwise: the full build
         const int64_t wavesLean = (int64_t)db->grid * (IGD_WG_LEAN / IGD_WAVE);
