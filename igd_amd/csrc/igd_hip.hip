@@ -205,6 +205,8 @@ struct igd_hip_db {
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
     int32_t *d_lpos;              // [nT+1] lpos[]: entries of its later block before query firstQ[t] (k_query_bounds)
+    int32_t *d_cov;               // coverage of long queries (IGD_COV_*): 2 x { diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2] }
+    bool covStale;                // a batch returned an error after its first kernel: clear d_cov before the next one
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
     int32_t *d_later;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
@@ -354,6 +356,19 @@ static_assert(IGD_LEAN_FIRST <= IGD_HEAVY_FIRST, "the list of heavy_sorted_body 
 #define WALK_BEYOND 0   // merge join: tiles n1+IGD_SHORT_TILES .. n2 of a long query
 #define WALK_FIRST 1    // tile n1 only: first-tile query with qe <= tile start (compact image cannot express it)
 #define WALK_ALL 2      // bucket path: every tile n1 .. n2 of a long query
+#define WALK_LAST 3     // merge join: tile n2 only of a long query (the tiles between are counted by coverage, see IGD_COV_*)
+// Long queries (more than IGD_SHORT_TILES tiles) in the merge join.  Tiles n1+1 .. n1+3 are reached by the query's
+// later[] entry like any other query's, the LAST tile n2 is walked exactly (WALK_LAST) -- and the tiles between, which the
+// query covers from end to end, by COVERAGE: every record that STARTS in such a tile (and passes the value filter) is
+// an overlap, whatever the query's ends are, so all that matters per tile is HOW MANY long queries cover it.
+// k_query_bounds adds +1 / -1 at the ends of each query's covered range to a difference array (two atomics per long
+// query, however long); the batch's last launch turns it into counts by a running sum and adds count x (records
+// starting in the tile) to hits[] (coverage_body): one atomic per record instead of one per (query, record) -- the
+// walk that did this before took 123 ms for 10^6 queries of 100-200 kb.  Two sets of arrays (batch parity): the last
+// launch of batch k+1 zeroes what batch k used.
+#define IGD_COV_SHIFT 10          // coarse level of the difference array: sums over 1024 tiles
+#define CTL_COV 16                // + (epoch & 1): epoch of the batch that put something into the parity's difference arrays
+#define IGD_CTL_WORDS 32
 
 // Sorted path, step 1.  key(i) = global tile id of query i's FIRST tile, clamped into the
 // tile range of its contig (unknown contigs go to the ends), so a batch ordered by
@@ -430,7 +445,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ later,
-                                                      int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
+                                                      int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised,
+                                                      int32_t *__restrict__ cov /* this batch's difference arrays (IGD_COV_*) */)
 {
     constexpr int NW = WGT / IGD_WAVE;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
@@ -597,7 +613,17 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const int g0 = cBase[v] + n1;
             const int T0 = (int)((unsigned)n1 * (unsigned)db.nbp);
             // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
-            if (n2 - n1 >= IGD_SHORT_TILES) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_BEYOND);
+            if (n2 - n1 >= IGD_SHORT_TILES) {
+                // a long query: its last tile is walked exactly, the tiles n1+4 .. n2-1 are covered from end to end (IGD_COV_*)
+                fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_LAST);
+                if (n2 - n1 > IGD_SHORT_TILES && !(rule == IGD_HIP_RULE_NEST && db.tileCnt[g0] == 0)) {   // (rule NEST: an empty first tile ends the query)
+                    const int ta = g0 + IGD_SHORT_TILES, tb = g0 + (n2 - n1);        // +1 on [ta, tb)
+                    atomicAdd(&cov[ta], 1); atomicAdd(&cov[tb], -1);
+                    int32_t *coarse = cov + db.nT + 2;
+                    if ((ta >> IGD_COV_SHIFT) != (tb >> IGD_COV_SHIFT)) { atomicAdd(&coarse[ta >> IGD_COV_SHIFT], 1); atomicAdd(&coarse[tb >> IGD_COV_SHIFT], -1); }
+                    ctl[CTL_COV + (epoch & 1)] = epoch;
+                }
+            }
             const bool needExact = packed && e0 <= T0;
             if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
             if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
@@ -1643,6 +1669,8 @@ struct SortArgs {
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
     int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to heavy_sorted_body
     int32_t *farList;            // [nUnits] units the lean build leaves to far_units_body (unit number | its tile is in heavyS << 31)
+    int32_t *covAll;             // both parities' coverage difference arrays (IGD_COV_*)
+    int tailHistOff;             // the last launch's per-workgroup u64 counters for exact walks and coverage: byte offset in its dynamic LDS (< 0: none)
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
@@ -2559,7 +2587,7 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
 // straight into the caller's global hits[] (and the batch total).  Rare by construction.
 template <bool USE_V>
 __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
-                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv)
+                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv, u64 *hist)
 {
     // ctlv: the batch's control words, word i in lane i (ONE load by the caller: the walk and the two skew valves
     // would otherwise each wait for their own, one after the other, to find out that there is nothing to do)
@@ -2582,6 +2610,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
         if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[base + n1] == 0) continue;   // :468
         int j0 = n1, j1 = n2 > n1 ? n2 : n1;
         if (kind == WALK_BEYOND) j0 = n1 + IGD_SHORT_TILES;
+        if (kind == WALK_LAST) j0 = j1;                  // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
         if (kind == WALK_FIRST) j1 = n1;
         for (int j = j0; j <= j1; j++) {
             const int t = base + j;
@@ -2606,12 +2635,69 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                     bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
                     if (USE_V) hit = hit & (va[r] >= a.v);
                     found += __popcll(__ballot(hit));
-                    if (hit) atomicAdd(&a.out[ix[r]], 1ull);
+                    if (hit) { if (hist) atomicAdd(&hist[ix[r]], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
                 }
             }
         }
     }
     if (a.total && lane == 0 && found) atomicAdd(a.total, found);
+}
+
+// coverage_body: the tiles that long queries of a merge-join batch cover from end to end (IGD_COV_*).  Every wave takes
+// a contiguous run of units, finds how many long queries cover its first tile (coarse sums + the fine differences of
+// the tile's block) and keeps that count running from tile to tile; a unit of a covered tile adds count x 1 to hits[]
+// for each of its records that starts in the tile (and passes the value filter).  The same launch zeroes the
+// difference arrays the batch BEFORE this one used (its own last launch is done with them).
+// (the reset is its own step: a batch that breaks its promise of order still has to clean up after the one before it)
+__device__ __forceinline__ void coverage_reset(const DbView &db, int32_t *__restrict__ covAll, int epoch, int gwave, int nwaves, int ctlv)
+{
+    const int other = (epoch & 1) ^ 1;
+    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + other) != epoch - 1) return;
+    const size_t covLen = (size_t)db.nT + 2 + ((size_t)db.nT >> IGD_COV_SHIFT) + 2;
+    int32_t *old = covAll + (size_t)other * covLen;
+    for (size_t k = (size_t)gwave * IGD_WAVE + (threadIdx.x & 63); k < covLen; k += (size_t)nwaves * IGD_WAVE) old[k] = 0;
+}
+
+template <bool USE_V>
+__device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, const int32_t *__restrict__ covAll, u64 *__restrict__ d_hits,
+                                              u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
+{
+    const int lane = threadIdx.x & 63;
+    const int par = a.epoch & 1;
+    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + par) != a.epoch) return;   // no long query in this batch
+    if (a.mode == 2 || __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch) return;   // the bucket path walks its long queries whole
+    const size_t covLen = (size_t)db.nT + 2 + ((size_t)db.nT >> IGD_COV_SHIFT) + 2;
+    const int32_t *diff = covAll + (size_t)par * covLen, *coarse = diff + db.nT + 2;
+    const int chunk = (db.nUnits + nwaves - 1) / nwaves;
+    const int u0 = gwave * chunk, u1 = u0 + chunk < db.nUnits ? u0 + chunk : db.nUnits;
+    if (u0 >= u1) return;
+    int cur = __builtin_amdgcn_readfirstlane(db.units[u0].tile);
+    int cv;                                              // long queries that cover tile `cur` from end to end
+    {
+        const int blk = cur >> IGD_COV_SHIFT;
+        int sum = 0;
+        for (int c = lane; c < blk; c += IGD_WAVE) sum += coarse[c];
+        for (int t = (blk << IGD_COV_SHIFT) + lane; t <= cur; t += IGD_WAVE) sum += diff[t];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        cv = __builtin_amdgcn_readfirstlane(sum);
+    }
+    u64 found = 0;
+    for (int u = u0; u < u1; u++) {
+        const UnitRegs ur = load_unit_regs(db.units + u);
+        const int tile = __builtin_amdgcn_readfirstlane(ur.tile), n = __builtin_amdgcn_readfirstlane(ur.n);
+        while (cur < tile) { cur++; cv += __builtin_amdgcn_readfirstlane(diff[cur]); }
+        if (cv <= 0) continue;
+        const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ur.offHi) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane(ur.offLo));
+        const int bd = db.tileBd[tile];                  // (a covered tile is never the first of its contig)
+        for (int i = lane; i < n; i += IGD_WAVE) {
+            bool in = db.start[off + i] >= bd;           // the copy of the record that counts (:510-511)
+            if (USE_V) in = in && db.value[off + i] >= a.v;
+            found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)cv;
+            if (in) { if (hist) atomicAdd(&hist[db.idx[off + i]], (u64)(unsigned)cv); else atomicAdd(&d_hits[db.idx[off + i]], (u64)(unsigned)cv); }
+        }
+    }
+    if (d_total && lane == 0 && found) atomicAdd(d_total, found);
 }
 
 // The batch's last launch.  Besides its own job it hosts the exact walks and the two skew valves (`valves` bit 0:
@@ -2624,7 +2710,29 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
                                            int ctlv /* the batch's control words, word i in lane i */)
 {
     const int lane = threadIdx.x & 63;
-    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv);
+    // what the exact walks and the coverage find is counted in the workgroup's LDS first (when the files fit): a batch of
+    // long queries makes one addition per (query, record) pair here
+    u64 *hist = nullptr;
+    if (K.a.tailHistOff >= 0) {
+        const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == wa.epoch;
+        const bool sortedPath = wa.mode == 1 || (wa.mode == 0 && !uns);
+        const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (wa.epoch & 1));
+        const bool cov = sortedPath && __builtin_amdgcn_readlane(ctlv, CTL_COV + (wa.epoch & 1)) == wa.epoch;
+        if (!(wa.mode == 1 && uns) && (nList > 0 || cov)) {          // (the same answer in every wave of the launch)
+            hist = (u64 *)(smem + K.a.tailHistOff);
+            for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) hist[f] = 0;
+            __syncthreads();
+        }
+    }
+    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
+    coverage_body<USE_V>(K.db, wa, K.a.covAll, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    if (hist) {
+        __syncthreads();
+        for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
+            const u64 c = hist[f];
+            if (c) atomicAdd(&d_hits[f], c);
+        }
+    }
     if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane, ctlv);
     if (valves & 2) {
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
@@ -2642,7 +2750,8 @@ __global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const i
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ctlv = (threadIdx.x & 63) < 16 ? a.ctl[threadIdx.x & 63] : 0;
+    const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? a.ctl[threadIdx.x & 63] : 0;
+    coverage_reset(K.db, K.a.covAll, a.epoch, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
     batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
 }
 
@@ -2658,7 +2767,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u64 red[4];
     // the batch's control words, word i in lane i: one load, in flight together with the slab rows
-    const int ctlv = (threadIdx.x & 63) < 16 ? ctl[threadIdx.x & 63] : 0;
+    const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? ctl[threadIdx.x & 63] : 0;
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
     if (f < nFiles) {
@@ -2677,6 +2786,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     }
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
+    coverage_reset(K.db, K.a.covAll, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
     if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
     if (s) atomicAdd(&hits[f], s);
     if (total) {
@@ -3025,7 +3135,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
-                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos,
+                    db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
                     db->d_spTable, db->d_spT, db->d_spBase};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
@@ -3231,7 +3341,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 80 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 96 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -3256,10 +3366,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_spill, (size_t)nT + 2, acct));
+    TRY(dalloc(&db->d_cov, 2 * ((size_t)nT + 2 + ((size_t)nT >> IGD_COV_SHIFT) + 2), acct));
     TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_pairPos, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_blockSums, (size_t)(nT / IGD_SCAN_TILE + 2), acct));
-    TRY(dalloc(&db->d_ctl, 16, acct));
+    TRY(dalloc(&db->d_ctl, IGD_CTL_WORDS, acct));
     TRY(dalloc(&db->d_hits, (size_t)d->nFiles + 1, acct));
     TRY(dalloc(&db->d_total, 4, acct));
     TRYHIP(hipMemcpy(db->d_tileOff, tileOff.data(), ((size_t)nT + 1) * 8, hipMemcpyHostToDevice));
@@ -3346,7 +3457,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             igd_hip_close(db);
             return ioerr ? IGD_HIP_ERR_ARG : IGD_HIP_ERR_DEVICE;
         }
-        TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
+        TRYHIP(hipMemset(db->d_ctl, 0, IGD_CTL_WORDS * 4));
         k_idx_range<<<256 * 8, 256, 0, db->stream>>>(db->d_idx, (int64_t)n, d->nFiles, db->d_ctl);
         int32_t bad = 0;
         TRYHIP(hipStreamSynchronize(db->stream));
@@ -3360,7 +3471,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     }
     TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
     TRYHIP(hipMemset(db->d_spill, 0, ((size_t)nT + 2) * 4));
-    TRYHIP(hipMemset(db->d_ctl, 0, 16 * 4));
+    TRYHIP(hipMemset(db->d_cov, 0, 2 * ((size_t)nT + 2 + ((size_t)nT >> IGD_COV_SHIFT) + 2) * 4));
+    TRYHIP(hipMemset(db->d_ctl, 0, IGD_CTL_WORDS * 4));
 
     // launch geometry of the scan kernel: computed above (db->grid, db->ldsBytes, db->ldsHits)
     if (db->ldsHits) {
@@ -3408,7 +3520,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             igd_hip_close(db);
             return rc2;
         }
-        hipError_t e = hipMemset(db->d_ctl, 0, 16 * 4);
+        hipError_t e = hipMemset(db->d_ctl, 0, IGD_CTL_WORDS * 4);
         // the chunk of padding behind the dataset numbers is READ (igd_scan_sorted lets the lanes past the last unit's end
         // name whatever datasets follow): it has to hold valid numbers
         if (e == hipSuccess) e = hipMemsetAsync(db->d_px + n, 0, IGD_CHUNK * sizeof(uint16_t), db->stream);
@@ -3419,7 +3531,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         int32_t fl = 0;
         if (e == hipSuccess) e = hipMemcpy(&fl, db->d_ctl, 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemset(db->d_ctl, 0, 16 * 4);
+        if (e == hipSuccess) e = hipMemset(db->d_ctl, 0, IGD_CTL_WORDS * 4);
         if (e != hipSuccess) {
             set_err("pack", e, __FILE__, __LINE__);
             igd_hip_close(db);
@@ -3530,7 +3642,7 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift; sa.lpos = db->d_lpos;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
-    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far;
+    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.covAll = db->d_cov; sa.tailHistOff = -1;
     sa.stamps = nullptr;
 #if IGD_EXP & 32
     {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -3608,9 +3720,12 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
     const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
     const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
-    if (db->epoch >= 0x3fffffff) {                       // the epoch stamps start over
+    if (db->epoch >= 0x3fffffff || db->covStale) {       // the epoch stamps start over (or a batch ended before its last launch)
         HIPCHK(hipMemsetAsync(db->d_spill, 0, ((size_t)db->nT + 2) * 4, st));
-        db->epoch = 0;
+        HIPCHK(hipMemsetAsync(db->d_cov, 0, 2 * ((size_t)db->nT + 2 + ((size_t)db->nT >> IGD_COV_SHIFT) + 2) * 4, st));
+        HIPCHK(hipMemsetAsync(db->d_ctl + CTL_COV, 0, 2 * 4, st));
+        if (!db->covStale) db->epoch = 0;
+        db->covStale = false;
     }
     db->epoch++;
     int slot = -1;
@@ -3637,7 +3752,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
     k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
-        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
+        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0, db->d_cov + (size_t)(db->epoch & 1) * ((size_t)db->nT + 2 + ((size_t)db->nT >> IGD_COV_SHIFT) + 2))
 #ifndef IGD_QB_WIDE
 #define IGD_QB_WIDE 1024
 #endif
@@ -3656,7 +3771,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         else
             rc = launch_bucket(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                                       mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
-        if (rc != IGD_HIP_OK) return rc;
+        if (rc != IGD_HIP_OK) { db->covStale = true; return rc; }
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
     ScanArgs a;
@@ -3668,7 +3783,9 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
                        (db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
     // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
-    const size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)IGD_WLDS_BYTES : 0;
+    size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)IGD_WLDS_BYTES : 0;
+    int tailHistOff = -1;                                // u64 counters for the exact walks and the coverage, when the files fit
+    if ((size_t)db->nFiles * 8 <= (size_t)48 * 1024) { tailHistOff = (int)tailLds; tailLds += (size_t)db->nFiles * 8; }
     if (db->ldsHits) {
         a.out = db->d_slab;
         const SortK K = make_sortk(db, a);
@@ -3678,7 +3795,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
             SortK Kt = K;
-            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES;
+            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES; Kt.a.tailHistOff = tailHistOff;
             dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
             const int rows32 = (mode != 2 && packed) ? db->epoch : 0;      // the merge join's kernel leaves 32-bit rows (CNT32)
             if (useV)
@@ -3698,7 +3815,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
             ScanArgs w = a;
             w.total = nullptr;
             SortK Kt = K;
-            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES;
+            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES; Kt.a.tailHistOff = tailHistOff;
             if (useV) k_exact_walk<true><<<1024, 256, tailLds, st>>>(Kt, w, db->d_fix, db->d_long, db->d_heavy, valves);
             else k_exact_walk<false><<<1024, 256, tailLds, st>>>(Kt, w, db->d_fix, db->d_long, db->d_heavy, valves);
         }
