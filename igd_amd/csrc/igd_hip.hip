@@ -183,6 +183,7 @@ struct DbView {
     const int32_t *ctgBase;                     // [nCtg] global tile id of the contig's tile 0
     const int32_t *ctgNTile;                    // [nCtg]
     const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
+    int32_t *cov;                               // workspace: 4 sets of coverage difference arrays (IGD_COV_*)
 };
 
 struct igd_hip_db {
@@ -205,7 +206,7 @@ struct igd_hip_db {
     int64_t resident;
     int32_t *d_firstQ, *d_pairN;  // [nT+1] first query of each tile (sorted path); pair counts copy
     int32_t *d_lpos;              // [nT+1] lpos[]: entries of its later block before query firstQ[t] (k_query_bounds)
-    int32_t *d_cov;               // coverage of long queries (IGD_COV_*): 2 x { diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2] }
+    int32_t *d_cov;               // coverage of long queries (IGD_COV_*): 4 sets (path x batch parity) of { diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2] }
     bool covStale;                // a batch returned an error after its first kernel: clear d_cov before the next one
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
     int32_t *d_later;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
@@ -367,7 +368,8 @@ static_assert(IGD_LEAN_FIRST <= IGD_HEAVY_FIRST, "the list of heavy_sorted_body 
 // walk that did this before took 123 ms for 10^6 queries of 100-200 kb.  Two sets of arrays (batch parity): the last
 // launch of batch k+1 zeroes what batch k used.
 #define IGD_COV_SHIFT 10          // coarse level of the difference array: sums over 1024 tiles
-#define CTL_COV 16                // + (epoch & 1): epoch of the batch that put something into the parity's difference arrays
+#define CTL_COV 16         // + set * 2 + parity (set 0: merge join, 1: bucket path): the epoch whose long queries wrote the set
+#define IGD_COV_LEN(nT_) ((size_t)(nT_) + 2 + ((size_t)(nT_) >> IGD_COV_SHIFT) + 2)   // one set: diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2]                // + (epoch & 1): epoch of the batch that put something into the parity's difference arrays
 #define IGD_CTL_WORDS 32
 
 // Sorted path, step 1.  key(i) = global tile id of query i's FIRST tile, clamped into the
@@ -437,6 +439,16 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 // compiled without the other cases' branches (a flat load picking between LDS and global tables, a division), and with a
 // short path for the waves all of whose queries lie in ONE contig, in range and in order (every wave of a large sorted
 // batch but a few): keys and words from the wave's scalar contig base, nothing looked up or clamped per query.
+// One long query covers tiles ta .. tb-1 (global tile numbers) from end to end: +1 / -1 in the batch's difference arrays
+// (fine, and per block of 2^IGD_COV_SHIFT tiles), to be summed up by coverage_body in the batch's last launch.
+__device__ __forceinline__ void cover_tiles(const DbView &db, int32_t *__restrict__ ctl, int set, int epoch, int ta, int tb)
+{
+    int32_t *diff = db.cov + (size_t)(set * 2 + (epoch & 1)) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
+    atomicAdd(&diff[ta], 1); atomicAdd(&diff[tb], -1);
+    if ((ta >> IGD_COV_SHIFT) != (tb >> IGD_COV_SHIFT)) { atomicAdd(&coarse[ta >> IGD_COV_SHIFT], 1); atomicAdd(&coarse[tb >> IGD_COV_SHIFT], -1); }
+    ctl[CTL_COV + set * 2 + (epoch & 1)] = epoch;
+}
+
 template <int VEC, bool FAST, int WGT>
 __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
@@ -445,8 +457,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                                                       int2 *__restrict__ fix, int32_t *__restrict__ ctl, int epoch,
                                                       u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
                                                       int32_t *__restrict__ qw0, int32_t *__restrict__ later,
-                                                      int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised,
-                                                      int32_t *__restrict__ cov /* this batch's difference arrays (IGD_COV_*) */)
+                                                      int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
     constexpr int NW = WGT / IGD_WAVE;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
@@ -617,11 +628,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                 // a long query: its last tile is walked exactly, the tiles n1+4 .. n2-1 are covered from end to end (IGD_COV_*)
                 fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_LAST);
                 if (n2 - n1 > IGD_SHORT_TILES && !(rule == IGD_HIP_RULE_NEST && db.tileCnt[g0] == 0)) {   // (rule NEST: an empty first tile ends the query)
-                    const int ta = g0 + IGD_SHORT_TILES, tb = g0 + (n2 - n1);        // +1 on [ta, tb)
-                    atomicAdd(&cov[ta], 1); atomicAdd(&cov[tb], -1);
-                    int32_t *coarse = cov + db.nT + 2;
-                    if ((ta >> IGD_COV_SHIFT) != (tb >> IGD_COV_SHIFT)) { atomicAdd(&coarse[ta >> IGD_COV_SHIFT], 1); atomicAdd(&coarse[tb >> IGD_COV_SHIFT], -1); }
-                    ctl[CTL_COV + (epoch & 1)] = epoch;
+                    cover_tiles(db, ctl, 0, epoch, g0 + IGD_SHORT_TILES, g0 + (n2 - n1));
                 }
             }
             const bool needExact = packed && e0 <= T0;
@@ -784,6 +791,7 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
     const int kind = walk_kind(db, qs[i], qe[i], ntl, packed);
     if (kind >= 0) {
         longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
+        if (kind == WALK_ALL) cover_tiles(db, ctl, 1, epoch, gt0 + 1, gt0 + ntl - 1);   // first and last tile by the walk, the rest covered
         return;
     }
     for (int k = 0; k < ntl; k++)
@@ -847,8 +855,10 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
             int g, n;
             if (query_span(db, ichr[i], s, e, rule, g, n)) {
                 const int kind = walk_kind(db, s, e, n, packed);
-                if (kind >= 0) longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
-                else {
+                if (kind >= 0) {
+                    longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
+                    if (kind == WALK_ALL) cover_tiles(db, ctl, 1, epoch, g + 1, g + n - 1);   // first and last tile by the walk, the rest covered
+                } else {
                     int live = 0;                         // bit j: tile g+j is not empty
                     for (int j = 0; j < n; j++) live |= (db.tileCnt[g + j] > 0) << j;
                     gt0[k] = g; ntl[k] = live; s_[k] = s; e_[k] = e;
@@ -1669,7 +1679,6 @@ struct SortArgs {
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
     int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to heavy_sorted_body
     int32_t *farList;            // [nUnits] units the lean build leaves to far_units_body (unit number | its tile is in heavyS << 31)
-    int32_t *covAll;             // both parities' coverage difference arrays (IGD_COV_*)
     int tailHistOff;             // the last launch's per-workgroup u64 counters for exact walks and coverage: byte offset in its dynamic LDS (< 0: none)
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
@@ -2598,44 +2607,71 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
     const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1));
     const int lane = threadIdx.x & 63;
     u64 found = 0;
-    for (int li = gwave; li < nList; li += nwaves) {
-        const int2 ent = list[li];
-        const int q = ent.x, kind = ent.y;
-        const int qs = a.q_qs[q], qe = a.q_qe[q], cc = a.q_ichr[q];
-        const int n1 = tile_of(db, qs);
-        int n2 = tile_of(db, (int)((unsigned)qe - 1u));
-        const int mT = db.ctgNTile[cc] - 1;
-        if (n2 > mT) n2 = mT;
-        const int base = db.ctgBase[cc];
-        if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[base + n1] == 0) continue;   // :468
-        int j0 = n1, j1 = n2 > n1 ? n2 : n1;
-        if (kind == WALK_BEYOND) j0 = n1 + IGD_SHORT_TILES;
-        if (kind == WALK_LAST) j0 = j1;                  // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
-        if (kind == WALK_FIRST) j1 = n1;
-        for (int j = j0; j <= j1; j++) {
-            const int t = base + j;
-            const int tcnt = db.tileCnt[t];
-            if (tcnt == 0) continue;
-            const int lob = (j == n1) ? INT_MIN : db.tileBd[t];
-            const int64_t toff = db.tileOff[t];
-            for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
-                int st[IGD_SLOTS], en[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];
-#pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) {
-                    const int i = rec0 + r * IGD_WAVE + lane;
-                    const bool ok = i < tcnt;
-                    st[r] = ok ? db.start[toff + i] : INT_MAX;
-                    en[r] = ok ? db.end[toff + i] : INT_MIN;
-                    ix[r] = ok ? db.idx[toff + i] : 0;
-                    if (USE_V) va[r] = ok ? db.value[toff + i] : INT_MIN;
+    // a wave takes `per` entries of the list at a time (one each while the list is shorter than the launch has waves): every
+    // lane reads one entry's query and contig first, so that the chain of dependent loads is paid once per group, not per query
+    int per = (nList + nwaves - 1) / nwaves;
+    per = per > IGD_WAVE ? IGD_WAVE : per;
+    for (int l0 = gwave * per; l0 < nList; l0 += nwaves * per) {
+        const int cnt = nList - l0 < per ? nList - l0 : per;
+        int vq = 0, vkind = -1, vqs = 0, vqe = 0, vn1 = 0, vj1 = -1, vbase = 0, vcnt = 0, voffLo = 0, voffHi = 0, vlob = 0;
+        if (lane < cnt) {
+            const int2 ent = list[l0 + lane];
+            vq = ent.x; vkind = ent.y;
+            vqs = a.q_qs[vq]; vqe = a.q_qe[vq];
+            const int cc = a.q_ichr[vq];
+            vn1 = tile_of(db, vqs);
+            int n2 = tile_of(db, (int)((unsigned)vqe - 1u));
+            const int mT = db.ctgNTile[cc] - 1;
+            if (n2 > mT) n2 = mT;
+            vbase = db.ctgBase[cc];
+            vj1 = n2 > vn1 ? n2 : vn1;
+            if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[vbase + vn1] == 0) vj1 = -1;   // :468 -- nothing to walk
+            if (vj1 >= 0) {                              // ... and the first tile of the walk (the only one of WALK_LAST and WALK_FIRST)
+                const int jf = vkind == WALK_BEYOND ? vn1 + IGD_SHORT_TILES : vkind == WALK_LAST ? vj1 : vn1;
+                if (jf <= vj1) {
+                    vcnt = db.tileCnt[vbase + jf];
+                    const int64_t o = db.tileOff[vbase + jf];
+                    voffLo = (int)o; voffHi = (int)(o >> 32);
+                    vlob = db.tileBd[vbase + jf];
                 }
-                if (__builtin_amdgcn_readfirstlane(st[0]) >= qe) break;    // sorted: nothing further
+            }
+        }
+        for (int e = 0; e < cnt; e++) {
+            const int kind = __builtin_amdgcn_readlane(vkind, e), qs = __builtin_amdgcn_readlane(vqs, e), qe = __builtin_amdgcn_readlane(vqe, e);
+            const int n1 = __builtin_amdgcn_readlane(vn1, e), base = __builtin_amdgcn_readlane(vbase, e);
+            int j1 = __builtin_amdgcn_readlane(vj1, e);
+            if (j1 < 0) continue;
+            int j0 = n1;
+            if (kind == WALK_BEYOND) j0 = n1 + IGD_SHORT_TILES;
+            if (kind == WALK_LAST) j0 = j1;              // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
+            if (kind == WALK_FIRST) j1 = n1;
+            for (int j = j0; j <= j1; j = (kind == WALK_ALL && j < j1) ? j1 : j + 1) {   // (WALK_ALL: first and last tile, coverage_body has the rest)
+                const int t = base + j;
+                const int tcnt = j == j0 ? __builtin_amdgcn_readlane(vcnt, e) : db.tileCnt[t];
+                if (tcnt == 0) continue;
+                const int lob = (j == n1) ? INT_MIN : j == j0 ? __builtin_amdgcn_readlane(vlob, e) : db.tileBd[t];
+                const int64_t toff = j == j0 ? (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(voffHi, e) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane(voffLo, e))
+                                             : db.tileOff[t];
+                for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
+                    int st[IGD_SLOTS], en[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) {
-                    bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
-                    if (USE_V) hit = hit & (va[r] >= a.v);
-                    found += __popcll(__ballot(hit));
-                    if (hit) { if (hist) atomicAdd(&hist[ix[r]], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int i = rec0 + r * IGD_WAVE + lane;
+                        const bool ok = i < tcnt;
+                        st[r] = ok ? db.start[toff + i] : INT_MAX;
+                        en[r] = ok ? db.end[toff + i] : INT_MIN;
+                        ix[r] = ok ? db.idx[toff + i] : 0;
+                        if (USE_V) va[r] = ok ? db.value[toff + i] : INT_MIN;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(st[0]) >= qe) break;    // sorted: nothing further
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
+                        if (USE_V) hit = hit & (va[r] >= a.v);
+                        found += __popcll(__ballot(hit));
+                        if (hit) { if (hist) atomicAdd(&hist[ix[r]], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
+                    }
                 }
             }
         }
@@ -2649,25 +2685,27 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
 // for each of its records that starts in the tile (and passes the value filter).  The same launch zeroes the
 // difference arrays the batch BEFORE this one used (its own last launch is done with them).
 // (the reset is its own step: a batch that breaks its promise of order still has to clean up after the one before it)
-__device__ __forceinline__ void coverage_reset(const DbView &db, int32_t *__restrict__ covAll, int epoch, int gwave, int nwaves, int ctlv)
+__device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int gwave, int nwaves, int ctlv)
 {
     const int other = (epoch & 1) ^ 1;
-    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + other) != epoch - 1) return;
-    const size_t covLen = (size_t)db.nT + 2 + ((size_t)db.nT >> IGD_COV_SHIFT) + 2;
-    int32_t *old = covAll + (size_t)other * covLen;
-    for (size_t k = (size_t)gwave * IGD_WAVE + (threadIdx.x & 63); k < covLen; k += (size_t)nwaves * IGD_WAVE) old[k] = 0;
+    const size_t covLen = IGD_COV_LEN(db.nT);
+    for (int set = 0; set < 2; set++) {
+        if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + other) != epoch - 1) continue;
+        int32_t *old = db.cov + (size_t)(set * 2 + other) * covLen;
+        for (size_t k = (size_t)gwave * IGD_WAVE + (threadIdx.x & 63); k < covLen; k += (size_t)nwaves * IGD_WAVE) old[k] = 0;
+    }
 }
 
 template <bool USE_V>
-__device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, const int32_t *__restrict__ covAll, u64 *__restrict__ d_hits,
+__device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
                                               u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
 {
     const int lane = threadIdx.x & 63;
-    const int par = a.epoch & 1;
-    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + par) != a.epoch) return;   // no long query in this batch
-    if (a.mode == 2 || __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch) return;   // the bucket path walks its long queries whole
-    const size_t covLen = (size_t)db.nT + 2 + ((size_t)db.nT >> IGD_COV_SHIFT) + 2;
-    const int32_t *diff = covAll + (size_t)par * covLen, *coarse = diff + db.nT + 2;
+    const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch;
+    if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
+    const int set = (a.mode == 1 || (a.mode == 0 && !uns)) ? 0 : 1, par = a.epoch & 1;   // merge join / bucket path
+    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + par) != a.epoch) return;     // no long query in this batch
+    const int32_t *diff = db.cov + (size_t)(set * 2 + par) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
     const int chunk = (db.nUnits + nwaves - 1) / nwaves;
     const int u0 = gwave * chunk, u1 = u0 + chunk < db.nUnits ? u0 + chunk : db.nUnits;
     if (u0 >= u1) return;
@@ -2690,11 +2728,20 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
         const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ur.offHi) << 32) |
                                       (unsigned)__builtin_amdgcn_readfirstlane(ur.offLo));
         const int bd = db.tileBd[tile];                  // (a covered tile is never the first of its contig)
-        for (int i = lane; i < n; i += IGD_WAVE) {
-            bool in = db.start[off + i] >= bd;           // the copy of the record that counts (:510-511)
-            if (USE_V) in = in && db.value[off + i] >= a.v;
+        int st[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];   // the whole unit's loads in flight together
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const int i = r * IGD_WAVE + lane;
+            st[r] = i < n ? db.start[off + i] : INT_MIN;
+            ix[r] = i < n ? db.idx[off + i] : 0;
+            if (USE_V) va[r] = i < n ? db.value[off + i] : INT_MIN;
+        }
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            bool in = st[r] >= bd;                       // the copy of the record that counts (:510-511)
+            if (USE_V) in = in && va[r] >= a.v;
             found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)cv;
-            if (in) { if (hist) atomicAdd(&hist[db.idx[off + i]], (u64)(unsigned)cv); else atomicAdd(&d_hits[db.idx[off + i]], (u64)(unsigned)cv); }
+            if (in) { if (hist) atomicAdd(&hist[ix[r]], (u64)(unsigned)cv); else atomicAdd(&d_hits[ix[r]], (u64)(unsigned)cv); }
         }
     }
     if (d_total && lane == 0 && found) atomicAdd(d_total, found);
@@ -2717,7 +2764,7 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
         const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == wa.epoch;
         const bool sortedPath = wa.mode == 1 || (wa.mode == 0 && !uns);
         const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (wa.epoch & 1));
-        const bool cov = sortedPath && __builtin_amdgcn_readlane(ctlv, CTL_COV + (wa.epoch & 1)) == wa.epoch;
+        const bool cov = __builtin_amdgcn_readlane(ctlv, CTL_COV + (sortedPath ? 0 : 2) + (wa.epoch & 1)) == wa.epoch;
         if (!(wa.mode == 1 && uns) && (nList > 0 || cov)) {          // (the same answer in every wave of the launch)
             hist = (u64 *)(smem + K.a.tailHistOff);
             for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) hist[f] = 0;
@@ -2725,7 +2772,7 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
         }
     }
     exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
-    coverage_body<USE_V>(K.db, wa, K.a.covAll, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
     if (hist) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
@@ -2751,7 +2798,7 @@ __global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const i
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? a.ctl[threadIdx.x & 63] : 0;
-    coverage_reset(K.db, K.a.covAll, a.epoch, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
+    coverage_reset(K.db, a.epoch, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
     batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
 }
 
@@ -2786,7 +2833,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     }
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
-    coverage_reset(K.db, K.a.covAll, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
+    coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
     if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
     if (s) atomicAdd(&hits[f], s);
     if (total) {
@@ -3341,7 +3388,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 96 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 112 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -3366,7 +3413,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_spill, (size_t)nT + 2, acct));
-    TRY(dalloc(&db->d_cov, 2 * ((size_t)nT + 2 + ((size_t)nT >> IGD_COV_SHIFT) + 2), acct));
+    TRY(dalloc(&db->d_cov, 4 * IGD_COV_LEN(nT), acct));
     TRY(dalloc(&db->d_pairCnt, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_pairPos, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_blockSums, (size_t)(nT / IGD_SCAN_TILE + 2), acct));
@@ -3471,7 +3518,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     }
     TRYHIP(hipMemset(db->d_pairCnt, 0, ((size_t)nT + 1) * 4));
     TRYHIP(hipMemset(db->d_spill, 0, ((size_t)nT + 2) * 4));
-    TRYHIP(hipMemset(db->d_cov, 0, 2 * ((size_t)nT + 2 + ((size_t)nT >> IGD_COV_SHIFT) + 2) * 4));
+    TRYHIP(hipMemset(db->d_cov, 0, 4 * IGD_COV_LEN(nT) * 4));
     TRYHIP(hipMemset(db->d_ctl, 0, IGD_CTL_WORDS * 4));
 
     // launch geometry of the scan kernel: computed above (db->grid, db->ldsBytes, db->ldsHits)
@@ -3506,7 +3553,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
     v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
-    v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile; v.tileUnit0 = db->d_tileUnit0;
+    v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile; v.tileUnit0 = db->d_tileUnit0; v.cov = db->d_cov;
     OPEN_PHASE("idx check, slab");
     // compact image (see k_pack_units): needs tile-relative offsets and idx to fit 16 bits
     db->packed = db->nbp <= 32768 && db->nFiles <= 65536 && db->nRec > 0 && !getenv("IGD_HIP_NO_PACK");
@@ -3642,7 +3689,7 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift; sa.lpos = db->d_lpos;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
-    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.covAll = db->d_cov; sa.tailHistOff = -1;
+    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.tailHistOff = -1;
     sa.stamps = nullptr;
 #if IGD_EXP & 32
     {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -3722,8 +3769,8 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
     if (db->epoch >= 0x3fffffff || db->covStale) {       // the epoch stamps start over (or a batch ended before its last launch)
         HIPCHK(hipMemsetAsync(db->d_spill, 0, ((size_t)db->nT + 2) * 4, st));
-        HIPCHK(hipMemsetAsync(db->d_cov, 0, 2 * ((size_t)db->nT + 2 + ((size_t)db->nT >> IGD_COV_SHIFT) + 2) * 4, st));
-        HIPCHK(hipMemsetAsync(db->d_ctl + CTL_COV, 0, 2 * 4, st));
+        HIPCHK(hipMemsetAsync(db->d_cov, 0, 4 * IGD_COV_LEN(db->nT) * 4, st));
+        HIPCHK(hipMemsetAsync(db->d_ctl + CTL_COV, 0, 4 * 4, st));
         if (!db->covStale) db->epoch = 0;
         db->covStale = false;
     }
@@ -3752,7 +3799,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
     k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
-        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0, db->d_cov + (size_t)(db->epoch & 1) * ((size_t)db->nT + 2 + ((size_t)db->nT >> IGD_COV_SHIFT) + 2))
+        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
 #ifndef IGD_QB_WIDE
 #define IGD_QB_WIDE 1024
 #endif
