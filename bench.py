@@ -478,6 +478,10 @@ def extra_configs(db, dev, stream, args, box):
         ps = np.sort((50000000 + rng.integers(0, 16384 * span, Q)).astype(np.int32))
         cases.append(("stress: 10^6 position-sorted queries inside %d tile%s of chr1 (skew valve)" % (span, "" if span == 1 else "s"),
                       (np.zeros(Q, np.int32), ps, (ps + rng.integers(100, 2000, Q)).astype(np.int32)), 0, 1, 10, None))
+    # ... queries of 6 .. 13 tiles each (difference arrays over the tiles they cover whole + an exact walk of the last tile) ...
+    cases.append(("stress: 10^5 position-sorted queries of 100-200 kbp (6-13 tiles each: 2.4e8 overlaps per step)",
+                  synth.make_queries(100000, seed=7, genome=synth.HG38, min_len=100000, max_len=200000, sorted_=True), 0, 1, 10,
+                  "long_sorted_q100000_v0"))
     dbs = [db] * len(cases)
     # ... and a clustered database (half of the intervals around 2000 hot spots: tiles of 10^3 .. 10^4 records, many chunks each)
     cl = None

@@ -38,9 +38,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 10 and not any("error" in e for e in x), x
+        assert len(x) == 11 and not any("error" in e for e in x), x
         assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
-        assert sum(e["workload"].startswith("stress:") for e in x) == 3
+        assert sum(e["workload"].startswith("stress:") for e in x) == 4
         assert r["cold"]["kernel_ms"] > 0 and 0 < r["cold"]["frac"] <= 1.0
         e2e = j["cli_end_to_end"]
         assert e2e["q_seconds"] > 0 and e2e["q_v500_seconds"] > 0 and e2e["q_f_seconds"] > 0 and e2e["q_total_matches_gpu"] is True

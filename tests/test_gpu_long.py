@@ -89,10 +89,15 @@ def test_long_queries_roadmap_scale():
         got, gtot = db.search(ichr[::20], qs[::20], qe[::20], 0, flags=1)
         assert gtot == wtot
         np.testing.assert_array_equal(got, want)
-        # the full batch: merge join == bucket path (which walks the long queries whole)
-        a, ta = db.search(ichr, qs, qe, 0, flags=1)
-        b, tb = db.search(ichr, qs, qe, 0, flags=2)
-        assert ta == tb
-        np.testing.assert_array_equal(a, b)
+        # the full batch, every mode, against the oracle's committed counts of it (tools/make_bench_checksums.py)
+        import json
+        gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_checksums.json")))["workloads"]
+        w = np.arange(1, db.nfiles + 1, dtype=np.uint64)
+        for v in (0, 500):
+            g = gold["long_sorted_q100000_v%d" % v]
+            for flags in (1, 0, 2):
+                h, tot = db.search(ichr, qs, qe, v, flags=flags)
+                assert tot == g["total"] and int(h.sum()) == tot, (v, flags)
+                assert int((h.astype(np.uint64) * w).sum() & np.uint64((1 << 63) - 1)) == g["checksum"], (v, flags)
     finally:
         db.close(); orc.close()

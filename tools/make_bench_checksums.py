@@ -3,7 +3,7 @@
 synthetic .igd, computed by the CPU ORACLE (oracle/, pinned to the reference) -- total and the position-weighted
 checksum bench.py prints (sum hits[i] * (i + 1) mod 2^63).  bench.py and tests/test_gpu_stress.py compare the GPU's
 counts of the same workloads with these numbers.  Runs without a GPU (about two minutes, 1 GB under /tmp/igdb).
-    python tools/make_bench_checksums.py"""
+    python tools/make_bench_checksums.py [--only NAME ...]      (--only: recompute these workloads, keep the others)"""
 import json
 import os
 import sys
@@ -37,7 +37,14 @@ def main():
         "config4_slab0_of_8": (synth.make_queries_slab(8 * PER_GPU, 0, PER_GPU, seed=7, genome=synth.HG38), (0, 500)),
         "config4_slab0_of_2": (synth.make_queries_slab(2 * PER_GPU, 0, PER_GPU, seed=7, genome=synth.HG38), (0,)),
         "config4_slab1_of_2": (synth.make_queries_slab(2 * PER_GPU, PER_GPU, 2 * PER_GPU, seed=7, genome=synth.HG38), (0,)),
+        # queries of 6 .. 13 tiles: coverage difference arrays + exact walk of the last tile
+        "long_sorted_q100000": (synth.make_queries(100000, seed=7, genome=synth.HG38, min_len=100000, max_len=200000, sorted_=True), (0, 500)),
     }
+    dst = os.path.join(ROOT, "tests", "golden", "bench_checksums.json")
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
+    if only:
+        out = json.load(open(dst))
+        work = {k: w for k, w in work.items() if k in only}
     for name, ((ichr, qs, qe), vs) in work.items():
         for v in vs:
             h, tot = orc.search(ichr, qs, qe, v)
@@ -45,7 +52,6 @@ def main():
             out["workloads"]["%s_v%d" % (name, v)] = {"queries": len(qs), "v": v, "total": int(tot), "checksum": checksum(h)}
             print(name, v, tot, flush=True)
     orc.close()
-    dst = os.path.join(ROOT, "tests", "golden", "bench_checksums.json")
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     print("wrote", dst)
 
