@@ -76,6 +76,9 @@
 #define IGD_SCAN_ITEMS 16                    // elements per thread in the tile scan
 #define IGD_SCAN_BLOCK 256
 #define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
+#ifndef IGD_TAIL_WGS
+#define IGD_TAIL_WGS 2048                    // workgroups (256 threads) of the batch's last launch
+#endif
 #ifndef IGD_REDUCE_GROUPS
 #define IGD_REDUCE_GROUPS 64                 // (32-bit slab rows: 6.2 us with 128 groups, 5.4 with 64, 6.4 with 32, 10.1 with 16)
 #endif
@@ -2696,6 +2699,7 @@ __device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int 
     }
 }
 
+#define IGD_COV_CHUNK 32      // units a wave takes at a time (strided over the launch's waves: long queries may all lie in one region)
 template <bool USE_V>
 __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
                                               u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
@@ -2706,42 +2710,62 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
     const int set = (a.mode == 1 || (a.mode == 0 && !uns)) ? 0 : 1, par = a.epoch & 1;   // merge join / bucket path
     if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + par) != a.epoch) return;     // no long query in this batch
     const int32_t *diff = db.cov + (size_t)(set * 2 + par) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
-    const int chunk = (db.nUnits + nwaves - 1) / nwaves;
-    const int u0 = gwave * chunk, u1 = u0 + chunk < db.nUnits ? u0 + chunk : db.nUnits;
-    if (u0 >= u1) return;
-    int cur = __builtin_amdgcn_readfirstlane(db.units[u0].tile);
-    int cv;                                              // long queries that cover tile `cur` from end to end
-    {
-        const int blk = cur >> IGD_COV_SHIFT;
-        int sum = 0;
-        for (int c = lane; c < blk; c += IGD_WAVE) sum += coarse[c];
-        for (int t = (blk << IGD_COV_SHIFT) + lane; t <= cur; t += IGD_WAVE) sum += diff[t];
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        cv = __builtin_amdgcn_readfirstlane(sum);
-    }
     u64 found = 0;
-    for (int u = u0; u < u1; u++) {
-        const UnitRegs ur = load_unit_regs(db.units + u);
-        const int tile = __builtin_amdgcn_readfirstlane(ur.tile), n = __builtin_amdgcn_readfirstlane(ur.n);
-        while (cur < tile) { cur++; cv += __builtin_amdgcn_readfirstlane(diff[cur]); }
-        if (cv <= 0) continue;
-        const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ur.offHi) << 32) |
-                                      (unsigned)__builtin_amdgcn_readfirstlane(ur.offLo));
+    for (int u0 = gwave * IGD_COV_CHUNK; u0 < db.nUnits; u0 += nwaves * IGD_COV_CHUNK) {
+        const int cnt = db.nUnits - u0 < IGD_COV_CHUNK ? db.nUnits - u0 : IGD_COV_CHUNK;
+        // one unit per lane: its tile, and the number of long queries that cover that tile from end to end = (coarse +
+        // fine prefix at the chunk's first tile) + the differences of the tiles since -- no chain of loads from unit to unit
+        UnitRegs ur = load_unit_regs(db.units + u0 + (lane < cnt ? lane : 0));
+        const int tile = ur.tile, tile0 = __builtin_amdgcn_readfirstlane(tile);
         const int bd = db.tileBd[tile];                  // (a covered tile is never the first of its contig)
-        int st[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];   // the whole unit's loads in flight together
-#pragma unroll
-        for (int r = 0; r < IGD_SLOTS; r++) {
-            const int i = r * IGD_WAVE + lane;
-            st[r] = i < n ? db.start[off + i] : INT_MIN;
-            ix[r] = i < n ? db.idx[off + i] : 0;
-            if (USE_V) va[r] = i < n ? db.value[off + i] : INT_MIN;
+        int p0;
+        {
+            const int blk = tile0 >> IGD_COV_SHIFT;
+            int sum = 0;
+            for (int c = lane; c < blk; c += IGD_WAVE) sum += coarse[c];
+            for (int t = (blk << IGD_COV_SHIFT) + lane; t <= tile0; t += IGD_WAVE) sum += diff[t];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            p0 = sum;
         }
+        const int before = __shfl_up(tile, 1);
+        const int gap = (lane == 0 || lane >= cnt) ? 0 : tile - before;   // tiles since the unit before (0: same tile; > 1: empty tiles between)
+        int d = 0;
+        if (gap <= 4) {
 #pragma unroll
-        for (int r = 0; r < IGD_SLOTS; r++) {
-            bool in = st[r] >= bd;                       // the copy of the record that counts (:510-511)
-            if (USE_V) in = in && va[r] >= a.v;
-            found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)cv;
-            if (in) { if (hist) atomicAdd(&hist[ix[r]], (u64)(unsigned)cv); else atomicAdd(&d_hits[ix[r]], (u64)(unsigned)cv); }
+            for (int k = 0; k < 4; k++) d += k < gap ? diff[tile - k] : 0;
+        }
+        for (unsigned long long m = __ballot(gap > 4); m; m &= m - 1) {   // a run of empty tiles (a centromere): summed by the whole wave
+            const int src = __builtin_ctzll(m);
+            const int hi = __builtin_amdgcn_readlane(tile, src), g = __builtin_amdgcn_readlane(gap, src);
+            int sum = 0;
+            for (int t = hi - g + 1 + lane; t <= hi; t += IGD_WAVE) sum += diff[t];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == src) d = sum;
+        }
+        const int since = wave_inclusive_sum(d);          // (every lane takes part)
+        const int cv = lane < cnt ? p0 + since : 0;
+        if (__ballot(cv > 0) == 0) continue;             // nothing of this chunk is covered
+        for (int e = 0; e < cnt; e++) {
+            const int c = __builtin_amdgcn_readlane(cv, e);
+            if (c <= 0) continue;
+            const int n = __builtin_amdgcn_readlane(ur.n, e), lob = __builtin_amdgcn_readlane(bd, e);
+            const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ur.offHi, e) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane(ur.offLo, e));
+            int st[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];   // the whole unit's loads in flight together
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                const int i = r * IGD_WAVE + lane;
+                st[r] = i < n ? db.start[off + i] : INT_MIN;
+                ix[r] = i < n ? db.idx[off + i] : 0;
+                if (USE_V) va[r] = i < n ? db.value[off + i] : INT_MIN;
+            }
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                bool in = st[r] >= lob;                  // the copy of the record that counts (:510-511)
+                if (USE_V) in = in && va[r] >= a.v;
+                found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)c;
+                if (in) { if (hist) atomicAdd(&hist[ix[r]], (u64)(unsigned)c); else atomicAdd(&d_hits[ix[r]], (u64)(unsigned)c); }
+            }
         }
     }
     if (d_total && lane == 0 && found) atomicAdd(d_total, found);
@@ -2817,7 +2841,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? ctl[threadIdx.x & 63] : 0;
     int f = blockIdx.x * 256 + threadIdx.x;
     u64 s = 0;
-    if (f < nFiles) {
+    if (f < nFiles && blockIdx.y < IGD_REDUCE_GROUPS) {  // (the workgroups beyond are there for the batch's tail only, see the launch)
         // (both kinds of rows are read before the control words say which kind this batch left: the loads are in flight
         // together, and a row of either kind lies inside the slab)
         u64 s64 = 0;
@@ -3843,7 +3867,11 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
             w.out = (u64 *)d_hits;
             SortK Kt = K;
             Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES; Kt.a.tailHistOff = tailHistOff;
-            dim3 rg((db->nFiles + 255) / 256, IGD_REDUCE_GROUPS);
+            // IGD_REDUCE_GROUPS row groups sum the slab; the launch is filled up to IGD_TAIL_WGS workgroups (8 waves per SIMD),
+            // which find out from the batch's control words that the tail has nothing for them -- or share a long
+            // exact-walk list and the coverage of long queries, whose loops are chains of dependent loads
+            const int gx = (db->nFiles + 255) / 256;
+            dim3 rg(gx, IGD_REDUCE_GROUPS * gx >= IGD_TAIL_WGS ? IGD_REDUCE_GROUPS : (IGD_TAIL_WGS + gx - 1) / gx);
             const int rows32 = (mode != 2 && packed) ? db->epoch : 0;      // the merge join's kernel leaves 32-bit rows (CNT32)
             if (useV)
                 k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
