@@ -347,6 +347,7 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define CTL_NFAR 14      // + (epoch & 1): units the lean build of igd_scan_sorted leaves to far_units_body
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
+#define IGD_FAR_WIDE 8         // full build: a unit whose later-tile candidates span this many blocks of later[] goes to far_units_body
 #define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body
 // The merge join's list can never overflow: a batch has <= IGD_MAX_BATCH queries and a listed tile holds more than
 // IGD_LEAN_FIRST (full build: IGD_HEAVY_FIRST) of them as first-tile queries, each query in exactly one tile.
@@ -2375,7 +2376,9 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
                     // the lean build keeps nothing but 32-bit LDS counters: a far unit -- whose later-tile candidates nobody
                     // has counted -- is left, whole, to far_units_body in the batch's last launch (the full build bounds what
                     // every unit can add and sends the unit that would overflow a counter to the global hits[] itself)
-                    if (!RANK && IGD_LN_FAR(L.ln)) {
+                    // (... and so does the full build when the candidates span IGD_FAR_WIDE blocks of later[] or more -- a tile
+                    // behind one with 10^4 .. 10^6 queries: there the unit is shared out over many waves)
+                    if (IGD_LN_FAR(L.ln) && (!RANK || (!BIG && (L.f0 >> a.lbShift) - (L.la >> a.lbShift) >= IGD_FAR_WIDE))) {
                         KARG(a.farList)[atomicAdd(&KARG(a.ctlw)[CTL_NFAR + (a.epoch & 1)], 1)] = (int)mi | (heavy ? (int)0x80000000 : 0);
                         L.c0 = 0; L.ln = 0;
                     }
@@ -2575,7 +2578,16 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
     for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     const bool rankOK = __builtin_amdgcn_readlane(ctlv, CTL_NOTSTART) != a.epoch;
-    for (int i = gwave; i < nF && i < db.nUnits; i += nwaves) {
+    // A listed unit behind a very dense tile has the later-tile words of up to 10^6 queries to go through -- hundreds of
+    // blocks of later[], 2.8 ms for one wave.  Every unit is therefore shared out in nS slices of its blocks (the rank
+    // method is a sum over queries: slices add up); slice 0 also takes the unit's first-tile queries.  nS shrinks as the
+    // list grows (a slice beyond a unit's few blocks costs its wave three dependent loads to find that out).
+    if (nF > db.nUnits) return;                          // (cannot happen: a unit is listed once)
+    int nS = nwaves / nF;
+    nS = nS < 1 ? 1 : (nS > 64 ? 64 : nS);
+    const int sh = a.lbShift;
+    for (long long item = gwave; item < (long long)nF * nS; item += nwaves) {
+        const int i = (int)(item / nS), sl_ = (int)(item % nS);
         const int ent = __builtin_amdgcn_readfirstlane(a.farList[i]);
         const UnitRegs ur = load_unit_regs(db.units + (ent & 0x7fffffff));        // the same unit in every lane
         SRegs L;
@@ -2585,8 +2597,28 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
         const int lj = ur.jf >> 4;
         const int lb = lj < IGD_SHORT_TILES - 1 ? lj : IGD_SHORT_TILES - 1;
         L.f0 = a.firstQ[ur.tile];
-        L.c0 = ent < 0 ? 0 : a.firstQ[ur.tile + 1] - L.f0;
+        L.c0 = (ent < 0 || sl_ > 0) ? 0 : a.firstQ[ur.tile + 1] - L.f0;
         later_range<false>(a, ur.tile, lb, a.firstQ[ur.tile - lb], L.f0, L.la, L.ln);
+        if (nS > 1) {
+            if (sl_ == 0) L.ln = 0;                      // slice 0: the first-tile queries (it needs the true f0) ...
+            else if (L.ln != 0) {
+                // ... slices 1 .. nS-1: blocks b0 .. b1 of the unit's bA .. bB, described the way far_later reads a range -- nA
+                // entries from la on, whole blocks between, the first nB entries of the block that holds "query f0"
+                const int bA = L.la >> sh, bB = L.f0 >> sh;
+                const int per = (bB - bA + nS - 1) / (nS - 1);   // = ceil((bB - bA + 1) / (nS - 1))
+                const int b0 = bA + (sl_ - 1) * per;
+                int b1 = b0 + per - 1;
+                b1 = b1 > bB ? bB : b1;
+                if (b0 > bB) continue;
+                if (b0 != bA || b1 != bB) {
+                    int nA = IGD_LN_A(L.ln), nB = IGD_LN_B(L.ln);
+                    if (b0 != bA) { L.la = b0 << sh; nA = b0 == bB ? nB : a.laterHdr[b0].x; }
+                    if (b1 != bB) { L.f0 = b1 << sh; nB = b1 == b0 ? 0 : a.laterHdr[b1].x; }   // (c0 = 0 here: f0 only names the last block)
+                    L.ln = (L.ln & ~0x3FFFFFF) | nA | (nB << 13);
+                }
+            }
+        }
+        if ((L.c0 | L.ln) == 0) continue;
         Raw2 A;
         s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
         s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
