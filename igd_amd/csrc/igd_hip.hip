@@ -100,7 +100,8 @@ typedef unsigned long long u64;
                        // 4 no compares at all, 8 no later-tile queries, 64/128/256 rank method without term B / the searches of
                        // term A / prefix sums, 512 later-tile queries found but not searched, 8192 k_query_bounds without the
                        // compaction of the later-tile words; 32 time stamps per wave (tools/stamps.py), 1024 section timers of the
-                       // rank method (printed by igd_hip_close)
+                       // rank method (printed by igd_hip_close); 0x10000 / 0x20000 the last launch without heavy_sorted_body /
+                       // far_units_body (WRONG counts)
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
@@ -2841,8 +2842,8 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
         if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
         else {
-            heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
-            far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);   // (the lean build does not exist for BIG images)
+            if (!(IGD_EXP & 0x10000)) heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+            if (!(IGD_EXP & 0x20000)) far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);   // (the lean build does not exist for BIG images)
         }
     }
 }
