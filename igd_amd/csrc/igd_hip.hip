@@ -348,6 +348,9 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define CTL_NFAR 14      // + (epoch & 1): units the lean build of igd_scan_sorted leaves to far_units_body
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
+#ifndef IGD_FAR_SLICES
+#define IGD_FAR_SLICES 256     // far_units_body: at most this many slices per listed unit
+#endif
 #define IGD_FAR_WIDE 8         // full build: a unit whose later-tile candidates span this many blocks of later[] goes to far_units_body
 #define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body
 // The merge join's list can never overflow: a batch has <= IGD_MAX_BATCH queries and a listed tile holds more than
@@ -1603,6 +1606,29 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
     }
 }
 
+// deal_items: the work items of a skew valve's listed tiles, dealt round-robin to all waves of the hosting launch.  The
+// tiles are looked up 64 at a time, one per lane (look(h) -> the tile's number of items, 0 for h < 0; it keeps what it
+// found in lane variables), and one modulo per group finds the wave's first item; fn(lane of the tile, item within the
+// tile) then runs for every item of this wave.  (A loop over the tiles with a chain of dependent loads and two 64-bit
+// remainders per tile and wave made 1000 listed tiles cost EVERY wave of the launch 0.75 ms.)
+template <typename LOOK, typename FN>
+__device__ __forceinline__ void deal_items(int nH, int gwave, int nwaves, int lane, LOOK look, FN fn)
+{
+    long long base = 0;
+    for (int h0 = 0; h0 < nH; h0 += IGD_WAVE) {
+        const int items = look(h0 + lane < nH ? h0 + lane : -1);
+        const int incl = wave_inclusive_sum(items);
+        const int total = __builtin_amdgcn_readlane(incl, IGD_WAVE - 1);
+        long long r = ((long long)gwave - base) % nwaves;
+        if (r < 0) r += nwaves;
+        for (long long g = r; g < total; g += nwaves) {
+            const int hh = __popcll(__ballot(incl <= (int)g));                     // the tile (lane) that holds item g of the group
+            fn(hh, (int)g - (hh ? __builtin_amdgcn_readlane(incl, hh - 1) : 0));
+        }
+        base += total;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // heavy_bucket_body: the bucket path's skew valve.  The tile chunk is the unit of work, so a batch whose queries pile
 // up in a few tiles (10^6 unordered queries in ONE tile: 62 ms) would be serialised on the waves that own them.
@@ -1619,26 +1645,27 @@ __device__ __forceinline__ void heavy_bucket_body(const DbView &db, const ScanAr
     int nH = __builtin_amdgcn_readlane(ctlv, CTL_NHEAVY + (a.epoch & 1));
     if (nH == 0) return;
     if (nH > IGD_HEAVY_MAX) nH = IGD_HEAVY_MAX;
-    long long base = 0;
-    for (int h = 0; h < nH; h++) {
-        const int t = __builtin_amdgcn_readfirstlane(heavy[h]);
-        const int np = -__builtin_amdgcn_readfirstlane(a.pairN[t]);
-        const int pend = __builtin_amdgcn_readfirstlane(a.pairPos[t]);
-        const int u0 = __builtin_amdgcn_readfirstlane(db.tileUnit0[t]), nu = __builtin_amdgcn_readfirstlane(db.tileUnit0[t + 1]) - u0;
-        const int ns = (np + IGD_HEAVY_PAIRS - 1) / IGD_HEAVY_PAIRS;
-        const long long items = (long long)nu * ns;
-        long long it = ((long long)gwave - base % nwaves + nwaves) % nwaves;     // this wave's first item of the tile
-        for (; it < items; it += nwaves) {
-            const int u = u0 + (int)(it % nu), sl = (int)(it / nu);
+    int lnp = 0, lpend = 0, lu0 = 0, lnu = 0;
+    deal_items(nH, gwave, nwaves, lane,
+        [&](int h) {
+            lnp = lpend = lu0 = lnu = 0;
+            if (h < 0) return 0;
+            const int t = heavy[h];
+            lnp = -a.pairN[t]; lpend = a.pairPos[t];
+            lu0 = db.tileUnit0[t]; lnu = db.tileUnit0[t + 1] - lu0;
+            return lnu * ((lnp + IGD_HEAVY_PAIRS - 1) / IGD_HEAVY_PAIRS);
+        },
+        [&](int hh, int it) {
+            const int np = __builtin_amdgcn_readlane(lnp, hh), pend = __builtin_amdgcn_readlane(lpend, hh);
+            const int u0 = __builtin_amdgcn_readlane(lu0, hh), nu = __builtin_amdgcn_readlane(lnu, hh);
+            const int u = u0 + it % nu, sl = it / nu;
             const int p1 = sl * IGD_HEAVY_PAIRS + IGD_HEAVY_PAIRS < np ? sl * IGD_HEAVY_PAIRS + IGD_HEAVY_PAIRS : np;
             const UnitRegs L = load_unit_regs(db.units + u);                      // the same unit in every lane
             const int Lr0 = p1 - sl * IGD_HEAVY_PAIRS, Lr1 = pend - np + p1;      // pairs of the slice, end of the slice
             Raw A;
             issue_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A);
             compute_unit<false, USE_V, true>(db, a, L, Lr0, Lr1, 0, lane, A, d_hits, d_total);
-        }
-        base += items;
-    }
+        });
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2524,26 +2551,21 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
     for (int k = lane; k < IGD_WLDS_S; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_WLDS_H; k += IGD_WAVE) hist[k] = 0u;
     const bool rankOK = __builtin_amdgcn_readlane(ctlv, CTL_NOTSTART) != a.epoch;
-    long long base = 0;
-    // the listed tiles' ranges are looked up 64 at a time, one tile per lane (the lean build may list thousands: a chain of
-    // dependent loads per tile and wave would cost every wave milliseconds)
+    // (the listed tiles' ranges are looked up 64 at a time, one tile per lane: the lean build may list thousands)
     int lf0 = 0, lc0 = 0, lu0 = 0, lnu = 0;
-    for (int h = 0; h < nH; h++) {
-        if ((h & 63) == 0) {
+    deal_items(nH, gwave, nwaves, lane,
+        [&](int h) {
             lf0 = lc0 = lu0 = lnu = 0;
-            if (h + lane < nH) {
-                const int tl = a.heavyS[h + lane];
-                lf0 = a.firstQ[tl]; lc0 = a.firstQ[tl + 1] - lf0;
-                lu0 = db.tileUnit0[tl]; lnu = db.tileUnit0[tl + 1] - lu0;
-            }
-        }
-        const int f0 = __builtin_amdgcn_readlane(lf0, h & 63), c0 = __builtin_amdgcn_readlane(lc0, h & 63);
-        const int u0 = __builtin_amdgcn_readlane(lu0, h & 63), nu = __builtin_amdgcn_readlane(lnu, h & 63);
-        const int ns = (c0 + IGD_HEAVY_SLICE - 1) / IGD_HEAVY_SLICE;
-        const long long items = (long long)nu * ns;
-        long long it = ((long long)gwave - base % nwaves + nwaves) % nwaves;     // this wave's first item of the tile
-        for (; it < items; it += nwaves) {
-            const int u = u0 + (int)(it % nu), sc = (int)(it / nu);
+            if (h < 0) return 0;
+            const int tl = a.heavyS[h];
+            lf0 = a.firstQ[tl]; lc0 = a.firstQ[tl + 1] - lf0;
+            lu0 = db.tileUnit0[tl]; lnu = db.tileUnit0[tl + 1] - lu0;
+            return lnu * ((lc0 + IGD_HEAVY_SLICE - 1) / IGD_HEAVY_SLICE);
+        },
+        [&](int hh, int it) {
+            const int f0 = __builtin_amdgcn_readlane(lf0, hh), c0 = __builtin_amdgcn_readlane(lc0, hh);
+            const int u0 = __builtin_amdgcn_readlane(lu0, hh), nu = __builtin_amdgcn_readlane(lnu, hh);
+            const int u = u0 + it % nu, sc = it / nu;
             const UnitRegs ur = load_unit_regs(db.units + u);                     // the same unit in every lane
             SRegs L;
             L.offLo = ur.offLo; L.offHi = ur.offHi; L.n = ur.n; L.jf = ur.jf;
@@ -2555,9 +2577,7 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
             Raw2 A;
             s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
             s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
-        }
-        base += items;
-    }
+        });
 }
 
 // far_units_body: the units the lean build of igd_scan_sorted listed (far: more later-tile candidates than come with a
@@ -2585,7 +2605,7 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
     // list grows (a slice beyond a unit's few blocks costs its wave three dependent loads to find that out).
     if (nF > db.nUnits) return;                          // (cannot happen: a unit is listed once)
     int nS = nwaves / nF;
-    nS = nS < 1 ? 1 : (nS > 64 ? 64 : nS);
+    nS = nS < 1 ? 1 : (nS > IGD_FAR_SLICES ? IGD_FAR_SLICES : nS);
     const int sh = a.lbShift;
     for (long long item = gwave; item < (long long)nF * nS; item += nwaves) {
         const int i = (int)(item / nS), sl_ = (int)(item % nS);
