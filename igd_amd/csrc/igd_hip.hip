@@ -349,7 +349,7 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
 #define IGD_HEAVY_SLICE 4096
 #ifndef IGD_FAR_SLICES
-#define IGD_FAR_SLICES 256     // far_units_body: at most this many slices per listed unit
+#define IGD_FAR_SLICES 1024    // far_units_body: at most this many slices per listed unit
 #endif
 #define IGD_FAR_WIDE 8         // full build: a unit whose later-tile candidates span this many blocks of later[] goes to far_units_body
 #define IGD_LEAN_FIRST 512     // the lean (pairwise-only) build of igd_scan_sorted hands denser tiles to heavy_sorted_body

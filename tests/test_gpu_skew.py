@@ -65,3 +65,29 @@ def test_piled_up_queries_are_shared_out(big, span_tiles, limit_ms):
             np.testing.assert_array_equal(hits.cpu().numpy(), want, err_msg=name)
             assert ms < limit_ms, "%s: %.2f ms per batch of 10^6 queries inside %d tile(s)" % (name, ms, span_tiles)
             print("%-28s inside %4d tiles: %.3f ms" % (name, span_tiles, ms))
+
+
+@pytest.mark.parametrize("build", ["lean", "full"])
+def test_hot_tile_and_its_neighbours_whole_batch_against_the_oracle(build, monkeypatch):
+    """3 x 10^5 queries inside one tile plus 2 x 10^5 spread over its neighbourhood, position-sorted: the hot tile goes to
+    heavy_sorted_body, the units of the tiles behind it -- later-tile words of hundreds of blocks -- to far_units_body in
+    slices (both builds list them).  The whole batch against the oracle, -v too."""
+    from igd_amd import Database
+    monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")
+    rng = np.random.default_rng(99)
+    hot = (50_003_968 + rng.integers(0, 16384, 300000)).astype(np.int64)          # tile 3052 of chr1
+    near = (50_003_968 + rng.integers(-40 * 16384, 40 * 16384, 200000)).astype(np.int64)
+    qs = np.sort(np.concatenate([hot, near])).astype(np.int32)
+    qe = (qs + rng.integers(1, 40000, len(qs))).astype(np.int32)                 # up to 3 tiles long: later-tile words everywhere
+    qe[::777] = qs[::777] - 2
+    ichr = np.zeros(len(qs), np.int32)
+    db, orc = Database(PATH), Oracle(PATH)
+    try:
+        for v in (0, 500):
+            want, wtot = orc.search(ichr, qs, qe, v)
+            for flags in (1, 0):
+                got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                assert gtot == wtot, (build, v, flags)
+                np.testing.assert_array_equal(got, want, err_msg="%s v=%d flags=%d" % (build, v, flags))
+    finally:
+        db.close(); orc.close()
