@@ -978,7 +978,15 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
                     m &= m - 1;
                     const unsigned at2 = (unsigned)__builtin_amdgcn_readlane((int)at, src);
                     const int c2 = __builtin_amdgcn_readlane(c, src);
-                    for (int j = lane; j < c2; j += IGD_WAVE) fn(reg[(size_t)at2 + j]);
+                    // four tuples in flight per lane (one workgroup owns the bucket: 10^6 queries piled up in a few tiles are
+                    // ALL its pairs, and a load waited for per tuple made that 2.6 ms)
+                    int j = lane;
+                    for (; j + 3 * IGD_WAVE < c2; j += 4 * IGD_WAVE) {
+                        const SpTuple a0 = reg[(size_t)at2 + j], a1 = reg[(size_t)at2 + j + IGD_WAVE];
+                        const SpTuple a2 = reg[(size_t)at2 + j + 2 * IGD_WAVE], a3 = reg[(size_t)at2 + j + 3 * IGD_WAVE];
+                        fn(a0); fn(a1); fn(a2); fn(a3);
+                    }
+                    for (; j < c2; j += IGD_WAVE) fn(reg[(size_t)at2 + j]);
                 }
             }
         }
