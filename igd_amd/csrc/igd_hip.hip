@@ -222,6 +222,7 @@ struct igd_hip_db {
     int lbShift;                  // log2(queries per later block) of the batch in flight
     int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
     int forceRank;                // IGD_HIP_RANK at open (tests): 0 lean build, 1 full build, -1 the engine decides
+    bool bigImage;                // the compact image is addressed with per-unit 64-bit bases (>= 2^30 tile records; IGD_HIP_BIG=1 at open: tests)
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
@@ -3374,6 +3375,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     {   // the environment is read here, once: the per-batch entry points look at nothing but the handle
         const char *fr = getenv("IGD_HIP_RANK");
         db->forceRank = fr && *fr ? atoi(fr) : -1;
+        const char *fb = getenv("IGD_HIP_BIG");
+        db->bigImage = fb && *fb == '1';                 // (|| the record count, once it is known)
         db->qbVec1 = getenv("IGD_HIP_QB_VEC1") != nullptr;
         db->timing = tim;
     }
@@ -3794,7 +3797,7 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
 {
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
     if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
-        const bool big = db->nRec + IGD_CHUNK >= (1ll << 30);
+        const bool big = db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
         const SortK K = make_sortk(db, a);
         // sparse on average (fewer than 28 queries per tile): the lean build, whose pairwise path is not burdened with the rank
@@ -3913,7 +3916,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
     const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
-                       (db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
+                       (db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
     // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
     size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)IGD_WLDS_BYTES : 0;
     int tailHistOff = -1;                                // u64 counters for the exact walks and the coverage, when the files fit

@@ -83,3 +83,45 @@ def test_more_files_than_lds_counters(build, workdir, monkeypatch):
                     np.testing.assert_array_equal(got, want, err_msg="%s n=%d v=%d flags=%d" % (build, n, v, flags))
     finally:
         db.close(); orc.close()
+
+
+def test_big_image_addressing_on_an_ordinary_database(monkeypatch, workdir):
+    """An image of 2^30 tile records or more (17 GB of .igd) is beyond a 32-bit byte offset: igd_scan_sorted<.., BIG = true, ..>
+    gives every unit its own 64-bit base, and the batch's last launch runs the BIG twin of the skew valve.  IGD_HIP_BIG=1
+    (read at open) runs an ordinary database through those instantiations: sparse, dense (rank method), -v, long
+    queries, a hot tile -- against the oracle's counts."""
+    import json
+    from igd_amd import Database, synth
+    monkeypatch.setenv("IGD_HIP_BIG", "1")
+    path = _roadmap()
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_checksums.json")))["workloads"]
+    db = Database(path)
+    try:
+        w = np.arange(1, db.nfiles + 1, dtype=np.uint64)
+        chk = lambda h: int((h.astype(np.uint64) * w).sum() & np.uint64((1 << 63) - 1))
+        base = synth.make_queries(1000000, seed=7, genome=synth.HG38, sorted_=True)
+        longq = synth.make_queries(100000, seed=7, genome=synth.HG38, min_len=100000, max_len=200000, sorted_=True)
+        for name, q in (("config2_sorted_q1000000", base), ("long_sorted_q100000", longq)):
+            for v in (0, 500):
+                g = gold["%s_v%d" % (name, v)]
+                for flags in (1, 0):
+                    h, tot = db.search(*q, v, flags=flags)
+                    assert (tot, chk(h)) == (g["total"], g["checksum"]), (name, v, flags)
+        # dense (rank method) + a hot tile, whole against the oracle
+        rng = np.random.default_rng(3)
+        hot = (50_003_968 + rng.integers(0, 16384, 120000)).astype(np.int64)
+        near = (50_003_968 + rng.integers(-20 * 16384, 20 * 16384, 180000)).astype(np.int64)
+        qs = np.sort(np.concatenate([hot, near])).astype(np.int32)
+        qe = (qs + rng.integers(1, 30000, len(qs))).astype(np.int32)
+        ichr = np.zeros(len(qs), np.int32)
+        orc = Oracle(path)
+        try:
+            for v in (0, 500):
+                want, wtot = orc.search(ichr, qs, qe, v)
+                got, gtot = db.search(ichr, qs, qe, v, flags=1)
+                assert gtot == wtot
+                np.testing.assert_array_equal(got, want)
+        finally:
+            orc.close()
+    finally:
+        db.close()
