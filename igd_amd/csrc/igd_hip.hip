@@ -222,7 +222,6 @@ struct igd_hip_db {
     int lbShift;                  // log2(queries per later block) of the batch in flight
     int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
     int forceRank;                // IGD_HIP_RANK at open (tests): 0 lean build, 1 full build, -1 the engine decides
-    int qbCap;                    // large batches: k_query_bounds runs this many workgroups of 1024 threads, each over several blocks of queries
     bool bigImage;                // the compact image is addressed with per-unit 64-bit bases (>= 2^30 tile records; IGD_HIP_BIG=1 at open: tests)
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
@@ -460,10 +459,7 @@ __device__ __forceinline__ void cover_tiles(const DbView &db, int32_t *__restric
 }
 
 template <int VEC, bool FAST, int WGT>
-#ifndef IGD_QB_OCC
-#define IGD_QB_OCC 8
-#endif
-__global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
+__global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
                                                       int packed_, int32_t *__restrict__ firstQ, int32_t *__restrict__ lpos,
@@ -475,44 +471,35 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
     constexpr int NW = WGT / IGD_WAVE;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
     // and the batch's state is looked up (a workgroup that then leaves at once has read 12 KiB for nothing).
-    // A workgroup takes the blocks blk = blockIdx.x, blockIdx.x + gridDim.x, ... (a large batch is launched with two
-    // workgroups per CU: the next block's queries are loaded while this one's are worked on -- one-shot workgroups spent
-    // half their life waiting for their loads and the other half not loading); a batch of fewer blocks than that: one each.
-    const int nBlk = (int)(((long long)nq + WGT * VEC - 1) / (WGT * VEC));
-    int blk = (int)blockIdx.x;
-    auto loadq = [&](int b, int (&c_)[VEC], int (&s_)[VEC], int (&e_)[VEC], int &pc_, int &ps_) {
-        const int j0 = (int)((unsigned)b * WGT + threadIdx.x) * VEC;
-        if (VEC == 4) {
-            int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
-            if (j0 + 3 < nq) {
-                c4 = *(const int4 *)(ichr + j0); s4 = *(const int4 *)(qs + j0); e4 = *(const int4 *)(qe + j0);
-            } else {
-                if (j0 < nq) { c4.x = ichr[j0]; s4.x = qs[j0]; e4.x = qe[j0]; }
-                if (j0 + 1 < nq) { c4.y = ichr[j0 + 1]; s4.y = qs[j0 + 1]; e4.y = qe[j0 + 1]; }
-                if (j0 + 2 < nq) { c4.z = ichr[j0 + 2]; s4.z = qs[j0 + 2]; e4.z = qe[j0 + 2]; }
-            }
-            c_[0] = c4.x; c_[1 % VEC] = c4.y; c_[2 % VEC] = c4.z; c_[3 % VEC] = c4.w;
-            s_[0] = s4.x; s_[1 % VEC] = s4.y; s_[2 % VEC] = s4.z; s_[3 % VEC] = s4.w;
-            e_[0] = e4.x; e_[1 % VEC] = e4.y; e_[2 % VEC] = e4.z; e_[3 % VEC] = e4.w;
-        } else if (j0 < nq) { c_[0] = ichr[j0]; s_[0] = qs[j0]; e_[0] = qe[j0]; }
-        pc_ = -1; ps_ = INT_MIN;
-        if (j0 > 0 && j0 < nq) { pc_ = ichr[j0 - 1]; ps_ = qs[j0 - 1]; }
-    };
-    // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
-    // and the batch's state is looked up (a workgroup that then leaves at once has read 12 KiB for nothing).
+    const int i0 = (int)(blockIdx.x * WGT + threadIdx.x) * VEC;
     int qc[VEC], qs_[VEC], qe_[VEC];
-    int pc, ps;
-    loadq(blk, qc, qs_, qe_, pc, ps);
+    if (VEC == 4) {
+        int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
+        if (i0 + 3 < nq) {
+            c4 = *(const int4 *)(ichr + i0); s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
+        } else {
+            if (i0 < nq) { c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
+            if (i0 + 1 < nq) { c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
+            if (i0 + 2 < nq) { c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
+        }
+        qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
+        qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
+        qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
+    } else if (i0 < nq) { qc[0] = ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
+    int pc = -1, ps = INT_MIN;
+    if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
-    __shared__ int sCnt[2][NW];   // (by parity of the workgroup's pass: a fast wave writes the next pass's while a slow one still reads this one's)
+    __shared__ int sCnt[NW];
     const bool ldsTab = FAST || db.nCtg <= QB_CTG;
     const int packed = FAST ? 1 : packed_;
     // Has any wave found the batch unordered already?  ONE device-scope load per workgroup (an L1-cached one would keep
     // returning the stale line): a load per wave -- 10^5 requests for the one address at 1.25e7 queries -- queued up at
     // its memory channel for as long as the rest of the kernel takes.
     __shared__ int sSeen;
-    if (threadIdx.x < NW) { sCnt[0][threadIdx.x] = 0; sCnt[1][threadIdx.x] = 0; }   // (a wave that leaves early counts as one without entries)
+    int seen = 0;
+    if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
+    if (threadIdx.x < NW) sCnt[threadIdx.x] = 0;          // (a wave that leaves early counts as one without entries)
     if (ldsTab)
         for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
     __syncthreads();
@@ -531,16 +518,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
         ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
     }
     const int lane = threadIdx.x & 63;
-    int total = 0;
-    for (int pass = 0; blk < nBlk; pass ^= 1) {
-    const int i0 = (int)((unsigned)blk * WGT + threadIdx.x) * VEC;
-    int seen = 0;
-    if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
-    // the next block's queries: in flight while this block is worked on
-    constexpr bool PERSIST = WGT == 1024;              // (the other builds are launched with one workgroup per block)
-    const int nxt = PERSIST ? blk + (int)gridDim.x : nBlk;
-    int nc[VEC], ns_[VEC], ne_[VEC], npc = -1, nps = INT_MIN;
-    if (PERSIST && nxt < nBlk) loadq(nxt, nc, ns_, ne_, npc, nps);
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
     // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here (an unordered batch
     // worked through to the end, gap filling included, took 50 instead of 5 us).
@@ -689,15 +666,15 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
     // query's (possible) entry = entries of the queries before it in the block.  (A wave that left above is not waited
     // for by the barrier -- and nothing of an unordered batch's block is read.)
     int pos[VEC];
-    total = 0;
-    const bool blockLive = packed != 0;
+    int total = 0;
+    const bool blockLive = packed && (long long)blockIdx.x * (WGT * VEC) < nq;   // (workgroups past the queries only help filling firstQ[])
 #pragma unroll
     for (int v = 0; v < VEC; v++) pos[v] = 0;
     int c = 0;
 #pragma unroll
     for (int v = 0; v < VEC; v++) c += w1v[v] != 0 ? 1 : 0;
     const int inc = wave_inclusive_sum(c);
-    if (lane == 63) sCnt[pass][threadIdx.x >> 6] = inc;
+    if (lane == 63) sCnt[threadIdx.x >> 6] = inc;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read (the merge join is
     // off, the bucket path keeps its own lists): workgroups that see the mark stop here, before they store anything (an
     // unordered batch worked through to the end, gap filling included, took 50 instead of 5 us).
@@ -708,18 +685,18 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
     if (blockLive && !(IGD_EXP & 8192)) {
         // entries of the waves before this one / of the whole block: one LDS read per lane and a wave scan (the numbers
         // are the same for all lanes of a wave)
-        const int mine = lane < NW ? sCnt[pass][lane] : 0;
+        const int mine = lane < NW ? sCnt[lane] : 0;
         const int run = wave_inclusive_sum(mine);
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         total = __builtin_amdgcn_readlane(run, NW - 1);
         int off = inc - c + (wv > 0 ? __builtin_amdgcn_readlane(run, wv - 1) : 0);
-        int32_t *reg = later + (size_t)blk * (WGT * VEC);
+        int32_t *reg = later + (size_t)blockIdx.x * (WGT * VEC);
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             pos[v] = off;
             if (w1v[v] != 0) reg[off++] = w1v[v];
         }
-        if (threadIdx.x == 0) laterHdr[blk] = make_int2(total, 0);
+        if (threadIdx.x == 0) laterHdr[blockIdx.x] = make_int2(total, 0);
     }
     // 5. firstQ (+ lpos): short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
     // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
@@ -772,18 +749,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
                 if (i0 + v < nq) qw0[i0 + v] = w0v[v];
         }
     } else if (i0 < nq) qw0[i0] = w0v[0];
-    // lpos[] of the first three tiles after the last query's (all that a query can still reach) = the entries of the last
-    // block, if the queries end inside it: written by that block's own workgroup
-    if (blk == nBlk - 1 && (int)threadIdx.x < IGD_SHORT_TILES - 1) {
-        const int kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
-        if (kl + 1 + (int)threadIdx.x <= db.nT) lpos[kl + 1 + threadIdx.x] = (nq % (WGT * VEC)) != 0 ? total : 0;
-    }
-    if (!PERSIST || nxt >= nBlk) break;
-    blk = nxt;
-#pragma unroll
-    for (int v = 0; v < VEC; v++) { qc[v] = nc[v]; qs_[v] = ns_[v]; qe_[v] = ne_[v]; }
-    pc = npc; ps = nps;
-    }
     // head and tail of firstQ[] -- the tiles up to the first query's key and after the last one's, together all the
     // tiles a batch does not reach (7/8 of them for one GPU's slab of an 8-GPU job) -- are filled by the whole grid:
     // left to the first / last query's own wave they took longer than everything else in this kernel.  lpos[] of the
@@ -794,6 +759,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? IGD_QB_OCC : 4)) void
         const int nth = gridDim.x * WGT;
         for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; lpos[tt] = 0; }
         for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;
+        if ((int)blockIdx.x == (nq - 1) / (WGT * VEC) && (int)threadIdx.x < IGD_SHORT_TILES - 1 && kl + 1 + (int)threadIdx.x <= db.nT)
+            lpos[kl + 1 + threadIdx.x] = (nq % (WGT * VEC)) != 0 ? total : 0;
     }
 }
 
@@ -3411,8 +3378,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         const char *fb = getenv("IGD_HIP_BIG");
         db->bigImage = fb && *fb == '1';                 // (|| the record count, once it is known)
         db->qbVec1 = getenv("IGD_HIP_QB_VEC1") != nullptr;
-        const char *qc = getenv("IGD_HIP_QB_CAP");       // A/B: workgroups of k_query_bounds for large batches (0: one per block of queries)
-        db->qbCap = qc && *qc ? atoi(qc) : 512;
         db->timing = tim;
     }
     db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
@@ -3920,7 +3885,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         const bool wide = vec && nq >= ((int64_t)1 << 22);
 #define QB_GRID(PER_) ((int)((nq + (PER_) - 1) / (PER_)) > fillBlocks ? (int)((nq + (PER_) - 1) / (PER_)) : fillBlocks)
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
-    k_query_bounds<VEC_, FAST_, WGT_><<<(WGT_ == 1024 && db->qbCap > 0 && QB_GRID(WGT_ * VEC_) > db->qbCap) ? db->qbCap : QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
+    k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
 #ifndef IGD_QB_WIDE
