@@ -363,10 +363,9 @@ static_assert(IGD_LEAN_FIRST <= IGD_HEAVY_FIRST, "the list of heavy_sorted_body 
 #define CTL_BUDGET 8
 // Exact-walk list entries (int2: query index, kind).  The scan kernels handle the common case
 // only; what they leave out is listed by the grouping kernels and done by k_exact_walk:
-#define WALK_BEYOND 0   // merge join: tiles n1+IGD_SHORT_TILES .. n2 of a long query
 #define WALK_FIRST 1    // tile n1 only: first-tile query with qe <= tile start (compact image cannot express it)
-#define WALK_ALL 2      // bucket path: every tile n1 .. n2 of a long query
-#define WALK_LAST 3     // merge join: tile n2 only of a long query (the tiles between are counted by coverage, see IGD_COV_*)
+#define WALK_ALL 2      // bucket path: the first and the last tile of a long query (the tiles between: coverage, see IGD_COV_*)
+#define WALK_LAST 3     // merge join: tile n2 only of a long query (n1 .. n1+3 by the scan kernel, the tiles between: coverage)
 // Long queries (more than IGD_SHORT_TILES tiles) in the merge join.  Tiles n1+1 .. n1+3 are reached by the query's
 // later[] entry like any other query's, the LAST tile n2 is walked exactly (WALK_LAST) -- and the tiles between, which the
 // query covers from end to end, by COVERAGE: every record that STARTS in such a tile (and passes the value filter) is
@@ -2656,9 +2655,10 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------
-// k_exact_walk: what the scan kernel leaves out (the exact-walk list of the batch's path): one
-// wave per listed query walks its tiles on the EXACT arrays, 6 slots at a time, and adds
-// straight into the caller's global hits[] (and the batch total).  Rare by construction.
+// exact_walk_body: what the scan kernel leaves out (the exact-walk list of the batch's path): a wave walks a listed
+// query's tiles (WALK_*: which of them) on the EXACT arrays, 5 slots at a time, and adds into the workgroup's LDS
+// counters of the batch's last launch -- the caller's global hits[] where the files do not fit -- and the batch total.
+// Rare for the benchmark's queries; a batch of long ones lists every query (its last tile).
 template <bool USE_V>
 __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
                                                 const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv, u64 *hist)
@@ -2692,7 +2692,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             vj1 = n2 > vn1 ? n2 : vn1;
             if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[vbase + vn1] == 0) vj1 = -1;   // :468 -- nothing to walk
             if (vj1 >= 0) {                              // ... and the first tile of the walk (the only one of WALK_LAST and WALK_FIRST)
-                const int jf = vkind == WALK_BEYOND ? vn1 + IGD_SHORT_TILES : vkind == WALK_LAST ? vj1 : vn1;
+                const int jf = vkind == WALK_LAST ? vj1 : vn1;
                 if (jf <= vj1) {
                     vcnt = db.tileCnt[vbase + jf];
                     const int64_t o = db.tileOff[vbase + jf];
@@ -2707,7 +2707,6 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             int j1 = __builtin_amdgcn_readlane(vj1, e);
             if (j1 < 0) continue;
             int j0 = n1;
-            if (kind == WALK_BEYOND) j0 = n1 + IGD_SHORT_TILES;
             if (kind == WALK_LAST) j0 = j1;              // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
             if (kind == WALK_FIRST) j1 = n1;
             for (int j = j0; j <= j1; j = (kind == WALK_ALL && j < j1) ? j1 : j + 1) {   // (WALK_ALL: first and last tile, coverage_body has the rest)
