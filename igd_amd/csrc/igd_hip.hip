@@ -19,7 +19,7 @@
 //         queries, and of those of the up-to-3 tiles before it that reach it, with the tile's
 //         records (a merge join: both sides stream, nothing is computed per candidate);
 //      b. any other order: every (query, visited tile) pair is grouped by tile id without global
-//         atomics (k_split_local -> k_split_totals -> k_split_fine: LDS counting in two levels);
+//         atomics (k_split_local -> k_split_fine: LDS counting in two levels);
 //         these kernels return at once when (a) holds.
 //      The NEST/FLAT visiting rule and the "first tile" notion live entirely in this step.
 //   2. scan:   igd_scan_sorted (a) / igd_scan_tiles (b) -- one wavefront owns one <=320-record chunk
@@ -226,7 +226,6 @@ struct igd_hip_db {
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
-    int32_t *d_spBase;            // pairs per coarse bucket
     int spShift, spCoarse;        // coarse bucket = tile >> spShift; spShift < 0: split path not applicable
     char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
     size_t arenaSize, arenaUsed;
@@ -813,7 +812,6 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
 //   k_split_local   a workgroup takes 1024 queries, counts their pairs per COARSE bucket (tile >> shift,
 //                   <= 1024 buckets) in LDS, and writes them, grouped by bucket, into its own region
 //                   + one table row (offset | count << 16 per bucket);
-//   k_split_totals  column sums of the table -> first pair of every bucket (one workgroup);
 //   k_split_fine    one workgroup per bucket collects the bucket's segments from all regions, counts per
 //                   tile in LDS (the bucket spans 2^shift tiles), writes pairN/pairPos of its tiles and
 //                   the pairs, tile by tile, into `pairs`.
@@ -914,29 +912,9 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
             }
 }
 
-// column sums of the table: workgroup g owns 64 buckets, its 16 waves share the rows
-__global__ __launch_bounds__(1024) void k_split_totals(const uint32_t *__restrict__ table, int nWG, int nCoarse,
-                                                       int32_t *__restrict__ totals, const int32_t *__restrict__ ctl, int gate)
-{
-    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
-    __shared__ uint32_t part[16][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.x * 64 + lane;
-    uint32_t tot = 0;
-    if (b < nCoarse)
-        for (int w = wv; w < nWG; w += 16) tot += table[(size_t)w * nCoarse + b] >> 16;
-    part[wv][lane] = tot;
-    __syncthreads();
-    if (wv == 0 && b < nCoarse) {
-        uint32_t t = 0;
-        for (int k = 0; k < 16; k++) t += part[k][lane];
-        totals[b] = (int32_t)t;
-    }
-}
-
 #define SP_ROWS 4     // table rows a thread keeps in flight
 __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
-                                                      const SpTuple *__restrict__ reg, const int32_t *__restrict__ totals,
+                                                      const SpTuple *__restrict__ reg,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
                                                       int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
                                                       int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
@@ -949,9 +927,10 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
     const int b = blockIdx.x, t0 = b << shift;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
-    {   // first pair of this bucket = pairs of all earlier buckets
+    {   // first pair of this bucket = pairs of all earlier buckets = the sum over the table's rows of each row's own
+        // exclusive prefix at this column (the low half of the entries this workgroup reads anyway): no kernel of column sums
         uint32_t x = 0;
-        for (int k = threadIdx.x; k < b; k += SPF_WG) x += (uint32_t)totals[k];
+        for (int w = threadIdx.x; w < nWG; w += SPF_WG) x += table[(size_t)w * nCoarse + b] & 0xFFFFu;
         for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_down((int)x, o);
         if (lane == 0) wsum[wv] = x;
     }
@@ -3268,7 +3247,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
-                    db->d_spTable, db->d_spT, db->d_spBase};
+                    db->d_spTable, db->d_spT};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
@@ -3706,9 +3685,9 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     const int64_t cap = nq > db->wsBucket ? nq : db->wsBucket;
     const int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
     {
-        void *ws[] = { db->d_pairs, db->d_long, db->d_spTable, db->d_spT, db->d_spBase };
+        void *ws[] = { db->d_pairs, db->d_long, db->d_spTable, db->d_spT };
         for (void *q : ws) if (q) (void)hipFree(q);
-        db->d_pairs = nullptr; db->d_long = nullptr; db->d_spTable = nullptr; db->d_spT = nullptr; db->d_spBase = nullptr;
+        db->d_pairs = nullptr; db->d_long = nullptr; db->d_spTable = nullptr; db->d_spT = nullptr;
     }
     db->wsBucket = 0;
     if ((rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr)) != IGD_HIP_OK) return rc;
@@ -3722,7 +3701,6 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
             const size_t nWG = (size_t)((cap + SP_Q - 1) / SP_Q);
             if ((rc = dalloc(&db->d_spTable, nWG * (size_t)db->spCoarse, nullptr)) != IGD_HIP_OK) return rc;
             if ((rc = dalloc(&db->d_spT, nWG * SP_CAP, nullptr)) != IGD_HIP_OK) return rc;
-            if ((rc = dalloc(&db->d_spBase, SP_MAXC + 2, nullptr)) != IGD_HIP_OK) return rc;
         }
     }
     db->wsBucket = cap;
@@ -3759,9 +3737,8 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
     const int nWG = (nq + SP_Q - 1) / SP_Q;
     k_split_local<<<nWG, SP_WG, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
                                          db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal);
-    k_split_totals<<<(db->spCoarse + 63) / 64, 1024, 0, st>>>(db->d_spTable, nWG, db->spCoarse, db->d_spBase, db->d_ctl, gate);
     k_split_fine<<<db->spCoarse, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
-                                                                          db->d_spT, db->d_spBase,
+                                                                          db->d_spT,
                                                                           db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs,
                                                                           db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
     HIPCHK(hipGetLastError());
