@@ -1939,7 +1939,8 @@ __device__ __forceinline__ void far_later(const SortArgs &a, int la, int ln, int
 // RANK = false: the lean build for batches that are sparse on average (the host decides by queries per tile): no rank
 // method in the kernel at all -- its registers would burden the pairwise path, which is what such a batch runs --
 // and a tile that is dense after all goes to heavy_sorted_body from IGD_LEAN_FIRST first-tile queries on.
-template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false>
+// FEW: the database has one file (1) / up to eight (2): builds of their own, so that the usual one pays nothing for them
+template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false, int FEW = 0>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
                                           u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u)
@@ -2240,7 +2241,17 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         direct = bound > (long long)(budget - *spent);
         if (!direct) *spent += (unsigned)bound;
     }
+    if (!direct && FEW == 1) {
+        // one file: every lane names counter 0 -- 64 LDS atomics on one address are 64 passes (10^6 queries against a
+        // database of one 2 x 10^7-record file: scan kernel 212 us, 54 with sixteen files) -- so the wave adds once
+        int s = 0;
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) s += cnt[r];
+        s = wave_inclusive_sum(s);
+        if (lane == IGD_WAVE - 1 && s) atomicAdd((unsigned int *)hits, (unsigned)s);
+    } else
     if (!direct) {
+        constexpr bool few = FEW != 0;                   // a handful of files: lanes without hits stay out (see below)
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++) {
 #if IGD_EXP & 1
@@ -2250,7 +2261,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // lean build: every lane adds, 0 included (no compare / exec masking -- that build is bound by instruction issue);
             // full build: lanes without hits stay out -- the lanes past a unit's end all name counter 0, and the dozens
             // of them in a unit's last slot would queue up for ONE address in an LDS the rank method keeps busy
-            if (!RANK || cnt[r]) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
+            if ((!RANK && !few) || cnt[r]) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
         }
     } else {
         u64 *gh = CNT32 ? KARG(hitsOut) : hits;          // (CNT32: the slab rows hold 32-bit counts, this unit's go to hits[] itself)
@@ -2292,7 +2303,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #define IGD_WG_LEAN IGD_WG      // ... and of the lean build
 #define IGD_WPE_LEAN IGD_WPE
 #endif
-template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK>
+template <bool USE_V, bool LDS_HITS, bool CNT32, bool BIG, bool RANK, int FEW = 0>
 // (waves per SIMD pinned from both sides: with only the lower bound the compiler budgets the scalar registers for 10 waves --
 // 80 -- although the vector registers already hold the kernel at 8, and spills a dozen of them)
 __global__ __launch_bounds__(RANK ? IGD_WG_RANK : IGD_WG_LEAN)
@@ -2421,11 +2432,11 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
             s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
             while (ka >= 0) {
                 s_issue<USE_V, BIG>(db, a, L, kb < 0 ? 0 : kb, kb >= 0, lane, B);
-                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, ka, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 ka = -1;
                 if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
                 s_issue<USE_V, BIG>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
-                if (kb >= 0) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+                if (kb >= 0) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kb, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 kb = -1;
                 if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
 #if IGD_OPT_PRIO
@@ -2450,11 +2461,11 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
             s_issue<USE_V, BIG>(db, a, L, 1, 1 < cntU, lane, B);
             for (int kk = 0; kk < cntU; kk += 3) {
                 s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, C);
-                s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+                s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 s_issue<USE_V, BIG>(db, a, L, kk + 3, kk + 3 < cntU, lane, A);
-                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
                 s_issue<USE_V, BIG>(db, a, L, kk + 4, kk + 4 < cntU, lane, B);
-                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
 #if IGD_OPT_PRIO
                 done += 3;
                 if (done >= prioAt) {
@@ -2475,9 +2486,9 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+            s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
             s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
@@ -3790,9 +3801,19 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         const int64_t wavesLean = (int64_t)db->grid * (IGD_WG_LEAN / IGD_WAVE);
         if (((int64_t)db->nUnits + wavesLean - 1) / wavesLean * (IGD_WG_LEAN / IGD_WAVE) * (IGD_LEAN_FIRST + IGD_WAVE) * IGD_CHUNK >= (1ll << 32)) lean = false;
         // <USE_V, LDS_HITS, CNT32, BIG, RANK>: workgroups with LDS counters keep them in 32 bits (igd_scan_sorted guards the range itself)
+        // (a database of one file / of up to eight: builds whose lanes do not all add to the same few LDS counters)
+        const int few = (LDS_HITS && !big) ? (db->nFiles == 1 ? 1 : db->nFiles <= 8 ? 2 : 0) : 0;
         if (big) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-        else if (lean) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, LDS_HITS ? ldsS : 0, st>>>(K);   // (the lean build's only LDS is its counters)
-        else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        else if (lean) {
+            const size_t l = LDS_HITS ? ldsS : 0;         // (the lean build's only LDS is its counters)
+            if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
+            else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
+            else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
+        } else {
+            if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+            else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+            else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        }
     } else
     if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
     if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);

@@ -125,3 +125,30 @@ def test_big_image_addressing_on_an_ordinary_database(monkeypatch, workdir):
             orc.close()
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("files", [1, 2, 8])
+def test_databases_of_very_few_files(files, workdir, monkeypatch):
+    """One file: every lane of a wave names the same LDS counter (the wave adds once: build FEW = 1); up to eight: lanes
+    without hits stay out (FEW = 2).  Sparse and dense batches, both builds of the merge join, -v, against the oracle."""
+    from igd_amd import Database, synth
+    path = os.path.join(workdir, "few%d.igd" % files)
+    synth.make_db(path, files=files, per_file=60000 // files, seed=4 + files, nbp_log=12, genome=synth.SMALL)
+    orc = Oracle(path)
+    try:
+        for build in ("0", "1"):
+            monkeypatch.setenv("IGD_HIP_RANK", build)
+            db = Database(path)
+            try:
+                for n in (2000, 150000):
+                    ichr, qs, qe = synth.make_queries(n, seed=9, genome=synth.SMALL, min_len=1, max_len=12000, sorted_=True, unknown_every=301)
+                    for v in (0, 400):
+                        want, wtot = orc.search(ichr, qs, qe, v)
+                        for flags in (1, 0, 2):
+                            got, gtot = db.search(ichr, qs, qe, v, flags=flags)
+                            assert gtot == wtot, (files, build, n, v, flags)
+                            np.testing.assert_array_equal(got, want, err_msg="files=%d build=%s n=%d v=%d flags=%d" % (files, build, n, v, flags))
+            finally:
+                db.close()
+    finally:
+        orc.close()
