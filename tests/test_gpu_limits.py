@@ -152,3 +152,38 @@ def test_databases_of_very_few_files(files, workdir, monkeypatch):
                 db.close()
     finally:
         orc.close()
+
+
+def test_search_on_a_database_of_3000_contigs(workdir):
+    """More contigs than k_query_bounds keeps in its LDS tables (1024): the build that gathers the per-contig tables
+    from global memory (FAST = false), every mode, against the oracle.  The database: 10 files of intervals on
+    chrUn_0000 .. chrUn_2999, made by the product's `create`."""
+    import subprocess
+    from helpers import ROOT
+    from igd_amd import Database
+    from test_oracle_create import write_odd_inputs
+    d = os.path.join(workdir, "manyctg")
+    os.makedirs(d, exist_ok=True)
+    write_odd_inputs(d, "many_contigs")
+    p = subprocess.run([os.path.join(ROOT, "bin", "igd"), "create", d + "/in/", d + "/o", "db", "-b", "13"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-500:]
+    path = d + "/o/db.igd"
+    db, orc = Database(path), Oracle(path)
+    try:
+        assert db.nctg > 1024
+        rng = np.random.default_rng(8)
+        for n in (3000, 200000):
+            ichr = rng.integers(-1, db.nctg + 2, n).astype(np.int32)
+            qs = rng.integers(-100, 260000, n).astype(np.int32)
+            qe = (qs + rng.integers(-5, 90000, n)).astype(np.int32)
+            o = np.lexsort((qs, ichr))
+            for q, modes in (((ichr[o], qs[o], qe[o]), (1, 0, 2)), ((ichr, qs, qe), (0, 2))):
+                for v in (0, 350):
+                    want, wtot = orc.search(*q, v)
+                    for flags in modes:
+                        got, gtot = db.search(*q, v, flags=flags)
+                        assert gtot == wtot, (n, v, flags)
+                        np.testing.assert_array_equal(got, want, err_msg="n=%d v=%d flags=%d" % (n, v, flags))
+    finally:
+        db.close(); orc.close()
