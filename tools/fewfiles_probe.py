@@ -10,14 +10,15 @@ st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 os.makedirs("/tmp/igdb", exist_ok=True)
 q = synth.make_queries(1000000, seed=7, genome=synth.HG38, sorted_=True)
 qu = synth.make_queries(1000000, seed=7, genome=synth.HG38, sorted_=False)
-for files in (1, 2, 4, 16, 64, 1900):
+qd = synth.make_queries_slab(bench.CONFIG4_PER_GPU, 0, bench.CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
+for files in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,2,4,16,64,1900".split(","))]:
     per = 20000000 // files if files < 1900 else 26316
     path = "/tmp/igdb/few%d.igd" % files if files < 1900 else "/tmp/igdb/rm1900x26316.igd"
     if not os.path.exists(path + ".done"):
         synth.make_db(path, files=files, per_file=per, seed=1000, nbp_log=14, genome=synth.HG38)
         open(path + ".done", "w").write("ok")
     db = Database(path)
-    for qq, flags, name in ((q, 1, "sorted"), (qu, 2, "bucket")):
+    for qq, flags, name in ((q, 1, "sorted"), (qu, 2, "bucket"), (qd, 1, "dense")):
         job = bench.Job(db, dev, st.cuda_stream, *qq, 0, flags)
         el, prof = job.run(10, 2)
         print("files %4d (%8d tile records) | %-6s | step %8.1f us scan %8.1f us | hits/step %d" %
