@@ -83,6 +83,8 @@
 #define IGD_REDUCE_GROUPS 64                 // (32-bit slab rows: 6.2 us with 128 groups, 5.4 with 64, 6.4 with 32, 10.1 with 16)
 #endif
 #define IGD_PIPE_EVENTS 16                   // profiling: launches whose whole pipeline (not just the scan kernel) is timed
+#define IGD_WINDOW_FILES 10240
+#define IGD_MAX_WINDOWS 16                   // passes over the files of a database with more files than LDS counters
 #define IGD_LDS_HITS_MAX_BYTES (120 * 1024)   // + 37 KiB of rank-method areas (igd_scan_sorted) stays below 160 KiB
 
 typedef unsigned long long u64;
@@ -188,6 +190,7 @@ struct DbView {
     const int32_t *ctgNTile;                    // [nCtg]
     const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
     int32_t *cov;                               // workspace: 4 sets of coverage difference arrays (IGD_COV_*)
+    int32_t fileLo;                             // scan kernels, WIN builds: the pass counts the files [fileLo, fileLo + nFiles) (see igd_hip_db::winN)
 };
 
 struct igd_hip_db {
@@ -242,6 +245,7 @@ struct igd_hip_db {
     u64 *d_slab;
     int grid, ldsBytes;
     bool ldsHits;
+    int winN, nWin;               // files per window / windows (1: the files fit the LDS counters, or there are too many for windows)
     // `-f` streaming workspace (created by the first enumeration, kept)
     int64_t *d_qcount, *d_qoff, *d_enumBsum;
     int64_t enumQCap, enumChunkCap;          // capacity in queries / overlaps per chunk buffer
@@ -1374,7 +1378,7 @@ __device__ __forceinline__ void match_slots(const Raw &R, int (&cnt)[IGD_SLOTS],
     }
 }
 
-template <bool SORTED, bool USE_V, bool PACKED>
+template <bool SORTED, bool USE_V, bool PACKED, bool WIN = false>
 __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a, const UnitRegs &L, int Lr0,
                                              int Lr1, int kk, int lane, Raw &R, u64 *hits, u64 *found = nullptr)
 {
@@ -1485,6 +1489,10 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
 #pragma unroll
     for (int r = 0; r < IGD_SLOTS; r++) {
         const int c = cnt[r];
+        if (WIN) {                                       // this pass counts the files of its window only
+            const unsigned x = (unsigned)R.x[r] - (unsigned)db.fileLo;
+            if (c && x < (unsigned)db.nFiles) atomicAdd((u64 *)((char *)hits + ((size_t)x << 3)), (u64)(unsigned)c);
+        } else
         if (c) atomicAdd((u64 *)((char *)hits + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
     }
     if (found) {                                         // skew valves: the batch total is kept by the caller of this unit
@@ -1499,7 +1507,10 @@ __device__ __forceinline__ void compute_unit(const DbView &db, const ScanArgs &a
 // SORTED = true : merge join over the caller's ordered arrays (firstQ[])
 // SORTED = false: bucketed pairs
 // In the device-decides mode both are enqueued and the one that does not apply returns at once.
-template <bool SORTED, bool USE_V, bool LDS_HITS, bool PACKED>
+// WIN: more files than LDS counters (15 360): the batch is scanned once per window of files, each pass counting its own
+// (db.fileLo, db.nFiles = the window); per-record global atomics -- the alternative -- run at 2.4e10 per second on this
+// part whatever their scope (tools/atomic_bench.hip): 1.05 ms per 10^6 queries where a pass takes 0.08
+template <bool SORTED, bool USE_V, bool LDS_HITS, bool PACKED, bool WIN = false>
 __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, ScanArgs a)
 {
     {
@@ -1554,9 +1565,9 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
             issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, 0, lane, A);
             for (int kk = 0; kk < cntU; kk += 2) {
                 if (kk + 1 < cntU) issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 1, lane, B);
-                compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
+                compute_unit<SORTED, USE_V, PACKED, WIN>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
                 if (kk + 2 < cntU) issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 2, lane, A);
-                if (kk + 1 < cntU) compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk + 1, lane, B, hits);
+                if (kk + 1 < cntU) compute_unit<SORTED, USE_V, PACKED, WIN>(db, a, L, Lr0, Lr1, kk + 1, lane, B, hits);
 #if IGD_OPT_PRIO
                 done += 2;
                 if (done >= prioAt) {
@@ -1571,7 +1582,7 @@ __global__ __launch_bounds__(IGD_WG, IGD_WPE) void igd_scan_tiles(DbView db, Sca
         } else {
             for (int kk = 0; kk < cntU; kk++) {
                 issue_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A);
-                compute_unit<SORTED, USE_V, PACKED>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
+                compute_unit<SORTED, USE_V, PACKED, WIN>(db, a, L, Lr0, Lr1, kk, lane, A, hits);
 #if IGD_OPT_PRIO
                 done += 1;
                 if (done >= prioAt) {
@@ -1698,6 +1709,7 @@ struct SortArgs {
     int sbCap, wldsBytes;        // rank method: u16 entries of a wave's sorted-query-start array / bytes of a wave's LDS area
     int32_t *ctlw, *heavyS;      // control words (writable) and the list of tiles left to heavy_sorted_body
     int32_t *farList;            // [nUnits] units the lean build leaves to far_units_body (unit number | its tile is in heavyS << 31)
+    int noList;                  // a later pass of a windowed batch: heavy tiles and far units are left out as in the first pass, which listed them
     int tailHistOff;             // the last launch's per-workgroup u64 counters for exact walks and coverage: byte offset in its dynamic LDS (< 0: none)
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
@@ -1939,7 +1951,8 @@ __device__ __forceinline__ void far_later(const SortArgs &a, int la, int ln, int
 // RANK = false: the lean build for batches that are sparse on average (the host decides by queries per tile): no rank
 // method in the kernel at all -- its registers would burden the pairwise path, which is what such a batch runs --
 // and a tile that is dense after all goes to heavy_sorted_body from IGD_LEAN_FIRST first-tile queries on.
-// FEW: the database has one file (1) / up to eight (2): builds of their own, so that the usual one pays nothing for them
+// FEW: the database has one file (1) / up to eight (2): builds of their own, so that the usual one pays nothing for them;
+// 3: a window of a database with more files than LDS counters (lanes without hits stay out as with 2: half the lanes have none)
 template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false, int FEW = 0>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
@@ -2225,6 +2238,15 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     // records) to any of them, every wave keeps the sum of that bound over its units, and the unit that would take the
     // wave beyond its share of 2^32 (and any `far` unit, whose candidates are not counted beforehand) adds to the caller's
     // 64-bit hits[] with global atomics instead -- as do the builds without LDS counters (one atomic per record hit).
+    if (FEW == 3) {                                      // a window of files (see igd_scan_tiles, WIN): the others' records count nothing in this pass
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const unsigned x = (unsigned)R.x[r] - (unsigned)db.fileLo;
+            const bool in = x < (unsigned)db.nFiles;
+            cnt[r] = in ? cnt[r] : 0;
+            R.x[r] = in ? (int)x : 0;
+        }
+    }
     bool direct = !CNT32;
     // (the lean build needs no guard: the host has bounded what its units -- <= IGD_LEAN_FIRST + 64 candidates each, the
     // far ones are not its own -- can add up to: launch_scan)     // the lean build: the host has bounded what its units -- <= IGD_LEAN_FIRST + 64
@@ -2396,7 +2418,7 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
                     // count, its first unit lists it; the list holds IGD_HEAVYS_MAX tiles -- more than a batch can have.
                     const bool heavy = L.c0 > (RANK ? IGD_HEAVY_FIRST : IGD_LEAN_FIRST);
                     if (heavy) {
-                        if (u.jf & 1) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
+                        if ((u.jf & 1) && !a.noList) KARG(a.heavyS)[atomicAdd(&KARG(a.ctlw)[CTL_NHEAVYS + (a.epoch & 1)], 1)] = u.tile;
                         L.c0 = 0;
                     }
                     // the lean build keeps nothing but 32-bit LDS counters: a far unit -- whose later-tile candidates nobody
@@ -2405,7 +2427,7 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
                     // (... and so does the full build when the candidates span IGD_FAR_WIDE blocks of later[] or more -- a tile
                     // behind one with 10^4 .. 10^6 queries: there the unit is shared out over many waves)
                     if (IGD_LN_FAR(L.ln) && (!RANK || (!BIG && (L.f0 >> a.lbShift) - (L.la >> a.lbShift) >= IGD_FAR_WIDE))) {
-                        KARG(a.farList)[atomicAdd(&KARG(a.ctlw)[CTL_NFAR + (a.epoch & 1)], 1)] = (int)mi | (heavy ? (int)0x80000000 : 0);
+                        if (!a.noList) KARG(a.farList)[atomicAdd(&KARG(a.ctlw)[CTL_NFAR + (a.epoch & 1)], 1)] = (int)mi | (heavy ? (int)0x80000000 : 0);
                         L.c0 = 0; L.ln = 0;
                     }
                 }
@@ -2908,7 +2930,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     }
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
-    coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
+    if (valves >= 0) coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
     if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
     if (s) atomicAdd(&hits[f], s);
     if (total) {
@@ -2920,11 +2942,12 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
             if (t) atomicAdd(total, t);
         }
     }
+    if (valves < 0) return;                              // an earlier pass of a windowed batch: the tail rides in the last pass's launch
     // ... and the batch's exact-walk list and skew valves (normally empty) ride in the same launch
     const int nb = gridDim.x * gridDim.y;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
     const int gwave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, hits, total, smem, gwave, nb * 4, ctlv);
+    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, wa.out, total, smem, gwave, nb * 4, ctlv);   // (wa.out: the caller's hits[]; `hits` is a window of it in a windowed batch)
 }
 
 // without LDS counters the batch total is the growth of sum(hits): measured around the launch
@@ -3444,11 +3467,25 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         int cus = 0;                                     // one attribute, not hipGetDeviceProperties (~30 ms)
         TRYHIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
         if (cus <= 0) cus = 256;
-        db->ldsBytes = (int)((size_t)d->nFiles * 8);
+        // more files than LDS counters (15 360): the batch is scanned once per WINDOW of files (up to IGD_MAX_WINDOWS passes:
+        // 163 840 files; beyond that per-record global atomics)
+        db->winN = d->nFiles; db->nWin = 1;
+        if ((size_t)d->nFiles * 8 > IGD_LDS_HITS_MAX_BYTES) {
+            // (windows of at most 10 240 files: two workgroups of the merge join's full build per CU then still have LDS arrays
+            // of 512 query starts -- with 15 360 counters they had none, and a dense batch took 631 instead of 150 us per pass)
+            const int cap = IGD_WINDOW_FILES;
+            db->nWin = (d->nFiles + cap - 1) / cap;
+            db->winN = ((d->nFiles + db->nWin - 1) / db->nWin + 31) & ~31;      // windows of equal size (the last one may be shorter)
+            if (db->winN > cap) db->winN = cap;
+            db->nWin = (d->nFiles + db->winN - 1) / db->winN;
+            // (no window builds for images addressed with 64-bit unit bases)
+            if (db->nWin > IGD_MAX_WINDOWS || getenv("IGD_HIP_NO_WINDOWS") || db->bigImage || (int64_t)n + IGD_CHUNK >= (1ll << 30)) { db->winN = d->nFiles; db->nWin = 1; }
+        }
+        db->ldsBytes = (int)((size_t)db->winN * 8);
         db->ldsHits = db->ldsBytes <= IGD_LDS_HITS_MAX_BYTES;
         {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
-            const int hitB = db->ldsHits ? (int)((((size_t)d->nFiles * 4) + 15) & ~(size_t)15) : 0;   // (32-bit counters: CNT32)
+            const int hitB = db->ldsHits ? (int)((((size_t)db->winN * 4) + 15) & ~(size_t)15) : 0;   // (32-bit counters: CNT32)
             int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;   // the full build: 2 workgroups per CU
             db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
             for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
@@ -3463,7 +3500,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         if (perCU < 1) perCU = 1;
         db->grid = cus * perCU;
-        const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1) * 8 : 0;
+        const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(db->winN > 0 ? db->winN : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
         size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 112 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
@@ -3600,7 +3637,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 
     // launch geometry of the scan kernel: computed above (db->grid, db->ldsBytes, db->ldsHits)
     if (db->ldsHits) {
-        TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(d->nFiles > 0 ? d->nFiles : 1), acct));
+        TRY(dalloc(&db->d_slab, (size_t)db->grid * (size_t)(db->winN > 0 ? db->winN : 1), acct));
         if (db->ldsBytes > 64 * 1024) {
             const void *fns[] = {(const void *)igd_scan_tiles<true, false, true, false>, (const void *)igd_scan_tiles<true, true, true, false>,
                                  (const void *)igd_scan_tiles<false, false, true, false>, (const void *)igd_scan_tiles<false, true, true, false>,
@@ -3608,6 +3645,14 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                                  (const void *)igd_scan_tiles<false, false, true, true>, (const void *)igd_scan_tiles<false, true, true, true>};
             for (const void *fn : fns)
                 TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            if (db->nWin > 1) {
+                const void *wfn[] = {(const void *)igd_scan_tiles<true, false, true, false, true>, (const void *)igd_scan_tiles<true, true, true, false, true>,
+                                     (const void *)igd_scan_tiles<false, false, true, false, true>, (const void *)igd_scan_tiles<false, true, true, false, true>,
+                                     (const void *)igd_scan_tiles<true, false, true, true, true>, (const void *)igd_scan_tiles<true, true, true, true, true>,
+                                     (const void *)igd_scan_tiles<false, false, true, true, true>, (const void *)igd_scan_tiles<false, true, true, true, true>};
+                for (const void *fn : wfn)
+                    TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsBytes));
+            }
         }
     }
     if (db->ldsSorted > 64 * 1024) {
@@ -3618,6 +3663,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         const void *sfn[] = {IGD_SORTED_FNS(false, true), IGD_SORTED_FNS(true, true), IGD_SORTED_FNS(false, false), IGD_SORTED_FNS(true, false)};
 #undef IGD_SORTED_FNS
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
+        if (db->nWin > 1) {
+            const void *wfn[] = {(const void *)igd_scan_sorted<false, true, true, false, false, 3>, (const void *)igd_scan_sorted<false, true, true, false, true, 3>,
+                                 (const void *)igd_scan_sorted<true, true, true, false, false, 3>, (const void *)igd_scan_sorted<true, true, true, false, true, 3>};
+            for (const void *fn : wfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
+        }
     }
 #undef TRY
 #undef TRYHIP
@@ -3764,7 +3814,7 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     sa.laterHdr = (const int2 *)db->d_laterHdr; sa.lbShift = db->lbShift; sa.lpos = db->d_lpos;
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
-    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.tailHistOff = -1;
+    sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.tailHistOff = -1; sa.noList = 0;
     sa.stamps = nullptr;
 #if IGD_EXP & 32
     {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
@@ -3779,14 +3829,18 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     return K;
 }
 
+// win >= 0: pass `win` of a batch against a database with more files than LDS counters (igd_hip_db::winN)
 template <bool USE_V, bool LDS_HITS, bool PACKED>
-static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
+static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st, int win = -1)
 {
+    const int fileLo = win > 0 ? win * db->winN : 0;
+    const int fileN = win >= 0 ? (db->nFiles - fileLo < db->winN ? db->nFiles - fileLo : db->winN) : db->nFiles;
     const size_t lds = LDS_HITS ? db->ldsBytes : 0;
     if (a.mode != 2 && PACKED) {                         // merge join over the compact image: its own kernel
         const bool big = db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30);
         const size_t ldsS = (size_t)db->ldsSorted;
-        const SortK K = make_sortk(db, a);
+        SortK K = make_sortk(db, a);
+        if (win >= 0) { K.db.nFiles = fileN; K.db.fileLo = fileLo; K.hitsOut += fileLo; K.a.noList = win > 0 ? 1 : 0; }
         // sparse on average (fewer than 28 queries per tile): the lean build, whose pairwise path is not burdened with the rank
         // method's registers; tiles that are dense all the same go to heavy_sorted_body
         const int forceRank = db->forceRank;              // tests: 0 lean, 1 full (IGD_HIP_RANK, read at open)
@@ -3802,29 +3856,37 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st)
         if (((int64_t)db->nUnits + wavesLean - 1) / wavesLean * (IGD_WG_LEAN / IGD_WAVE) * (IGD_LEAN_FIRST + IGD_WAVE) * IGD_CHUNK >= (1ll << 32)) lean = false;
         // <USE_V, LDS_HITS, CNT32, BIG, RANK>: workgroups with LDS counters keep them in 32 bits (igd_scan_sorted guards the range itself)
         // (a database of one file / of up to eight: builds whose lanes do not all add to the same few LDS counters)
-        const int few = (LDS_HITS && !big) ? (db->nFiles == 1 ? 1 : db->nFiles <= 8 ? 2 : 0) : 0;
+        const int few = (LDS_HITS && !big) ? (win >= 0 ? 3 : db->nFiles == 1 ? 1 : db->nFiles <= 8 ? 2 : 0) : 0;
         if (big) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         else if (lean) {
             const size_t l = LDS_HITS ? ldsS : 0;         // (the lean build's only LDS is its counters)
             if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
             else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
+            else if (few == 3) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 3 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
             else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
         } else {
             if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
             else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+            else if (few == 3) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 3 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
             else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
         }
     } else
-    if (a.mode != 2) igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
-    if (a.mode != 1) igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    if (a.mode != 2) {
+        if (win >= 0) { DbView v = db->v; v.nFiles = fileN; v.fileLo = fileLo; igd_scan_tiles<true, USE_V, LDS_HITS, PACKED, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(v, a); }
+        else igd_scan_tiles<true, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    }
+    if (a.mode != 1) {
+        if (win >= 0) { DbView v = db->v; v.nFiles = fileN; v.fileLo = fileLo; igd_scan_tiles<false, USE_V, LDS_HITS, PACKED, LDS_HITS><<<db->grid, IGD_WG, lds, st>>>(v, a); }
+        else igd_scan_tiles<false, USE_V, LDS_HITS, PACKED><<<db->grid, IGD_WG, lds, st>>>(db->v, a);
+    }
 }
 template <bool LDS_HITS>
-static void launch_scan_any(igd_hip_db *db, const ScanArgs &a, bool useV, bool packed, hipStream_t st)
+static void launch_scan_any(igd_hip_db *db, const ScanArgs &a, bool useV, bool packed, hipStream_t st, int win = -1)
 {
     if (packed) {
-        if (useV) launch_scan<true, LDS_HITS, true>(db, a, st); else launch_scan<false, LDS_HITS, true>(db, a, st);
+        if (useV) launch_scan<true, LDS_HITS, true>(db, a, st, win); else launch_scan<false, LDS_HITS, true>(db, a, st, win);
     } else {
-        if (useV) launch_scan<true, LDS_HITS, false>(db, a, st); else launch_scan<false, LDS_HITS, false>(db, a, st);
+        if (useV) launch_scan<true, LDS_HITS, false>(db, a, st, win); else launch_scan<false, LDS_HITS, false>(db, a, st, win);
     }
 }
 
@@ -3921,9 +3983,13 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     if (db->ldsHits) {
         a.out = db->d_slab;
         const SortK K = make_sortk(db, a);
-        launch_scan_any<true>(db, a, useV, packed, st);
-        if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
-        {   // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
+        // (more files than LDS counters: one pass of scan + reduction per window of files; the batch's tail rides in the last)
+        for (int win = 0; win < db->nWin; win++) {
+            const bool last = win == db->nWin - 1;
+            const int fileLo = win * db->winN, fileN = db->nWin == 1 ? db->nFiles : (db->nFiles - fileLo < db->winN ? db->nFiles - fileLo : db->winN);
+            launch_scan_any<true>(db, a, useV, packed, st, db->nWin > 1 ? win : -1);
+            if (slot >= 0 && last) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+            // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
             SortK Kt = K;
@@ -3931,15 +3997,15 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
             // IGD_REDUCE_GROUPS row groups sum the slab; the launch is filled up to IGD_TAIL_WGS workgroups (8 waves per SIMD),
             // which find out from the batch's control words that the tail has nothing for them -- or share a long
             // exact-walk list and the coverage of long queries, whose loops are chains of dependent loads
-            const int gx = (db->nFiles + 255) / 256;
-            dim3 rg(gx, IGD_REDUCE_GROUPS * gx >= IGD_TAIL_WGS ? IGD_REDUCE_GROUPS : (IGD_TAIL_WGS + gx - 1) / gx);
+            const int gx = (fileN + 255) / 256;
+            dim3 rg(gx, (!last || IGD_REDUCE_GROUPS * gx >= IGD_TAIL_WGS) ? IGD_REDUCE_GROUPS : (IGD_TAIL_WGS + gx - 1) / gx);
             const int rows32 = (mode != 2 && packed) ? db->epoch : 0;      // the merge join's kernel leaves 32-bit rows (CNT32)
             if (useV)
-                k_reduce_slabs<true><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                               db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves, rows32);
+                k_reduce_slabs<true><<<rg, 256, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
+                                                               db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, last ? valves : -1, rows32);
             else
-                k_reduce_slabs<false><<<rg, 256, tailLds, st>>>(Kt, db->d_slab, db->grid, db->nFiles, (u64 *)d_hits, (u64 *)d_total,
-                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, valves, rows32);
+                k_reduce_slabs<false><<<rg, 256, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
+                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, last ? valves : -1, rows32);
         }
     } else {
         a.out = (u64 *)d_hits;

@@ -61,9 +61,14 @@ def test_more_dense_tiles_than_the_bucket_list_holds(build, monkeypatch):
         db.close(); orc.close()
 
 
-@pytest.mark.parametrize("build", ["auto", "lean", "full"])
+@pytest.mark.parametrize("build", ["auto", "lean", "full", "lean-global-atomics", "full-global-atomics"])
 def test_more_files_than_lds_counters(build, workdir, monkeypatch):
+    """16 000 files: two windows of 8000 files, one pass of scan + reduction each (LDS counters); with IGD_HIP_NO_WINDOWS
+    the per-record global atomics that windows replaced (still what > 163 840 files get)."""
     from igd_amd import Database, synth
+    if build.endswith("-global-atomics"):
+        monkeypatch.setenv("IGD_HIP_NO_WINDOWS", "1")
+        build = build.split("-")[0]
     if build != "auto":
         monkeypatch.setenv("IGD_HIP_RANK", "0" if build == "lean" else "1")
     path = os.path.join(workdir, "manyfiles.igd")
@@ -187,3 +192,38 @@ def test_search_on_a_database_of_3000_contigs(workdir):
                         np.testing.assert_array_equal(got, want, err_msg="n=%d v=%d flags=%d" % (n, v, flags))
     finally:
         db.close(); orc.close()
+
+
+@pytest.mark.parametrize("files,per_file", [(40000, 30), (70000, 12)])
+def test_windows_of_files(files, per_file, workdir, monkeypatch):
+    """40 000 files: three windows over the compact image; 70 000: five windows over the exact arrays (the compact image
+    holds 16-bit file numbers).  Short, long (coverage arrays, exact walks: the batch's tail adds to the caller's hits[],
+    not to a window of it) and piled-up queries, every mode and build, -v, against the oracle."""
+    from igd_amd import Database, synth
+    path = os.path.join(workdir, "win%d.igd" % files)
+    synth.make_db(path, files=files, per_file=per_file, seed=11, nbp_log=12, genome=synth.SMALL)
+    orc = Oracle(path)
+    try:
+        rng = np.random.default_rng(files)
+        ichr, qs, qe = synth.make_queries(60000, seed=6, genome=synth.SMALL, min_len=1, max_len=9000, sorted_=True, unknown_every=173)
+        qe[::50] = qs[::50] + rng.integers(5 * 4096, 200 * 4096, len(qs[::50]))          # long ones
+        hot = 30000
+        qs[hot:hot + 9000] = qs[hot] + rng.integers(0, 4096, 9000)                        # a hot tile
+        qe[hot:hot + 9000] = qs[hot:hot + 9000] + rng.integers(1, 9000, 9000)
+        o = np.lexsort((qs, ichr))
+        srt = (ichr[o], qs[o], qe[o])
+        for build in ("0", "1"):
+            monkeypatch.setenv("IGD_HIP_RANK", build)
+            db = Database(path)
+            try:
+                assert db.nfiles == files
+                for v in (0, 600):
+                    want, wtot = orc.search(ichr, qs, qe, v)
+                    for q, flags in ((srt, 1), (srt, 0), ((ichr, qs, qe), 0), ((ichr, qs, qe), 2)):
+                        got, gtot = db.search(*q, v, flags=flags)
+                        assert gtot == wtot, (files, build, v, flags)
+                        np.testing.assert_array_equal(got, want, err_msg="files=%d build=%s v=%d flags=%d" % (files, build, v, flags))
+            finally:
+                db.close()
+    finally:
+        orc.close()
