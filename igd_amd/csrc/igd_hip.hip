@@ -3489,6 +3489,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;   // the full build: 2 workgroups per CU
             db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
             for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
+            if (db->sbCap == 0) {                        // counters that leave two workgroups per CU nothing: one workgroup, with the arrays
+                spare = (160 * 1024 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;
+                for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
+            }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
