@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/fuzz_engine.py [cases] [seed0] -- GPU box: the ENGINE (igd_hip_search through igd_amd.Database) against the oracle on
-random databases (tile size 2^10 .. 2^15 and one that is no power of two is left to tests/, 1 .. 300 files, gType 0/1,
+random databases (tile size 2^10 .. 2^15 and one that is no power of two is left to tests/, 1 .. 300 files and 21 000 (windows of files), gType 0/1,
 clustered or not) and random batches that mix what the kernels treat differently: short queries, queries of many
 tiles, inverted ones, unknown contigs, starts beyond the contig, duplicates, a hot tile with 10^3 .. 10^5 queries --
 position-sorted (order promise and device decides), unordered (device decides, bucket path), both builds of the merge
@@ -45,8 +45,9 @@ def main():
         rng = np.random.default_rng(seed0 + ci)
         d = tempfile.mkdtemp(prefix="ige", dir="/tmp")
         try:
-            b = int(rng.choice([10, 11, 12, 13, 14, 15])); files = int(rng.choice([1, 7, 60, 300]))
+            b = int(rng.choice([10, 11, 12, 13, 14, 15])); files = int(rng.choice([1, 7, 60, 300, 300, 21000]))
             per = int(rng.choice([200, 3000, 20000])); gtype = int(rng.choice([0, 1, 1])); cl = bool(rng.random() < 0.3)
+            if files > 10000: per = int(rng.choice([15, 150]))        # (more files than LDS counters: windows of files)
             path = os.path.join(d, "f.igd")
             synth.make_db(path, files=files, per_file=per, seed=int(rng.integers(1, 1 << 30)), nbp_log=b, genome=synth.SMALL,
                           clustered=cl, gtype=gtype)
