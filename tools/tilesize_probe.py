@@ -8,7 +8,7 @@ from igd_amd import Database, synth
 import bench
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
-for b in (14, 12, 11, 10):
+for b in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "14,12,11,10".split(","))]:
     path = "/tmp/igdb/rm1900x26316_b%d.igd" % b
     os.makedirs("/tmp/igdb", exist_ok=True)
     if not os.path.exists(path + ".done"):
