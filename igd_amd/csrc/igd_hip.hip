@@ -827,7 +827,9 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
 #define SP_PER 4
 #endif
 #define SP_Q (SP_WG * SP_PER) // queries per workgroup of k_split_local: more queries = longer segments per (workgroup, bucket)
+#ifndef SPF_WG
 #define SPF_WG 256           // threads of k_split_fine
+#endif
 #define SP_CAP (SP_Q * IGD_SHORT_TILES)
 #define SP_MAXC 1024
 
@@ -977,7 +979,8 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
     walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
     __syncthreads();
     {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
-        const int per = F / SPF_WG, f0 = threadIdx.x * per;
+        const int per0 = F >= SPF_WG ? F / SPF_WG : 1, f0 = threadIdx.x * per0;
+        const int per = f0 < F ? per0 : 0;               // (more threads than tiles: the rest own none)
         uint32_t sum = 0;
         for (int k = 0; k < per; k++) sum += cnt[f0 + k];
         uint32_t x = sum;
