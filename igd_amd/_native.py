@@ -9,7 +9,9 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIBDIR = os.environ.get("IGD_AMD_LIBDIR") or os.path.join(HERE, "lib")   # override: kernel-variant experiments
+# IGD_AMD_LIBDIR: kernel-variant experiments (tools/ab.sh, tools/valu_ab.sh) load another build of the libraries.  Which
+# build is mapped is never a guess: igd_hip_build_flags() names it, and Database() refuses one that gives wrong counts.
+LIBDIR = os.environ.get("IGD_AMD_LIBDIR") or os.path.join(HERE, "lib")
 
 i32p = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
@@ -83,7 +85,7 @@ class CoreDb(C.Structure):
     """struct igdc_db of igd_amd/csrc/igd_core.h"""
     _fields_ = [("nbp", C.c_int32), ("gType", C.c_int32), ("nCtg", C.c_int32), ("nFiles", C.c_int32),
                 ("nTile", i32p), ("nCntFlat", i32p), ("nCnt", C.POINTER(i32p)),
-                ("tIdxFlat", i64p), ("tIdx", C.POINTER(i64p)),
+                ("tBase", i64p), ("reserved_", C.c_void_p),
                 ("cName", C.POINTER(C.c_char_p)), ("fileName", C.POINTER(C.c_char_p)),
                 ("fileNr", i32p), ("fileMd", C.POINTER(C.c_double)),
                 ("nTileTotal", C.c_int64), ("nRecords", C.c_int64), ("dataOff", C.c_int64),
@@ -140,6 +142,8 @@ def hip():
         L.igd_hip_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.igd_hip_max_batch.restype = C.c_int64
+        L.igd_hip_build_flags.restype = C.c_uint
+        L.igd_hip_build_wrong_counts.restype = C.c_uint
         L.igd_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
         L.igd_hip_enumerate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.POINTER(C.POINTER(HipHit)), i64p]

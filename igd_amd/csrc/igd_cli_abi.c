@@ -169,13 +169,16 @@ iGD_t *get_igdinfo(char *igdFile)                                  /* src/igd_ba
     g->nCnt = (int32_t **)malloc(sizeof(int32_t *) * (size_t)(m + 1));
     g->tIdx = (int64_t **)malloc(sizeof(int64_t *) * (size_t)(m + 1));
     g->cName = (char **)malloc(sizeof(char *) * (size_t)(m + 1));
+    const int64_t recBytes = core->gType == 0 ? 12 : 16;
+    int64_t loc = core->dataOff;                               /* tile offsets: the running sum of src/igd_base.c:288-303 */
     for (int32_t c = 0; c < m; c++) {
         const int32_t k = core->nTile[c];
         g->nTile[c] = k;
-        g->nCnt[c] = (int32_t *)calloc((size_t)k + 1, sizeof(int32_t));
-        g->tIdx[c] = (int64_t *)calloc((size_t)k + 1, sizeof(int64_t));
+        g->nCnt[c] = (int32_t *)malloc(((size_t)k + 1) * sizeof(int32_t));
+        g->tIdx[c] = (int64_t *)malloc(((size_t)k + 1) * sizeof(int64_t));
         memcpy(g->nCnt[c], core->nCnt[c], sizeof(int32_t) * (size_t)k);
-        memcpy(g->tIdx[c], core->tIdx[c], sizeof(int64_t) * (size_t)k);
+        g->nCnt[c][k] = 0; g->tIdx[c][k] = 0;
+        for (int32_t j = 0; j < k; j++) { g->tIdx[c][j] = loc; loc += recBytes * (int64_t)core->nCnt[c][j]; }
         g->cName[c] = (char *)malloc(40);
         memcpy(g->cName[c], core->cName[c], 40);
     }
@@ -248,6 +251,18 @@ static void *parse_run(void *arg)
     return NULL;
 }
 
+/* a file of at most igdc_host_limit() queries, while no engine is resident: counted on the host (igd_hostpath.c) */
+static igdc_map *host_map(int64_t nq)
+{
+    if (!g_core || g_core->dev || nq > igdc_host_limit()) return NULL;
+    const int fd = g_core_path ? open(g_core_path, O_RDONLY) : (fP ? dup(fileno(fP)) : -1);
+    if (fd < 0) return NULL;
+    g_core->nFiles = cur_igd()->nFiles;          /* hits[] is sized from the TSV (:923-925) */
+    igdc_map *m = igdc_map_open(g_core, fd);
+    close(fd);
+    return m;
+}
+
 static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
 {
     if (!g_core || !cur_igd()) { engine(); return 0; }
@@ -255,7 +270,8 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
     J.qFile = qFile; J.rc = -1;
     double t0 = now_s();
     pthread_t th;
-    const int threaded = !(g_core->dev) && pthread_create(&th, NULL, parse_run, &J) == 0;
+    /* a file that is probably small is parsed first and the engine is only started if it turns out not to be */
+    const int threaded = !(g_core->dev) && !igdc_host_probably_small(qFile) && pthread_create(&th, NULL, parse_run, &J) == 0;
     if (threaded) { engine(); pthread_join(th, NULL); }
     else parse_run(&J);
     if (J.rc != 0) return 0;                                         /* :701-702 */
@@ -264,7 +280,14 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
     int64_t total = 0;
     if (q.unsorted && igdc_queries_group_contigs(&q, g_core->nCtg))       /* a sorted BED, chromosomes in another order */
         phase("contig runs put into the database's order", &t0);
-    if (q.n > 0) {
+    else if (q.unsorted && timing_on())                                   /* one out-of-place line is enough */
+        fprintf(stderr, "[igd timing] the query file is not position-sorted: the engine groups it (bucket path)\n");
+    igdc_map *hm = q.n > 0 ? host_map(q.n) : NULL;
+    if (hm) {
+        if (igdc_search_host(g_core, hm, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total) != 0) total = 0;
+        igdc_map_close(hm);
+        phase("search on the host (small file)", &t0);
+    } else if (q.n > 0) {
         igd_hip_db *dev = engine();
         t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
@@ -534,8 +557,9 @@ static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, c
 static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 {
     if (q->n == 0) return 0;
-    igd_hip_db *dev = engine();
-    if (!dev) return 0;
+    igdc_map *hm = host_map(q->n);
+    igd_hip_db *dev = hm ? NULL : engine();
+    if (!hm && !dev) return 0;
     iGD_t *G = cur_igd();
     int64_t *qoff = (int64_t *)malloc(sizeof(int64_t) * (size_t)(q->n + 1));
     int64_t total = 0, grand = 0;
@@ -551,6 +575,16 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
     print_ctx P;
     P.q = q; P.names = names; P.G = G; P.flen = flen; P.maxL = maxL; P.nt = nt;
     memset(P.keep, 0, sizeof P.keep);
+    if (hm) {                                                    /* small file: the overlaps come from the host, the text as always */
+        igd_hip_hit *hit = NULL;
+        P.q0 = 0;
+        if (igdc_enumerate_host(g_core, hm, q->ichr, q->qs, q->qe, q->n, qoff, &hit, &total) == 0) {
+            print_chunk(&P, 0, q->n, qoff, hit);
+            grand = total;
+        }
+        free(hit);
+        igdc_map_close(hm);
+    } else
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
         P.q0 = q0;

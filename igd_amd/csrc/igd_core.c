@@ -82,20 +82,18 @@ igdc_db *igdc_open(const char *igd_path)
     db->nTileTotal = nT;
     db->dataOff = 12 + 44 * (int64_t)m + 4 * nT;
     db->nCntFlat = (int32_t *)calloc((size_t)nT + 1, sizeof(int32_t));
-    db->tIdxFlat = (int64_t *)calloc((size_t)nT + 1, sizeof(int64_t));
+    db->tBase = (int64_t *)calloc((size_t)(nT >> 6) + 2, sizeof(int64_t));
     db->nCnt = (int32_t **)calloc((size_t)m + 1, sizeof(int32_t *));
-    db->tIdx = (int64_t **)calloc((size_t)m + 1, sizeof(int64_t *));
     db->cName = (char **)calloc((size_t)m + 1, sizeof(char *));
-    if (!db->nCntFlat || !db->tIdxFlat || !db->nCnt || !db->tIdx || !db->cName) goto bad;
+    if (!db->nCntFlat || !db->tBase || !db->nCnt || !db->cName) goto bad;
     if (read_exact(fp, db->nCntFlat, sizeof(int32_t) * (size_t)nT) != 0) goto bad;
     const int64_t recBytes = db->gType == 0 ? 12 : 16;
     int64_t loc = db->dataOff, t = 0;
     for (int32_t c = 0; c < m; c++) {
         db->nCnt[c] = db->nCntFlat + t;
-        db->tIdx[c] = db->tIdxFlat + t;
         for (int32_t j = 0; j < db->nTile[c]; j++, t++) {
             if (db->nCntFlat[t] < 0) goto bad;
-            db->tIdxFlat[t] = loc;
+            if ((t & 63) == 0) db->tBase[t >> 6] = loc;
             loc += recBytes * (int64_t)db->nCntFlat[t];
             db->nRecords += db->nCntFlat[t];
         }
@@ -167,7 +165,7 @@ void igdc_close(igdc_db *db)
     if (db->fileName)
         for (int32_t i = 0; i < db->nFiles; i++) free(db->fileName[i]);
     free(db->cName); free(db->fileName); free(db->fileNr); free(db->fileMd);
-    free(db->nTile); free(db->nCntFlat); free(db->nCnt); free(db->tIdxFlat); free(db->tIdx);
+    free(db->nTile); free(db->nCntFlat); free(db->nCnt); free(db->tBase);
     free(db->dict);
     free(db);
 }
@@ -236,11 +234,12 @@ int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32
     for (int32_t j = n1; j <= (n2 > n1 ? n2 : n1); j++) {
         const int32_t cnt = db->nCnt[ichr][j];
         if (cnt <= 0) continue;
+        const int64_t off = igdc_tile_off(db, ichr, j);
         const size_t bytes = (size_t)cnt * recBytes;
         if (bytes > cap) { free(buf); buf = (int32_t *)malloc(bytes); cap = bytes; if (!buf) return -1; }
         size_t done = 0;
         while (done < bytes) {
-            ssize_t got = pread(fd, (char *)buf + done, bytes - done, (off_t)(db->tIdx[ichr][j] + (int64_t)done));
+            ssize_t got = pread(fd, (char *)buf + done, bytes - done, (off_t)(off + (int64_t)done));
             if (got <= 0) { free(buf); return -1; }
             done += (size_t)got;
         }

@@ -29,8 +29,10 @@ typedef struct igdc_db {
     int32_t *nTile;          /* [nCtg]                                                  */
     int32_t *nCntFlat;       /* sum(nTile), contig-major (file order)                   */
     int32_t **nCnt;          /* [nCtg] -> into nCntFlat                                 */
-    int64_t *tIdxFlat;       /* byte offset of each tile in the .igd                    */
-    int64_t **tIdx;          /* [nCtg] -> into tIdxFlat                                 */
+    int64_t *tBase;          /* byte offset in the .igd of every 64th tile (flat numbering): a per-tile table would be
+                                1.5 MB of fresh pages at roadmap scale -- 0.75 ms of page faults at every open, as much as
+                                the reference needs for its whole header -- for a number that is one short sum away   */
+    void    *reserved_;
     char   **cName;          /* [nCtg], each a 40-byte buffer as stored in the file     */
     char   **fileName;       /* [nFiles]                                                */
     int32_t *fileNr;
@@ -43,6 +45,15 @@ typedef struct igdc_db {
     int32_t     ndev;
     igd_hip_db *devs[IGDC_MAX_DEVICES];
 } igdc_db;
+
+/* byte offset of tile j of contig c in the .igd (what the reference keeps as tIdx[c][j], src/igd_base.c:288-303) */
+static inline int64_t igdc_tile_off(const igdc_db *db, int32_t c, int32_t j)
+{
+    const int64_t t = (db->nCnt[c] - db->nCntFlat) + j;
+    int64_t n = 0;
+    for (int64_t k = t & ~(int64_t)63; k < t; k++) n += db->nCntFlat[k];
+    return db->tBase[t >> 6] + n * (db->gType == 0 ? 12 : 16);
+}
 
 /* header tables of an .igd (no tile data is read) */
 igdc_db *igdc_open(const char *igd_path);
@@ -83,6 +94,29 @@ int igdc_devices_from_env(int *devices, int max);
 typedef void (*igdc_emit_fn)(void *ctx, int32_t idx, int32_t start, int32_t end, int32_t in_tile, int32_t tile);
 int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32_t qe, int32_t v, int use_v, int rule,
                       int64_t *hits, igdc_emit_fn emit, void *ctx);
+
+/* SMALL query files on the host (igd_hostpath.c; product code).  The reference starts cheaply -- header only, then the
+ * tiles a query touches (src/igd_base.c:269-323, src/igd_search.c:469-476) -- while the engine costs a fixed ~0.18 s of HIP
+ * start-up and upload: files of at most igdc_host_limit() queries (IGD_HOST_MAX_QUERIES; 0 = every file goes to the GPU) are
+ * counted from a read-only mapping of the .igd by a few host threads, the reference's per-query algorithm.  NOT a
+ * fallback: the choice depends on the number of queries only, never on whether a device is usable; larger files have
+ * no CPU path.  The engine's own entry points (igd_hip.h) never come here. */
+typedef struct igdc_map igdc_map;
+int64_t   igdc_host_limit(void);
+int       igdc_host_probably_small(const char *qfile);       /* by file size: parse it before starting the engine */
+igdc_map *igdc_map_open(const igdc_db *db, int fd);           /* fd stays the caller's */
+void      igdc_map_close(igdc_map *m);
+/* hits[] is ADDED to; *total = overlaps of the batch.  v = IGD_HIP_NO_VALUE_FILTER: no filter.  0 on success. */
+int igdc_search_host(const igdc_db *db, const igdc_map *m, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                     int64_t nq, int32_t v, int rule, int64_t *hits, int64_t *total);
+/* `-f` (rule NEST, the reference's order): qoff[0..nq] offsets, *out malloc'd (free()), entries as igd_hip_enumerate's */
+int igdc_enumerate_host(const igdc_db *db, const igdc_map *m, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                        int64_t nq, int64_t *qoff, igd_hip_hit **out, int64_t *total);
+
+/* handle flavours: small batch and no engine resident -> host; else the engine, attached (igdc_attach_path) when first needed.
+ * Returns IGD_HIP_OK or the engine's error code. */
+int igdc_search_auto(igdc_db *db, const char *path, int device, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                     int64_t nq, int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
 
 /* BED line -> (contig, start, end).  Mutates `line`.  require_chr=1 is the CLI rule
  * (name starts with "chr", shorter than 40, end > 0: src/igd_base.c:69); require_chr=0 is

@@ -153,7 +153,27 @@ extern "C" int igd_hip_device_count(void)
     return n;
 }
 
-extern "C" int64_t igd_hip_max_batch(void) { return IGD_MAX_BATCH; }
+// Queries per engine call of the HOST-buffer entry points (igd_hip_search*, igd_hip_enumerate*, igd_hip_seqpare*) and the
+// step of the command line tool's loops over longer query files.  IGD_MAX_BATCH in production; the TEST-ONLY variable
+// IGD_HIP_MAX_BATCH (read once per process) lowers it so that every multi-batch seam -- the loop of igd_hip_search_ex, the
+// `-f` and `-s` loops of igd_cli_abi.c -- is crossed by ordinary small fixtures (tests/test_gpu_batches.py).
+static int64_t max_batch(void)
+{
+    static const int64_t m = []() -> int64_t {
+        const char *e = getenv("IGD_HIP_MAX_BATCH");
+        const long long x = e && *e ? atoll(e) : 0;
+        return x >= 1 && x < IGD_MAX_BATCH ? (int64_t)x : (int64_t)IGD_MAX_BATCH;
+    }();
+    return m;
+}
+extern "C" int64_t igd_hip_max_batch(void) { return max_batch(); }
+
+// What this library was compiled as: bits 0..23 = IGD_EXP, bit 24 = IGD_EXP_NOMATCH.  A build with any bit of
+// IGD_HIP_BUILD_WRONG_COUNTS gives WRONG counts on purpose (measurement of kernel sections): igd_hip_open refuses to
+// work in such a build unless IGD_HIP_ALLOW_EXP_BUILD=1 says the caller knows (tools/valu_ab.sh does).
+#define IGD_EXP_WRONG_BITS (1 | 2 | 4 | 8 | 64 | 128 | 256 | 512 | 8192 | 0x10000 | 0x20000)
+extern "C" unsigned igd_hip_build_flags(void) { return ((unsigned)IGD_EXP & 0xffffffu) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
+extern "C" unsigned igd_hip_build_wrong_counts(void) { return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
 
 // ------------------------------------------------------------------------------------------
 // device view of one database (passed to kernels by value)
@@ -502,6 +522,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     int seen = 0;
     if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
     if (threadIdx.x < NW) sCnt[threadIdx.x] = 0;          // (a wave that leaves early counts as one without entries)
+    if (threadIdx.x == NW) sSeen = 0;                     // (defined also when wave 0 is the one that leaves before it stores the flag)
     if (ldsTab)
         for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
     __syncthreads();
@@ -3374,6 +3395,15 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         snprintf(g_err, sizeof g_err, "igd_hip_open: bad descriptor");
         return IGD_HIP_ERR_ARG;
     }
+    if (igd_hip_build_wrong_counts()) {
+        const char *ok = getenv("IGD_HIP_ALLOW_EXP_BUILD");
+        if (!ok || ok[0] != '1') {
+            snprintf(g_err, sizeof g_err, "igd_hip_open: this libigd_hip.so is a measurement build (IGD_EXP=0x%x) that gives WRONG counts; "
+                     "set IGD_HIP_ALLOW_EXP_BUILD=1 to use it anyway", igd_hip_build_flags());
+            return IGD_HIP_ERR_ARG;
+        }
+        fprintf(stderr, "igd_hip: WARNING: measurement build IGD_EXP=0x%x -- counts are WRONG on purpose\n", igd_hip_build_flags());
+    }
     int ndev = igd_hip_device_count();
     if (ndev <= 0) {
         if (!g_err[0]) snprintf(g_err, sizeof g_err, "igd_hip_open: no HIP device");
@@ -3670,6 +3700,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         const void *sfn[] = {IGD_SORTED_FNS(false, true), IGD_SORTED_FNS(true, true), IGD_SORTED_FNS(false, false), IGD_SORTED_FNS(true, false)};
 #undef IGD_SORTED_FNS
         for (const void *fn : sfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
+        if (db->nFiles <= 8) {       // FEW = 1 (one file) / 2 (up to eight): launch_scan's builds for databases of very few files
+            const void *ffn[] = {(const void *)igd_scan_sorted<false, true, true, false, false, 1>, (const void *)igd_scan_sorted<false, true, true, false, true, 1>,
+                                 (const void *)igd_scan_sorted<true, true, true, false, false, 1>, (const void *)igd_scan_sorted<true, true, true, false, true, 1>,
+                                 (const void *)igd_scan_sorted<false, true, true, false, false, 2>, (const void *)igd_scan_sorted<false, true, true, false, true, 2>,
+                                 (const void *)igd_scan_sorted<true, true, true, false, false, 2>, (const void *)igd_scan_sorted<true, true, true, false, true, 2>};
+            for (const void *fn : ffn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
+        }
         if (db->nWin > 1) {
             const void *wfn[] = {(const void *)igd_scan_sorted<false, true, true, false, false, 3>, (const void *)igd_scan_sorted<false, true, true, false, true, 3>,
                                  (const void *)igd_scan_sorted<true, true, true, false, false, 3>, (const void *)igd_scan_sorted<true, true, true, false, true, 3>};
@@ -3929,6 +3966,10 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         db->covStale = false;
     }
     db->epoch++;
+    // From here on kernels of this batch may have written the coverage difference arrays: ANY error exit before the batch's
+    // last launch (a failed hipEventRecord / hipGetLastError as much as a failed launch_split) must have them cleared
+    // before the next batch -- two batches later (same parity) long queries would otherwise add to stale +1 / -1 entries.
+    struct StaleGuard { igd_hip_db *d; bool done; ~StaleGuard() { if (!done) d->covStale = true; } } guard{db, false};
     int slot = -1;
     if (db->evOn && db->evUsed < db->evMax && (db->evSeen++ % (db->evEvery > 0 ? db->evEvery : 1)) == 0) slot = db->evUsed++;
     // the whole pipeline is bracketed for the first IGD_PIPE_EVENTS launches only: every event is one more packet in the
@@ -3972,7 +4013,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         else
             rc = launch_bucket(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                                       mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
-        if (rc != IGD_HIP_OK) { db->covStale = true; return rc; }
+        if (rc != IGD_HIP_OK) return rc;                 // (guard: covStale)
     }
     if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
     ScanArgs a;
@@ -4034,6 +4075,7 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
     if (mode == 1) db->promised = db->epoch;
     db->lastMode = mode; db->lastPacked = packed ? 1 : 0;
     HIPCHK(hipGetLastError());
+    guard.done = true;
     return IGD_HIP_OK;
 }
 
@@ -4097,8 +4139,9 @@ extern "C" int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int3
     hipStream_t st = db->stream;
     HIPCHK(hipMemsetAsync(db->d_hits, 0, (size_t)db->nFiles * 8, st));
     HIPCHK(hipMemsetAsync(db->d_total, 0, 8, st));
-    for (int64_t q0 = 0; q0 < nq; q0 += IGD_MAX_BATCH) {
-        int64_t m = nq - q0 < IGD_MAX_BATCH ? nq - q0 : IGD_MAX_BATCH;
+    const int64_t step = max_batch();
+    for (int64_t q0 = 0; q0 < nq; q0 += step) {
+        int64_t m = nq - q0 < step ? nq - q0 : step;
         const bool timing = db->timing;
         auto now = []() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
         double t0 = now();
@@ -4307,8 +4350,8 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
 extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                                  int64_t nq, int64_t *qoff, igd_hip_hit **out, int64_t *total)
 {
-    if (!db || !qoff || !out || nq < 0 || nq > IGD_MAX_BATCH || (nq > 0 && (!ichr || !qs || !qe))) {
-        snprintf(g_err, sizeof g_err, "igd_hip_enumerate: bad argument (batch limit %lld)", (long long)IGD_MAX_BATCH);
+    if (!db || !qoff || !out || nq < 0 || nq > max_batch() || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate: bad argument (batch limit %lld)", (long long)max_batch());
         return IGD_HIP_ERR_ARG;
     }
     *out = nullptr;
@@ -4321,8 +4364,8 @@ extern "C" int igd_hip_enumerate(igd_hip_db *db, const int32_t *ichr, const int3
 extern "C" int igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                                         int64_t nq, int64_t *qoff, igd_hip_enum_sink sink, void *ctx, int64_t *total)
 {
-    if (!db || !qoff || !sink || nq < 0 || nq > IGD_MAX_BATCH || (nq > 0 && (!ichr || !qs || !qe))) {
-        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: bad argument (batch limit %lld)", (long long)IGD_MAX_BATCH);
+    if (!db || !qoff || !sink || nq < 0 || nq > max_batch() || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: bad argument (batch limit %lld)", (long long)max_batch());
         return IGD_HIP_ERR_ARG;
     }
     if (total) *total = 0;
@@ -4491,9 +4534,9 @@ __global__ void k_seq_accumulate(const float *__restrict__ sel, const int32_t *_
 static int seqpare_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
                         const int32_t *qgroup, int32_t nGroups, double *sums, bool carry)
 {
-    if (!db || !sums || nq < 0 || nq > IGD_MAX_BATCH || nGroups < 0 || (nq > 0 && (!ichr || !qs || !qe || !qgroup)) ||
+    if (!db || !sums || nq < 0 || nq > max_batch() || nGroups < 0 || (nq > 0 && (!ichr || !qs || !qe || !qgroup)) ||
         (int64_t)nGroups * db->nFiles >= 0x7fffffffLL) {
-        snprintf(g_err, sizeof g_err, "igd_hip_seqpare: bad argument (batch limit %lld queries)", (long long)IGD_MAX_BATCH);
+        snprintf(g_err, sizeof g_err, "igd_hip_seqpare: bad argument (batch limit %lld queries)", (long long)max_batch());
         return IGD_HIP_ERR_ARG;
     }
     if (db->gType != 1) {

@@ -25,11 +25,16 @@ static int usage(int code)
  * the HIP runtime's exit handlers -- freeing a gigabyte of device memory, unloading code objects and tearing the
  * context down takes as long as the whole search (60-90 ms of a 0.25 s command), and the kernel driver reclaims all of it
  * anyway.  (IGD_CLEAN_EXIT=1: leave through exit() as usual, e.g. under a leak checker.) */
+int igd_hip_lazy_loaded(void);          /* libigd.so (igd_hip_lazy.c): has this process mapped the HIP engine? */
 static int leave(int rc)
 {
-    fflush(NULL);
+    /* a write that failed (full disk, closed pipe) must not look like success */
+    if ((fflush(NULL) != 0 || ferror(stdout)) && rc == 0) rc = EX_IOERR;
     const char *e = getenv("IGD_CLEAN_EXIT");
-    if (e && *e && *e != '0') return rc;
+    /* only a process that brought the HIP runtime up has those exit handlers to skip; everything else -- `-r`, small
+     * query files, usage errors -- and any run under a profiler / sanitizer / coverage tool (IGD_CLEAN_EXIT=1: they
+     * finalise in atexit) leaves through exit() as usual */
+    if ((e && *e && *e != '0') || !igd_hip_lazy_loaded()) return rc;
     _exit(rc);
 }
 

@@ -13,6 +13,7 @@
 
 struct iGD_t {
     igdc_db *core;          /* NULL until open_iGD */
+    char *path;             /* the engine is attached from it by the first batch that needs the GPU */
 };
 
 static int device_from_env(void)
@@ -48,6 +49,7 @@ void open_iGD(iGD_t *iGD, char *igdFile)
 {
     if (!iGD) return;
     if (iGD->core) { igdc_close(iGD->core); iGD->core = NULL; }
+    free(iGD->path); iGD->path = NULL;
     igdc_db *core = igdc_open(igdFile);
     if (!core) {
         printf("Can't open file %s", igdFile);
@@ -56,15 +58,17 @@ void open_iGD(iGD_t *iGD, char *igdFile)
     char *tsv = igdc_index_path(igdFile);
     if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
     free(tsv);
-    int rc = igdc_attach_path(core, igdFile, device_from_env());
-    if (rc != IGD_HIP_OK) { igdc_close(core); engine_failed("open_iGD", rc); return; }
+    /* header and index only, like the reference's open_iGD (src_py/igd_base.c); the tile region goes to the GPU when the
+     * first batch that is not small arrives (igdc_search_auto) */
     iGD->core = core;
+    iGD->path = strdup(igdFile);
 }
 
 void close_iGD(iGD_t *iGD)
 {
     if (!iGD) return;
     if (iGD->core) igdc_close(iGD->core);
+    free(iGD->path);
     free(iGD);
 }
 
@@ -107,8 +111,8 @@ void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
     if (!iGD || !iGD->core) return;
     int32_t ichr = igdc_get_id(iGD->core, chrm);
     if (ichr < 0) return;
-    int rc = igd_hip_search(iGD->core->dev, &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
-                            IGD_HIP_RULE_NEST, hits, NULL);
+    int rc = igdc_search_auto(iGD->core, iGD->path, device_from_env(), &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
+                              IGD_HIP_RULE_NEST, 0, hits, NULL);
     if (rc != IGD_HIP_OK) engine_failed("get_overlaps", rc);
 }
 
@@ -119,8 +123,8 @@ int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
     if (igdc_read_queries(iGD->core, qFile, 0, &q) != 0) return 0;
     (void)igdc_queries_group_contigs(&q, iGD->core->nCtg);    /* a sorted BED with another chromosome order than the database's */
     if (q.n > 0) {
-        int rc = igd_hip_search_ex(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                   IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
+        int rc = igdc_search_auto(iGD->core, iGD->path, device_from_env(), q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                  IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
         if (rc != IGD_HIP_OK) { engine_failed("getOverlaps", rc); igdc_queries_free(&q); return 0; }
     }
     igdc_queries_free(&q);

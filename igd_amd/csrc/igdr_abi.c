@@ -46,8 +46,8 @@ iGD_t *open_iGD(char *igdFile)
     char *tsv = igdc_index_path(igdFile);
     if (igdc_load_index(core, tsv) != 0) printf("file not found:%s\n", tsv);
     free(tsv);
-    int rc = igdc_attach_path(core, igdFile, device_from_env());
-    if (rc != IGD_HIP_OK) { igdc_close(core); engine_failed("open_iGD", rc); return NULL; }
+    /* header and index only, like the reference's open_iGD (IGDr/src/igd_base.c); the tile region goes to the GPU when the
+     * first batch that is not small arrives (igdc_search_auto) */
     iGD_t *h = (iGD_t *)calloc(1, sizeof *h);
     h->core = core;
     h->path = strdup(igdFile);
@@ -72,8 +72,8 @@ void get_overlaps(iGD_t *iGD, char *chrm, int32_t qs, int32_t qe, int64_t *hits)
     if (!iGD) return;
     int32_t ichr = igdc_get_id(iGD->core, chrm);
     if (ichr < 0) return;
-    int rc = igd_hip_search(iGD->core->dev, &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
-                            IGD_HIP_RULE_NEST, hits, NULL);
+    int rc = igdc_search_auto(iGD->core, iGD->path, device_from_env(), &ichr, &qs, &qe, 1, IGD_HIP_NO_VALUE_FILTER,
+                              IGD_HIP_RULE_NEST, 0, hits, NULL);
     if (rc != IGD_HIP_OK) engine_failed("get_overlaps", rc);
 }
 
@@ -90,8 +90,8 @@ void igdr_search_n32(iGD_t *iGD, int32_t n, const char *const *chrm, const int32
     const int32_t nf = iGD->core->nFiles;
     int64_t *h64 = (int64_t *)calloc((size_t)nf + 1, sizeof(int64_t));
     if (q.n > 0) {
-        int rc = igd_hip_search(iGD->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                IGD_HIP_RULE_NEST, h64, NULL);
+        int rc = igdc_search_auto(iGD->core, iGD->path, device_from_env(), q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                  IGD_HIP_RULE_NEST, 0, h64, NULL);
         if (rc != IGD_HIP_OK) { engine_failed("search", rc); memset(h64, 0, sizeof(int64_t) * (size_t)nf); }
     }
     for (int32_t f = 0; f < nf; f++) hits[f] = (int32_t)((int64_t)hits[f] + h64[f]);
@@ -135,8 +135,8 @@ void getOverlaps(char **igdFile, char **qFile, int64_t *hits)
     if (igdc_read_queries(h->core, *qFile, 0, &q) == 0) {
         (void)igdc_queries_group_contigs(&q, h->core->nCtg);  /* a sorted BED with another chromosome order than the database's */
         if (q.n > 0) {
-            int rc = igd_hip_search_ex(h->core->dev, q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                       IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
+            int rc = igdc_search_auto(h->core, h->path, device_from_env(), q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
+                                      IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
             if (rc != IGD_HIP_OK) engine_failed("getOverlaps", rc);
         }
         igdc_queries_free(&q);
@@ -272,7 +272,7 @@ SEXP get_binData(SEXP igdr, SEXP ichr, SEXP bin)
     const size_t rb = c->gType == 0 ? 12 : 16;
     int32_t *raw = (int32_t *)malloc(rb * (size_t)n);
     FILE *fp = fopen(h->path, "rb");
-    if (!fp || fseeko(fp, (off_t)c->tIdx[i][j], SEEK_SET) != 0 || fread(raw, rb, (size_t)n, fp) != (size_t)n) {
+    if (!fp || fseeko(fp, (off_t)igdc_tile_off(c, i, j), SEEK_SET) != 0 || fread(raw, rb, (size_t)n, fp) != (size_t)n) {
         if (fp) fclose(fp);
         free(raw);
         return R_NilValue;

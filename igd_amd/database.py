@@ -5,6 +5,7 @@ Mirrors what the reference's front-ends do around the hot path -- load header + 
 and hands every search to the HIP engine (include/igd_hip.h).  numpy arrays for host
 batches; raw device pointers (e.g. torch tensors' data_ptr()) for resident batches."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -28,6 +29,10 @@ class Database:
     def __init__(self, igd_path, device=0):
         self._L = N.cli()
         self._H = N.hip()
+        self.build_flags = int(self._H.igd_hip_build_flags())
+        if self._H.igd_hip_build_wrong_counts() and os.environ.get("IGD_HIP_ALLOW_EXP_BUILD") != "1":
+            raise IgdError("%s is a measurement build (IGD_EXP=0x%x) whose counts are WRONG on purpose; "
+                           "IGD_HIP_ALLOW_EXP_BUILD=1 loads it anyway" % (os.path.join(N.LIBDIR, "libigd_hip.so"), self.build_flags))
         self.path = igd_path
         self._core = self._L.igdc_open(igd_path.encode())
         if not self._core:

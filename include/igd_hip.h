@@ -121,7 +121,7 @@ int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, co
 int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
                        const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                        int64_t *d_hits, int64_t *d_total, void *stream);
-int64_t igd_hip_max_batch(void);
+int64_t igd_hip_max_batch(void);   /* queries per call of the host-buffer entry points (2^24; test-only IGD_HIP_MAX_BATCH lowers it) */
 int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
 
 /* `-f`: full enumeration in reference order (queries in batch order; per query tiles
@@ -191,6 +191,13 @@ typedef struct {
 } igd_hip_created;
 int  igd_hip_create(const igd_hip_create_desc *d, int device, igd_hip_created *out);
 void igd_hip_created_free(igd_hip_created *c);
+
+/* What the loaded library was compiled as.  igd_hip_build_flags(): bits 0..23 = the IGD_EXP experiment mask of the build
+ * (0 in a shipped library), bit 24 = IGD_EXP_NOMATCH.  igd_hip_build_wrong_counts(): the subset of those bits that make the
+ * kernels give WRONG counts on purpose (section-by-section measurement builds, tools/valu_ab.sh).  igd_hip_open refuses
+ * such a library unless IGD_HIP_ALLOW_EXP_BUILD=1 is set, and igd_amd.Database refuses it outright. */
+unsigned igd_hip_build_flags(void);
+unsigned igd_hip_build_wrong_counts(void);
 
 /* Instrumentation ------------------------------------------------------------------- */
 /* Exact algorithmic-work terms for a device-resident batch (blocking). */

@@ -329,7 +329,7 @@ def build_r_call_harness(outdir):
            "-Werror=incompatible-pointer-types", "-DIGDR_HAVE_R",
            "-I" + os.path.join(ROOT, "tests", "mock_r"), "-I" + os.path.join(ROOT, "include"), "-I" + src, "-I" + os.path.join(ROOT, "tools"),
            "-o", exe, os.path.join(ROOT, "tests", "c", "r_call_main.c"), os.path.join(ROOT, "tests", "mock_r", "mock_r.c"),
-           os.path.join(src, "igdr_abi.c"), os.path.join(src, "igd_core.c"), os.path.join(src, "igd_create.c"),
+           os.path.join(src, "igdr_abi.c"), os.path.join(src, "igd_core.c"), os.path.join(src, "igd_hostpath.c"), os.path.join(src, "igd_create.c"),
            "-L" + lib, "-ligd_hip", "-lz", "-lpthread", "-Wl,-rpath," + lib]
     subprocess.check_call(cmd)
     return exe

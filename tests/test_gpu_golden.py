@@ -212,40 +212,6 @@ def test_reference_main_linked_against_libigd_prints_reference_output():
         shutil.rmtree(d, ignore_errors=True)
 
 
-def test_reference_cython_wrapper_on_libigd_py_returns_what_it_returned_on_the_reference():
-    """the reference's UNCHANGED src_py/igd_py.pyx, built by oracle/build_ref_pyx.py against
-    libigd_py.so (only setup.py differs), driven like the reference's src_py/igd_test.py; tests/golden/pywrap.json
-    holds what the same wrapper returned when it sat on the reference's own C code."""
-    import glob
-    import sys
-    pyx_dir = os.path.join(ROOT, "oracle", "_ref", "pyx")
-    if not glob.glob(os.path.join(pyx_dir, "igd_py*.so")):
-        pytest.skip("oracle/_ref/pyx/igd_py*.so not built (needs /root/reference and Cython at build time)")
-    pins = json.load(open(os.path.join(GOLDEN, "pywrap.json")))
-    code = r"""
-import sys, json
-sys.path.insert(0, %r)
-import numpy as np
-import igd_py as iGD                       # the reference's module name and class
-igd = iGD.igd_py()
-igd.open(%r)
-n = igd.get_nFiles()
-hits = np.zeros(n, dtype='int64')
-tot = igd.search_n(%r, hits)
-out = {'nFiles': n, 'search_n_return': int(tot), 'search_n_hits': hits.tolist(), 'search_1': {}}
-for key in %r:
-    c, rng = key.split(':'); s, e = rng.split('-')
-    v = np.zeros(n, dtype='int64')
-    igd.search_1(c, int(s), int(e), v)
-    out['search_1'][key] = v.tolist()
-print(json.dumps(out))
-""" % (pyx_dir, os.path.join(GOLDEN, "smallrand", "db.igd"), os.path.join(GOLDEN, "smallrand", "q.bed"), list(pins["search_1"].keys()))
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert p.returncode == 0, p.stderr.decode()[-800:]
-    got = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    assert got == pins
-
-
 def test_f_output_does_not_depend_on_the_number_of_formatting_threads():
     """`-f` text is produced by several threads (contiguous query ranges, written in order): any thread count must
     give the reference's bytes."""

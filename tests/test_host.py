@@ -231,8 +231,10 @@ def test_no_gpu_means_loud_failure_not_a_cpu_fallback(N):
     with pytest.raises(IgdError, match="no CPU search path"):
         Database(os.path.join(GOLDEN, "edge", "db.igd"))
     exe = os.path.join(ROOT, "bin", "igd")
+    # (query files of at most IGD_HOST_MAX_QUERIES lines are the host's by design -- tests/test_hostpath.py; a batch for the
+    # engine, which every file is with the limit at 0, has no CPU path)
     p = subprocess.run([exe, "search", os.path.join(GOLDEN, "edge", "db.igd"), "-q", os.path.join(GOLDEN, "edge", "q.bed")],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, IGD_HOST_MAX_QUERIES="0"))
     assert p.returncode == 69 and b"no CPU search path" in p.stderr and b"Total" not in p.stdout
     # ... and the package never imports the oracle
     src = "".join(open(os.path.join(ROOT, "igd_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "igd_amd")) if f.endswith(".py"))
@@ -253,20 +255,24 @@ from igd_amd import igd_py as P
 db, q = %r, %r
 if N.hip().igd_hip_device_count() > 0:
     os.environ["IGD_DEVICE"] = "99"
-# handle flavour through the ctypes twin of the .pyx class: raises, interpreter alive
+os.environ["IGD_HOST_MAX_QUERIES"] = "0"     # every batch is the engine's (small files would be the host's: tests/test_hostpath.py)
+# handle flavour through the ctypes twin of the .pyx class: open reads header + index only (like the reference's); the
+# batch that needs the engine raises, interpreter alive
 h = P.igd_py()
+h.open(db)
+n = h.get_nFiles(); assert n == 10
+hits = np.zeros(n, np.int64)
 try:
-    h.open(db); print("NO-RAISE")
+    h.search_n(q, hits); print("NO-RAISE")
 except P.IgdEngineError as e:
     print("py raised:", "no CPU search path" in str(e))
-hits = np.zeros(8, np.int64)
-assert h.search_n(q, hits) == 0 and not hits.any() and h.get_nFiles() == 0   # handle stayed closed
+assert not hits.any()
 # R flavour (.C entry points)
 R = N.rabi()
-assert R.open_iGD(db.encode()) is None and R.igd_engine_status() != 0
+assert R.igd_engine_status() == 0
 hits[:] = 0
 a, b = C.c_char_p(db.encode()), C.c_char_p(q.encode())
-R.getOverlaps(C.byref(a), C.byref(b), hits.ctypes.data_as(N.i64p)); assert not hits.any()
+R.getOverlaps(C.byref(a), C.byref(b), hits.ctypes.data_as(N.i64p)); assert not hits.any() and R.igd_engine_status() != 0
 # CLI flavour as a library
 L = N.cli()
 g = L.get_igdinfo(db.encode()); assert g
@@ -394,13 +400,20 @@ def test_r_call_entry_points_compile_against_a_mock_of_the_r_api():
     IGDr/src/igd_base.c:382-461) cannot be built against R here -- the image has none -- so they are compiled, with
     implicit declarations and pointer mismatches as errors, against a MOCK of the few R C-API names they use
     (tests/mock_r, plainly labelled: not R) and linked with a harness that calls every one of them
-    (tests/c/r_call_main.c; run on the GPU box: tests/test_gpu_golden.py).  Here, without a GPU: iGD_new must raise an R
-    error that names the reason -- not crash, not end the process on its own."""
+    (tests/c/r_call_main.c; with the engine on the GPU box: tests/test_gpu_golden.py).  Here, without a GPU: iGD_new reads
+    header + index only (like the reference's), the small search_nr batch is the host's (igd_hostpath.c), and every check of
+    the harness passes; with the host path off (limit 0) the batch needs the engine and search_nr raises an R error that
+    names the reason -- not a crash, not an exit."""
     from helpers import build_r_call_harness
     d = short_tmpdir("igr")
     try:
         exe = build_r_call_harness(d)
-        p = subprocess.run([exe, os.path.join(GOLDEN, "smallrand", "db.igd")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        db = os.path.join(GOLDEN, "smallrand", "db.igd")
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+        env.pop("IGD_HOST_MAX_QUERIES", None)
+        p = subprocess.run([exe, db, "gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+        assert p.returncode == 0 and b"R-CALL-OK" in p.stdout and b"search_nr" in p.stdout, (p.returncode, p.stdout.decode(), p.stderr.decode()[-800:])
+        p = subprocess.run([exe, db, "gpu"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=dict(env, IGD_HOST_MAX_QUERIES="0"))
         assert p.returncode == 3 and b"mock Rf_error outside a guarded call" in p.stderr and b"GPU engine" in p.stderr, \
             (p.returncode, p.stdout.decode(), p.stderr.decode()[-800:])
     finally:

@@ -1,6 +1,10 @@
 """The reference's UNCHANGED Cython wrapper (src_py/igd_py.pyx) compiles and links against
 libigd_py.so with only setup.py changed, as INTEGRATION.md says.  Needs /root/reference (build
-container); the .pyx is read from there at test time, never copied into the repo."""
+container, CPU only); the .pyx is read from there at test time and everything built from it lives and
+dies in a directory under /tmp: nothing of the reference's wrapper -- source, generated C or compiled
+module -- enters the repository or travels to the GPU box.  What the wrapper's batch call returns on the
+GPU is pinned through the ctypes class against the same tests/golden/pywrap.json (tests/test_gpu_golden.py)."""
+import json
 import os
 import shutil
 import subprocess
@@ -34,5 +38,19 @@ def test_unchanged_pyx_builds_against_libigd_py():
                 "print('nFiles', g.get_nFiles()); del g" % d)
         out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, check=True).stdout.decode()
         assert "nFiles 0" in out          # a never-opened handle: 0 files, and dropping it is safe
+        # open / get_nFiles / search_1 (answered on the host from the interval's own tiles: no GPU needed) return
+        # what the same wrapper returned on the reference's own C code (tests/golden/pywrap.json)
+        pins = json.load(open(os.path.join(ROOT, "tests", "golden", "pywrap.json")))
+        code = ("import sys, json; sys.path.insert(0, %r); import numpy as np; import igd_py as iGD\n"
+                "igd = iGD.igd_py(); igd.open(%r); n = igd.get_nFiles(); out = {'nFiles': n, 'search_1': {}}\n"
+                "for key in %r:\n"
+                "    c, rng = key.split(':'); s, e = rng.split('-'); v = np.zeros(n, dtype='int64')\n"
+                "    igd.search_1(c, int(s), int(e), v); out['search_1'][key] = v.tolist()\n"
+                "print(json.dumps(out))\n"
+                % (d, os.path.join(ROOT, "tests", "golden", "smallrand", "db.igd"), list(pins["search_1"].keys())))
+        p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-800:]
+        got = json.loads(p.stdout.decode().strip().splitlines()[-1])
+        assert got["nFiles"] == pins["nFiles"] and got["search_1"] == pins["search_1"]
     finally:
         shutil.rmtree(d, ignore_errors=True)

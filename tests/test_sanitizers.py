@@ -1,9 +1,10 @@
 """AddressSanitizer + UBSan over the HOST C code (CPU build only; GPU sanitizers are not available):
   - the oracle CLI on every golden command line and on `create`;
-  - the product's host code (igd_main.c, igd_cli_abi.c, igd_core.c, igd_create.c) up to the point where
-    it needs the GPU: on this GPU-less host `create` parses all its input (threads, dictionaries, the
+  - the product's host code (igd_main.c, igd_cli_abi.c, igd_core.c, igd_hostpath.c, igd_create.c) up to the point
+    where it needs the GPU: on this GPU-less host `create` parses all its input (threads, dictionaries, the
     sequential re-parse for mixed columns, long-line cutting) and then fails loudly; `search` reads the
-    header and the index.  Any sanitizer report fails the test.
+    header and the index and answers the small golden query files on the host (igd_hostpath.c: -q, -v, -f, 1 and
+    5 threads) with the reference's bytes.  Any sanitizer report fails the test.
 """
 import glob
 import json
@@ -28,12 +29,13 @@ def sanbin():
     subprocess.check_call(["gcc", "-std=gnu99", *SAN, "-o", orc, "oracle/igd_oracle.c", "oracle/igd_oracle_create.c",
                            "oracle/igd_oracle_main.c", "-lz"], cwd=ROOT)
     igd = os.path.join(d, "igd_san")
-    src = ["igd_amd/csrc/igd_main.c", "igd_amd/csrc/igd_cli_abi.c", "igd_amd/csrc/igd_core.c", "igd_amd/csrc/igd_create.c"]
+    src = ["igd_amd/csrc/igd_main.c", "igd_amd/csrc/igd_cli_abi.c", "igd_amd/csrc/igd_core.c", "igd_amd/csrc/igd_hostpath.c", "igd_amd/csrc/igd_create.c",
+           "igd_amd/csrc/igd_hip_lazy.c"]                    # the engine library is dlopen'ed through the rpath at the first engine call
     subprocess.check_call(["gcc", "-std=gnu99", *SAN, "-Iinclude", "-Iigd_amd/csrc", "-o", igd, *src,
-                           "-Ligd_amd/lib", "-ligd_hip", "-lz", "-lpthread", "-Wl,-rpath," + os.path.join(ROOT, "igd_amd/lib")], cwd=ROOT)
+                           "-lz", "-lpthread", "-ldl", "-Wl,-rpath," + os.path.join(ROOT, "igd_amd/lib")], cwd=ROOT)
     ing = os.path.join(d, "ingest_san")
     subprocess.check_call(["gcc", "-std=gnu99", *SAN, "-Iinclude", "-Iigd_amd/csrc", "-o", ing, "tests/c/ingest_san_main.c",
-                           "igd_amd/csrc/igd_core.c", "-Ligd_amd/lib", "-ligd_hip", "-lz", "-lpthread",
+                           "igd_amd/csrc/igd_core.c", "igd_amd/csrc/igd_hostpath.c", "-Ligd_amd/lib", "-ligd_hip", "-lz", "-lpthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "igd_amd/lib")], cwd=ROOT)
     yield {"orc": orc, "igd": igd, "ingest": ing, "dir": d}
     shutil.rmtree(d, ignore_errors=True)
@@ -101,15 +103,26 @@ def test_create_host_code_clean(sanbin, mode):
 def test_search_host_code_clean_until_the_gpu_is_needed(sanbin):
     if gpu_present():
         pytest.skip("host ASan build is exercised on GPU-less hosts only")
-    case = os.path.join(GOLDEN, "parse")
-    d = short_tmpdir("igs")
-    try:
-        dst = os.path.join(d, "c")
-        shutil.copytree(case, dst)
-        for run in json.load(open(os.path.join(case, "manifest.json")))["runs"][:4]:
-            run_clean([sanbin["igd"]] + run["args"], cwd=dst)
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
+    n = 0
+    for fam in ("parse", "edge", "quirk", "gtype0", "smallrand"):
+        case = os.path.join(GOLDEN, fam)
+        d = short_tmpdir("igs")
+        try:
+            dst = os.path.join(d, "c")
+            shutil.copytree(case, dst)
+            for run in json.load(open(os.path.join(case, "manifest.json")))["runs"]:
+                if "-o" in run["args"] or "-s" in run["args"] or "-m" in run["args"]:
+                    continue
+                for threads in ("1", "5"):
+                    p = subprocess.run([sanbin["igd"]] + run["args"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=dst,
+                                       env=dict(ENV, IGD_HOST_THREADS=threads))
+                    err = p.stderr.decode(errors="replace")
+                    assert "AddressSanitizer" not in err and "runtime error" not in err and p.returncode == 0, err[-3000:]
+                    assert p.stdout.decode() == open(os.path.join(dst, run["stdout"])).read(), (fam, run["args"])
+                    n += 1
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    assert n >= 40
 
 
 def test_query_ingest_clean_threaded_and_sequential(sanbin):

@@ -35,6 +35,11 @@ def main():
         "config2_sorted_q1000000": (synth.make_queries(1000000, seed=7, genome=synth.HG38, sorted_=True), (0, 500)),
         "config4_share_q12500000": (synth.make_queries_slab(PER_GPU, 0, PER_GPU, seed=7, genome=synth.HG38), (0, 500)),
         "config4_slab0_of_8": (synth.make_queries_slab(8 * PER_GPU, 0, PER_GPU, seed=7, genome=synth.HG38), (0, 500)),
+        # config 4 is not pinned on slab 0 alone: a slab from the middle and the last one of the 10^8-query set
+        "config4_slab3_of_8": (synth.make_queries_slab(8 * PER_GPU, 3 * PER_GPU, 4 * PER_GPU, seed=7, genome=synth.HG38), (0,)),
+        "config4_slab7_of_8": (synth.make_queries_slab(8 * PER_GPU, 7 * PER_GPU, 8 * PER_GPU, seed=7, genome=synth.HG38), (0, 500)),
+        # a query FILE beyond one device batch (2^24): what `bin/igd search -q` loops over (tests/test_gpu_batches.py)
+        "cli_sorted_q20000000": (synth.make_queries(20000000, seed=11, genome=synth.HG38, sorted_=True), (0,)),
         "config4_slab0_of_2": (synth.make_queries_slab(2 * PER_GPU, 0, PER_GPU, seed=7, genome=synth.HG38), (0,)),
         "config4_slab1_of_2": (synth.make_queries_slab(2 * PER_GPU, PER_GPU, 2 * PER_GPU, seed=7, genome=synth.HG38), (0,)),
         # queries of 6 .. 13 tiles: coverage difference arrays + exact walk of the last tile

@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for d in $root/igd_amd/lib $root/igd_amd/libv_*; do
   [ -f $d/libigd_hip.so ] || continue
   tag=$(basename $d)
+  export IGD_HIP_ALLOW_EXP_BUILD=1   # the section variants give wrong counts on purpose
   for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_WAVES"; do
     g=$(echo $grp | tr ' ' '_')
     IGD_AMD_LIBDIR=$d rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag/$g -- python3 $root/bench.py --no-cpu --no-extra --no-cold --steps 6 --warmup 2 "$@" > /dev/null 2>&1
