@@ -375,9 +375,11 @@ class Job:
         self.d_qe = torch.from_numpy(qe).to(dev)
         self.d_hits = torch.zeros(max(db.nfiles, 1), dtype=torch.int64, device=dev)
 
-    def step(self):
+    def step(self, zero_first=False):
+        """One pass of the hot path over the resident batch; zero_first: the batch's first kernel clears hits[]
+        (IGD_HIP_FLAG_ZERO_FIRST) -- the job's accumulator starts from zero without a launch of its own."""
         self.db.search_dev(self.d_ichr.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr(), self.Q,
-                           self.d_hits.data_ptr(), None, v=self.v, stream=self.stream, flags=self.gflags)
+                           self.d_hits.data_ptr(), None, v=self.v, stream=self.stream, flags=self.gflags | (8 if zero_first else 0))
 
     def run(self, steps, warmup, barrier=lambda: None, collective=lambda t: None):
         """W untimed steps, then exactly K steps + the path's one collective between barrier+synchronize."""
@@ -391,11 +393,13 @@ class Job:
         # the dominant kernel is timed with HIP events on its own stream on every 4th step of the timed region (an event
         # is one more packet between two kernels: timing every step costs the job ~4 us per step)
         self.db.profile_begin(steps, every=4 if steps >= 16 else 1)
+        spin = not os.environ.get("IGD_BENCH_NO_SPIN")
         t0 = time.perf_counter()
-        self.d_hits.zero_()
-        for _ in range(steps):
-            self.step()
+        for k in range(steps):
+            self.step(zero_first=(k == 0))      # hits[] of the job starts from zero: cleared by the first batch's first kernel
         collective(self.d_hits)                 # the one collective of the path
+        if spin:                                # poll the stream instead of sleeping on its signal: the job ends when its last
+            self.db.sync(self.stream, spin=True)  # kernel does, not an interrupt later (0.1 ms of a 2 ms job at --steps 20)
         torch.cuda.synchronize(self.dev)
         barrier()
         t1 = time.perf_counter()

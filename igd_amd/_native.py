@@ -90,7 +90,7 @@ class CoreDb(C.Structure):
                 ("fileNr", i32p), ("fileMd", C.POINTER(C.c_double)),
                 ("nTileTotal", C.c_int64), ("nRecords", C.c_int64), ("dataOff", C.c_int64),
                 ("dict", i32p), ("dictCap", C.c_int32), ("dev", C.c_void_p),
-                ("ndev", C.c_int32), ("devs", C.c_void_p * 16)]
+                ("ndev", C.c_int32), ("devs", C.c_void_p * 16), ("grp", C.c_void_p)]
 
 
 class CoreQueries(C.Structure):
@@ -145,6 +145,7 @@ def hip():
         L.igd_hip_build_flags.restype = C.c_uint
         L.igd_hip_build_wrong_counts.restype = C.c_uint
         L.igd_hip_sync.argtypes = [C.c_void_p, C.c_void_p]
+        L.igd_hip_sync_spin.argtypes = [C.c_void_p, C.c_void_p]
         L.igd_hip_enumerate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.POINTER(C.POINTER(HipHit)), i64p]
         L.igd_hip_free.argtypes = [C.c_void_p]

@@ -103,7 +103,11 @@ static igd_hip_db *engine(void)
      * query files are searched in contiguous slabs, one per device (igdc_search_multi) */
     int devs[IGDC_MAX_DEVICES];
     const int nd = g_core_path ? igdc_devices_from_env(devs, IGDC_MAX_DEVICES) : 0;
-    int rc = nd > 1 ? igdc_attach_path_multi(g_core, g_core_path, devs, nd)
+    /* (IGD_MULTI_REDUCE=rccl with ONE listed device still goes through the group: a one-rank communicator and all-reduce --
+     * how the RCCL call-site is exercised on a one-GPU box, tests/test_gpu_multidev.py) */
+    const char *mr = getenv("IGD_MULTI_REDUCE");
+    const int group = nd > 1 || (nd == 1 && mr && !strcmp(mr, "rccl"));
+    int rc = group ? igdc_attach_path_multi(g_core, g_core_path, devs, nd)
            : g_core_path ? igdc_attach_path(g_core, g_core_path, nd == 1 ? devs[0] : device_from_env())
                          : igdc_attach_fp(g_core, fP, device_from_env());
     if (rc != IGD_HIP_OK) { engine_failed("open", rc); return NULL; }
@@ -292,7 +296,7 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
         t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
         int rc = !dev ? IGD_HIP_OK
-               : g_core->ndev > 1 ? igdc_search_multi(g_core, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total)
+               : g_core->grp ? igdc_search_multi(g_core, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total)
                : igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
         if (rc != IGD_HIP_OK) { engine_failed("search", rc); total = 0; }
         phase("search (H2D + kernels + D2H)", &t0);

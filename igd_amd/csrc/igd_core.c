@@ -158,6 +158,7 @@ int igdc_load_index(igdc_db *db, const char *tsv_path)
 void igdc_close(igdc_db *db)
 {
     if (!db) return;
+    if (db->grp) { igd_hip_group_destroy(db->grp); db->grp = NULL; }
     for (int k = 1; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);   /* devs[0] == dev */
     if (db->dev) igd_hip_close(db->dev);
     if (db->cName)
@@ -178,6 +179,7 @@ static int attach_records(igdc_db *db, const void *records, int fd, int device)
     d.nbp = db->nbp; d.gType = db->gType; d.nCtg = db->nCtg; d.nFiles = db->nFiles;
     d.nTile = db->nTile; d.nCnt = db->nCntFlat; d.records = records; d.nRecords = db->nRecords;
     d.fd = fd; d.fd_offset = db->dataOff;
+    if (db->grp) { igd_hip_group_destroy(db->grp); db->grp = NULL; }
     for (int k = 1; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);
     db->ndev = 0;
     if (db->dev) { igd_hip_close(db->dev); db->dev = NULL; }
@@ -292,6 +294,7 @@ static void *attach_run(void *arg)
 int igdc_attach_path_multi(igdc_db *db, const char *igd_path, const int *devices, int n)
 {
     if (n < 1 || n > IGDC_MAX_DEVICES) return IGD_HIP_ERR_ARG;
+    if (db->grp) { igd_hip_group_destroy(db->grp); db->grp = NULL; }
     for (int k = 0; k < db->ndev; k++) if (db->devs[k]) igd_hip_close(db->devs[k]);
     db->ndev = 0; db->dev = NULL;
     attach_job job[IGDC_MAX_DEVICES];
@@ -315,58 +318,27 @@ int igdc_attach_path_multi(igdc_db *db, const char *igd_path, const int *devices
     for (int k = 0; k < n; k++) db->devs[k] = job[k].out;
     db->ndev = n;
     db->dev = db->devs[0];
+    /* the devices as one group: the communicators of the path's one exchange are built once, here */
+    rc = igd_hip_group_create(db->devs, n, &db->grp);
+    if (rc != IGD_HIP_OK) {
+        for (int k = 0; k < n; k++) { igd_hip_close(db->devs[k]); db->devs[k] = NULL; }
+        db->ndev = 0; db->dev = NULL;
+        return rc;
+    }
+    const char *tm = getenv("IGD_TIMING");
+    if (tm && *tm && *tm != '0')
+        fprintf(stderr, "[igd timing] %d devices, hits[] summed by: %s%s%s\n", n, igd_hip_group_reduce_kind(db->grp),
+                igd_hip_group_reduce_note(db->grp)[0] ? " -- " : "", igd_hip_group_reduce_note(db->grp));
     return IGD_HIP_OK;
-}
-
-typedef struct {
-    igd_hip_db *dev; const int32_t *ichr, *qs, *qe; int64_t n; int32_t v; int rule, flags;
-    int64_t *hits, total; int rc; char err[256];
-} slab_job;
-static void *slab_run(void *arg)
-{
-    slab_job *J = (slab_job *)arg;
-    J->rc = igd_hip_search_ex(J->dev, J->ichr, J->qs, J->qe, J->n, J->v, J->rule, J->flags, J->hits, &J->total);
-    if (J->rc != IGD_HIP_OK) snprintf(J->err, sizeof J->err, "%s", igd_hip_last_error());
-    return NULL;
 }
 
 int igdc_search_multi(igdc_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
                       int32_t v, int rule, int flags, int64_t *hits, int64_t *total)
 {
-    const int n = db->ndev;
-    if (n < 1) return IGD_HIP_ERR_ARG;
-    if (n == 1 || nq < n) return igd_hip_search_ex(db->devs[0], ichr, qs, qe, nq, v, rule, flags, hits, total);
-    slab_job job[IGDC_MAX_DEVICES];
-    pthread_t th[IGDC_MAX_DEVICES];
-    int started[IGDC_MAX_DEVICES];
-    const int32_t nf = db->nFiles;
-    int64_t *part = (int64_t *)calloc((size_t)n * (size_t)(nf + 1), sizeof(int64_t));
-    if (!part) return IGD_HIP_ERR_NOMEM;
-    const int64_t base = nq / n, rem = nq % n;              /* the slab rule of igd_amd/dist.py shard_bounds */
-    for (int r = 0; r < n; r++) {
-        const int64_t lo = r * base + (r < rem ? r : rem), m = base + (r < rem ? 1 : 0);
-        slab_job *J = &job[r];
-        J->dev = db->devs[r]; J->ichr = ichr + lo; J->qs = qs + lo; J->qe = qe + lo; J->n = m;
-        J->v = v; J->rule = rule; J->flags = flags; J->hits = part + (size_t)r * (size_t)(nf + 1); J->total = 0;
-        J->rc = IGD_HIP_OK; J->err[0] = 0;
-        started[r] = r > 0 && pthread_create(&th[r], NULL, slab_run, J) == 0;
-        if (r > 0 && !started[r]) slab_run(J);
-    }
-    slab_run(&job[0]);
-    int rc = IGD_HIP_OK;
-    int64_t tot = 0;
-    for (int r = 0; r < n; r++) {
-        if (started[r]) pthread_join(th[r], NULL);
-        if (job[r].rc != IGD_HIP_OK && rc == IGD_HIP_OK) { rc = job[r].rc; igd_hip_set_error_(job[r].err); }
-        tot += job[r].total;
-    }
-    if (rc == IGD_HIP_OK) {                                  /* the one exchange of the path: sum of the n vectors */
-        for (int r = 0; r < n; r++)
-            for (int32_t f = 0; f < nf; f++) hits[f] += part[(size_t)r * (size_t)(nf + 1) + (size_t)f];
-        if (total) *total = tot;
-    }
-    free(part);
-    return rc;
+    if (db->ndev < 1) return IGD_HIP_ERR_ARG;
+    if (!db->grp || nq < db->ndev) return igd_hip_search_ex(db->devs[0], ichr, qs, qe, nq, v, rule, flags, hits, total);
+    /* contiguous slabs, one per device, and the one exchange of the path: the engine group (RCCL all-reduce of hits[]) */
+    return igd_hip_group_search(db->grp, ichr, qs, qe, nq, v, rule, flags, hits, total);
 }
 
 /* --------------------------------------------------------------------------------------- */

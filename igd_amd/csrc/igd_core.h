@@ -44,6 +44,7 @@ typedef struct igdc_db {
     /* multi-GPU: the same database resident on further devices; dev == devs[0] */
     int32_t     ndev;
     igd_hip_db *devs[IGDC_MAX_DEVICES];
+    igd_hip_group *grp;      /* the devices as one group: slabs + ONE RCCL all-reduce of hits[] (igd_hip_group_search) */
 } igdc_db;
 
 /* byte offset of tile j of contig c in the .igd (what the reference keeps as tIdx[c][j], src/igd_base.c:288-303) */
@@ -72,9 +73,9 @@ int igdc_attach_fp(igdc_db *db, FILE *fp, int device);
  * igdc_search_multi gives device r the r-th CONTIGUOUS slab of the batch (one host thread per
  * device), then adds the n per-device vectors of nFiles counts into hits[] -- the reference keeps one
  * hits[] for all queries and prints it once (src/igd_search.c:925,1032-1039); a sum of non-negative
- * integers, so any partition of the queries gives the identical vector.  In this single process the
- * "all-reduce" of the multi-process path (igd_amd/dist.py, RCCL) is that host-side add of n x 8*nFiles
- * bytes.  "IGD_DEVICES=0,1,.." selects the devices for the command line tool. */
+ * integers, so any partition of the queries gives the identical vector.  The sum is the engine group's RCCL all-reduce
+ * (ncclAllReduce of int64[nFiles] on every engine's stream, igd_hip_group_search); a host-side add of the n vectors only
+ * where RCCL cannot be used (igd_hip.h).  "IGD_DEVICES=0,1,.." selects the devices for the command line tool. */
 int igdc_attach_path_multi(igdc_db *db, const char *igd_path, const int *devices, int n);
 int igdc_search_multi(igdc_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
                       int32_t v, int rule, int flags, int64_t *hits, int64_t *total);

@@ -161,3 +161,40 @@ void igd_hip_created_free(igd_hip_created *c)
     RESOLVE(fn_t, "igd_hip_created_free");
     if (fn) fn(c);
 }
+
+int igd_hip_group_create(igd_hip_db *const *dbs, int n, igd_hip_group **out)
+{
+    typedef int (*fn_t)(igd_hip_db *const *, int, igd_hip_group **);
+    RESOLVE(fn_t, "igd_hip_group_create");
+    return fn ? fn(dbs, n, out) : IGD_HIP_ERR_DEVICE;
+}
+
+void igd_hip_group_destroy(igd_hip_group *g)
+{
+    typedef void (*fn_t)(igd_hip_group *);
+    if (!g) return;
+    RESOLVE(fn_t, "igd_hip_group_destroy");
+    if (fn) fn(g);
+}
+
+const char *igd_hip_group_reduce_kind(const igd_hip_group *g)
+{
+    typedef const char *(*fn_t)(const igd_hip_group *);
+    RESOLVE(fn_t, "igd_hip_group_reduce_kind");
+    return fn ? fn(g) : "";
+}
+
+const char *igd_hip_group_reduce_note(const igd_hip_group *g)
+{
+    typedef const char *(*fn_t)(const igd_hip_group *);
+    RESOLVE(fn_t, "igd_hip_group_reduce_note");
+    return fn ? fn(g) : "";
+}
+
+int igd_hip_group_search(igd_hip_group *g, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t v, int rule,
+                         int flags, int64_t *hits, int64_t *total)
+{
+    typedef int (*fn_t)(igd_hip_group *, const int32_t *, const int32_t *, const int32_t *, int64_t, int32_t, int, int, int64_t *, int64_t *);
+    RESOLVE(fn_t, "igd_hip_group_search");
+    return fn ? fn(g, ichr, qs, qe, nq, v, rule, flags, hits, total) : IGD_HIP_ERR_DEVICE;
+}

@@ -31,8 +31,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#define IGDC_HOST_LIMIT_DEFAULT 150000
-
+/* Where the engine starts to pay.  Measured on the pool's host (2 x EPYC 9575F, 16 counting threads) with the roadmap-scale
+ * database, wall time of `igd search -q` (tools/cli_small_probe.py --gpu, profiles/r04/cli_small.txt): the engine costs a fixed
+ * 0.15-0.2 s (HIP start-up + 851 MB upload) whatever the file holds; the host counts ~2 x 10^5 queries per 40 ms with 16
+ * threads (10^5: 19 ms vs 195 ms on the engine and 120 ms for the reference; 1.5 x 10^5: 32 ms), i.e. the two meet near 10^6
+ * queries there -- and near 1.3 x 10^5 on a host whose threads do not scale (the 8-vCPU build sandbox: 1.4 us per query
+ * whatever the thread count).  The limit follows the threads that are there: 25 000 queries per usable thread, between
+ * 50 000 and 400 000. */
 int64_t igdc_host_limit(void)
 {
     const char *e = getenv("IGD_HOST_MAX_QUERIES");
@@ -40,7 +45,10 @@ int64_t igdc_host_limit(void)
         const long long x = atoll(e);
         return x < 0 ? 0 : (int64_t)x;
     }
-    return IGDC_HOST_LIMIT_DEFAULT;
+    long t = sysconf(_SC_NPROCESSORS_ONLN);
+    if (t > 16) t = 16;
+    if (t < 2) t = 2;
+    return 25000 * (int64_t)t;
 }
 
 /* a query file of `bytes` bytes can be expected to hold at most the limit's number of lines (a BED3 line of a human

@@ -134,8 +134,9 @@ class Database:
         _chk(self._H.igd_hip_search_dev(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, int(flags), d_hits,
                                         d_total, stream), "igd_hip_search_dev")
 
-    def sync(self, stream=None):
-        _chk(self._H.igd_hip_sync(self.dev, stream), "igd_hip_sync")
+    def sync(self, stream=None, spin=False):
+        """Wait for the stream (spin: polling instead of sleeping on the completion signal) and surface asynchronous errors."""
+        _chk((self._H.igd_hip_sync_spin if spin else self._H.igd_hip_sync)(self.dev, stream), "igd_hip_sync")
 
     def enumerate(self, ichr, qs, qe):
         """`-f`: returns (qoff int64[nq+1], records int32[n,4] = q,idx,start,end) in reference order."""

@@ -123,6 +123,24 @@ int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_q
                        int64_t *d_hits, int64_t *d_total, void *stream);
 int64_t igd_hip_max_batch(void);   /* queries per call of the host-buffer entry points (2^24; test-only IGD_HIP_MAX_BATCH lowers it) */
 int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
+int  igd_hip_sync_spin(igd_hip_db *db, void *stream); /* the same, polling hipStreamQuery instead of sleeping on the signal */
+
+/* Several devices driven by one process (the C host's form): the database resident on each device of the
+ * group (igd_hip_open once per device; a device may be listed twice), a query set cut into contiguous slabs, one per device,
+ * and the path's ONE exchange -- the sum of the per-device hits[nFiles] vectors, the reference's single accumulator
+ * (src/igd_search.c:925,1032-1039) -- as an RCCL all-reduce (ncclInt64, ncclSum) on the engines' own streams, over xGMI.
+ * librccl is mapped when the first group is created.  When it cannot be used (not loadable, communicator refused, a device
+ * listed twice, IGD_MULTI_REDUCE=host) the vectors are added on the host; igd_hip_group_reduce_kind() returns "rccl" or
+ * "host", igd_hip_group_reduce_note() the reason for "host"; IGD_MULTI_REDUCE=rccl makes create fail instead of falling back.
+ * igd_hip_group_search: hits[] is ADDED to, *total = overlaps of the whole set.  Blocking.  The group does not own the
+ * databases (destroy the group first, then close them). */
+typedef struct igd_hip_group igd_hip_group;
+int  igd_hip_group_create(igd_hip_db *const *dbs, int n, igd_hip_group **out);
+void igd_hip_group_destroy(igd_hip_group *g);
+const char *igd_hip_group_reduce_kind(const igd_hip_group *g);
+const char *igd_hip_group_reduce_note(const igd_hip_group *g);
+int  igd_hip_group_search(igd_hip_group *g, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
+                          int32_t v, int rule, int flags, int64_t *hits, int64_t *total);
 
 /* `-f`: full enumeration in reference order (queries in batch order; per query tiles
  * ascending, record index DESCENDING inside a tile; rule NEST, no value filter).
