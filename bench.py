@@ -393,13 +393,15 @@ class Job:
         # the dominant kernel is timed with HIP events on its own stream on every 4th step of the timed region (an event
         # is one more packet between two kernels: timing every step costs the job ~4 us per step)
         self.db.profile_begin(steps, every=4 if steps >= 16 else 1)
-        spin = not os.environ.get("IGD_BENCH_NO_SPIN")
+        # (polling the stream with hipStreamQuery instead of sleeping on its signal was measured and is OFF: 89-94 us per step
+        # against 87-88 at --steps 20 -- the polling thread gets in the way of the runtime's own completion handling)
+        spin = bool(os.environ.get("IGD_BENCH_SPIN"))
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(zero_first=(k == 0))      # hits[] of the job starts from zero: cleared by the first batch's first kernel
         collective(self.d_hits)                 # the one collective of the path
-        if spin:                                # poll the stream instead of sleeping on its signal: the job ends when its last
-            self.db.sync(self.stream, spin=True)  # kernel does, not an interrupt later (0.1 ms of a 2 ms job at --steps 20)
+        if spin:
+            self.db.sync(self.stream, spin=True)
         torch.cuda.synchronize(self.dev)
         barrier()
         t1 = time.perf_counter()

@@ -2180,6 +2180,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         {
             const int levels = 32 - __builtin_clz((unsigned)c0), top = 1 << levels;   // top = 2^levels > c0 >= IGD_DENSE_MIN, c0 < 2^30
             int pos[IGD_SLOTS];
+            bool inLdsDone = false;
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) pos[r] = 0;
             if (IGD_EXP & 64) {
@@ -2196,32 +2197,31 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 // instead of five, nine dependent steps fewer per unit -- and it was no faster.)
                 typedef __attribute__((address_space(3))) const unsigned short *lds_u16;
                 const unsigned sb0 = (unsigned)(size_t)(lds_u16)sb;
-                unsigned P[IGD_SLOTS];
+                // The probes are carried as LDS byte addresses: with stride S the probe is entry pos + S - 1; taking the step
+                // moves the next probe (stride S / 2) up by S / 2 entries, not taking it moves it down by S / 2 -- so a step is
+                // read, compare, select +-S bytes, add, in a loop with a wave-uniform trip count.  (The steps used to be
+                // written out behind a switch over the tile's first stride: every case label was a merge point for which
+                // the compiler copied the five positions -- 55 moves per unit, 20 of them in the cases a tile of 66 queries
+                // skips: 135 vector instructions where 7 steps need 105.)
+                unsigned Q[IGD_SLOTS], E[IGD_SLOTS];
+                const unsigned q0 = sb0 + (unsigned)top - 2u;            // entry top / 2 - 1
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) P[r] = sb0;
-#define IGD_BSTEP(S)                                                                                                    \
-    {                                                                                                                   \
-        int vq[IGD_SLOTS];                                                                                              \
-        _Pragma("unroll") for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)*(lds_u16)(size_t)(P[r] + 2u * ((S) - 1u)); \
-        _Pragma("unroll") for (int r = 0; r < IGD_SLOTS; r++) P[r] += vq[r] <= (int)(R.a[r] >> 16) ? 2u * (S) : 0u;    \
-    }
-                switch (levels) {                        // c0 < sbCap <= 2048: at most 11 steps
-                case 11: IGD_BSTEP(1024u) [[fallthrough]];
-                case 10: IGD_BSTEP(512u) [[fallthrough]];
-                case 9: IGD_BSTEP(256u) [[fallthrough]];
-                case 8: IGD_BSTEP(128u) [[fallthrough]];
-                case 7: IGD_BSTEP(64u) [[fallthrough]];
-                case 6: IGD_BSTEP(32u) [[fallthrough]];
-                case 5: IGD_BSTEP(16u) [[fallthrough]];
-                case 4: IGD_BSTEP(8u) [[fallthrough]];
-                case 3: IGD_BSTEP(4u) [[fallthrough]];
-                case 2: IGD_BSTEP(2u) [[fallthrough]];
-                case 1: IGD_BSTEP(1u)
-                default: break;
+                for (int r = 0; r < IGD_SLOTS; r++) { Q[r] = q0; E[r] = R.a[r] >> 16; }
+                int vq[IGD_SLOTS];
+                for (int S = top >> 1; S > 1; S >>= 1) {                 // S = byte distance to the next probe
+                    const int up = S, dn = -S;
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)*(lds_u16)(size_t)Q[r];
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) Q[r] += (unsigned)(vq[r] <= (int)E[r] ? up : dn);   // compare, select, add
                 }
-#undef IGD_BSTEP
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) pos[r] = (int)((P[r] - sb0) >> 1);
+                for (int r = 0; r < IGD_SLOTS; r++) vq[r] = (int)*(lds_u16)(size_t)Q[r];   // the last probe is the position itself
+                // cnt -= c0 - pos with pos = (Q - sb0) / 2 + (last probe taken), in one go: subtract, halve, add with carry
+                const unsigned zero = sb0 + 2u * (unsigned)c0;
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] += ((int)(Q[r] - zero) >> 1) + (vq[r] <= (int)E[r] ? 1 : 0);
+                inLdsDone = true;
             } else {                                     // more queries than the LDS array holds: bisect q_qs[] itself
                 const int32_t *q_qs = KARG(a.q_qs);
                 const int T = IGD_TILE_START;
@@ -2236,8 +2236,10 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                     for (int r = 0; r < IGD_SLOTS; r++) pos[r] += vq[r] <= (int)(R.a[r] >> 16) + T - 1 ? step : 0;   // qs' <= e'
                 }
             }
+            if (!inLdsDone) {
 #pragma unroll
-            for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0 - pos[r];
+                for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0 - pos[r];
+            }
         }
         SECT(3);
         // term A: #{q: p_q <= i} = inclusive prefix sum of the histogram over the record positions
@@ -4269,7 +4271,14 @@ extern "C" int igd_hip_group_create(igd_hip_db *const *dbs, int n, igd_hip_group
     if (how && !strcmp(how, "host")) snprintf(g->why, sizeof g->why, "IGD_MULTI_REDUCE=host");
     else if (!distinct) snprintf(g->why, sizeof g->why, "a device is listed twice: RCCL wants one rank per GPU");
     else if (RcclApi *A = rccl_api()) {
+        // RCCL announces its version on STDOUT when the first communicator is built -- stdout is the command line tool's
+        // result (the reference's table): file descriptor 1 points at stderr while the communicators are made
+        fflush(stdout);
+        const int keep = dup(1);
+        if (keep >= 0) (void)dup2(2, 1);
         const ncclResult_t e = A->CommInitAll(g->comm, n, devs);
+        fflush(stdout);
+        if (keep >= 0) { (void)dup2(keep, 1); close(keep); }
         if (e == ncclSuccess) g->rccl = true;
         else {
             snprintf(g->why, sizeof g->why, "ncclCommInitAll: %s", A->GetErrorString ? A->GetErrorString(e) : "failed");
