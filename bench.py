@@ -71,6 +71,9 @@ def parse_args(argv=None):
                     help="N=1 only: this GPU's step is slab 0 of a G-GPU config-4 job (G x --queries position-sorted queries) -- "
                          "what one of G GPUs would run, measured without the other G-1")
     ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
+    ap.add_argument("--query-layout", choices=["runs", "ichr"], default="runs",
+                    help="how a position-sorted batch under the order promise is resident: contig runs + starts + ends (8 B/query) or "
+                         "one contig number per query (12 B/query)")
     ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
                     help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
                          "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
@@ -366,10 +369,19 @@ def pmc_traffic(key):
 class Job:
     """One resident batch + the timed loop over it (shared by the headline run and extra_configs)."""
 
-    def __init__(self, db, dev, stream, ichr, qs, qe, v, gflags):
+    def __init__(self, db, dev, stream, ichr, qs, qe, v, gflags, layout="runs"):
         import torch
         self.db, self.dev, self.stream, self.v, self.gflags = db, dev, stream, v, gflags
         self.Q = len(qs)
+        # A position-sorted batch under the order promise is resident as (contig runs, starts, ends): run_start[nCtg + 1]
+        # instead of one contig number per query -- what a position-sorted BED is, and 4 bytes per query less for the
+        # grouping kernel to read (igd_hip_search_runs_dev).  The ichr[] form stays resident for the instrumentation calls.
+        self.d_runs = None
+        if layout == "runs" and (gflags & 1) and not (gflags & 2):
+            try:
+                self.d_runs = torch.from_numpy(db.contig_runs(ichr, db.nctg)).to(dev)
+            except Exception:
+                self.d_runs = None                          # (unknown contigs in the batch: no run table)
         self.d_ichr = torch.from_numpy(ichr).to(dev)
         self.d_qs = torch.from_numpy(qs).to(dev)
         self.d_qe = torch.from_numpy(qe).to(dev)
@@ -378,6 +390,10 @@ class Job:
     def step(self, zero_first=False):
         """One pass of the hot path over the resident batch; zero_first: the batch's first kernel clears hits[]
         (IGD_HIP_FLAG_ZERO_FIRST) -- the job's accumulator starts from zero without a launch of its own."""
+        if self.d_runs is not None:
+            self.db.search_runs_dev(self.d_runs.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr(), self.Q,
+                                    self.d_hits.data_ptr(), None, v=self.v, stream=self.stream, flags=self.gflags | (8 if zero_first else 0))
+            return
         self.db.search_dev(self.d_ichr.data_ptr(), self.d_qs.data_ptr(), self.d_qe.data_ptr(), self.Q,
                            self.d_hits.data_ptr(), None, v=self.v, stream=self.stream, flags=self.gflags | (8 if zero_first else 0))
 
@@ -505,7 +521,7 @@ def extra_configs(db, dev, stream, args, box):
         out.append({"workload": "stress: clustered database", "error": str(e)})
     for (name, (ichr, qs, qe), v, gflags, steps, gkey), db in zip(cases, dbs):
         try:
-            job = Job(db, dev, stream, ichr, qs, qe, v, gflags)
+            job = Job(db, dev, stream, ichr, qs, qe, v, gflags, args.query_layout)
             el, prof = job.run(steps, 3)
             rl = job.roofline(prof)
             hj = job.d_hits.cpu().numpy()
@@ -621,7 +637,7 @@ def main():
     # one accumulator over the whole query file (src/igd_search.c:925,1032-1039) and the engine adds --
     # followed by the path's ONE exchange: a SUM all-reduce of hits[nFiles] (no-op at N=1).  Both are
     # inside the timed region.
-    job = Job(db, dev, stream, ichr, qs, qe, args.v, gflags)
+    job = Job(db, dev, stream, ichr, qs, qe, args.v, gflags, args.query_layout)
     elapsed, prof = job.run(args.steps, args.warmup, barrier, allreduce_hits)
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if grouped:
@@ -660,6 +676,8 @@ def main():
                                       "-v %d signal filter" % args.v if mode == "v" else "hits-only"),
                        "queries_per_gpu": Q, "queries_per_step_all_gpus": world * Q, "nfiles": db.nfiles,
                        "parallelism": "query-sharded x%d" % world, "grouping": args.grouping,
+                       "query_layout": ("contig runs + starts + ends (8 B/query; igd_hip_search_runs_dev)" if job.d_runs is not None
+                                        else "contig numbers + starts + ends (12 B/query; igd_hip_search_dev)"),
                        "collective": ("ONE sum all-reduce of int64[%d] per job (after the %d batches), inside the timed region"
                                       % (db.nfiles, args.steps)) if grouped else "none"},
             "roofline": rl,

@@ -141,6 +141,8 @@ def hip():
                                         C.c_int32, C.c_int, C.c_int, C.c_void_p, i64p]
         L.igd_hip_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.igd_hip_search_runs_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                              C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.igd_hip_max_batch.restype = C.c_int64
         L.igd_hip_build_flags.restype = C.c_uint
         L.igd_hip_build_wrong_counts.restype = C.c_uint

@@ -46,6 +46,7 @@
 //   greedy order (igd_sortscan.hpp) + a wave-per-group matching kernel (k_seq_greedy).
 // No MFMA anywhere: this is integer compare + count, bound by HBM / VALU issue, not by math.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -235,6 +236,8 @@ struct igd_hip_db {
     int32_t *d_lpos;              // [nT+1] lpos[]: entries of its later block before query firstQ[t] (k_query_bounds)
     int32_t *d_cov;               // coverage of long queries (IGD_COV_*): 4 sets (path x batch parity) of { diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2] }
     bool covStale;                // a batch returned an error after its first kernel: clear d_cov before the next one
+    int32_t *d_runIchr;           // igd_hip_search_runs_dev: contig numbers written out for the batches the RUNS build does not take
+    int64_t runCap;
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
     int32_t *d_later;               // [wsQueries + 1088] later[]: later-tile words, compacted per later block (compact image only)
     int32_t *d_spill;             // [nT+1] epoch stamps: a query covers the tile as a later tile
@@ -281,6 +284,8 @@ struct igd_hip_db {
     // profiling
     std::vector<hipEvent_t> ev;   // 4 per launch: pipeline start, scan start, scan stop, pipeline stop
     int evMax, evUsed;
+    hipEvent_t evStart, evStop;   // set while a timed launch of a promised-sorted batch is being enqueued: the scan kernel's own dispatch is
+                                  // bracketed by them (hipExtLaunchKernel), not two event packets around it
     int evEvery, evSeen;          // every evEvery-th launch is timed (igd_hip_profile_sampling)
     bool evOn;
 };
@@ -480,7 +485,12 @@ __device__ __forceinline__ void cover_tiles(const DbView &db, int32_t *__restric
     ctl[CTL_COV + set * 2 + (epoch & 1)] = epoch;
 }
 
-template <int VEC, bool FAST, int WGT>
+// RUNS: a position-sorted batch given as contig RUNS -- `ichr` then points at runStart[nCtg + 1] (queries [runStart[c],
+// runStart[c + 1]) lie on contig c, runStart[0] = 0, runStart[nCtg] = nq) instead of one contig number per query: 4 of the
+// 12 bytes per query are not read (igd_hip_search_runs_dev).  The table is staged in LDS and checked (a table that is not
+// monotone or does not cover [0, nq) is a broken order promise); a wave finds its contig with one bisection and is on the
+// short path unless it straddles a run boundary.
+template <int VEC, bool FAST, int WGT, bool RUNS = false>
 __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
@@ -498,18 +508,19 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (VEC == 4) {
         int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
         if (i0 + 3 < nq) {
-            c4 = *(const int4 *)(ichr + i0); s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
+            if (!RUNS) c4 = *(const int4 *)(ichr + i0);
+            s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
         } else {
-            if (i0 < nq) { c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
-            if (i0 + 1 < nq) { c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
-            if (i0 + 2 < nq) { c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
+            if (i0 < nq) { if (!RUNS) c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
+            if (i0 + 1 < nq) { if (!RUNS) c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
+            if (i0 + 2 < nq) { if (!RUNS) c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
         }
         qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
         qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
         qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
-    } else if (i0 < nq) { qc[0] = ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
+    } else if (i0 < nq) { qc[0] = RUNS ? 0 : ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
     int pc = -1, ps = INT_MIN;
-    if (i0 > 0 && i0 < nq) { pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
+    if (i0 > 0 && i0 < nq) { if (!RUNS) pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
     __shared__ int sCnt[NW];
@@ -525,7 +536,43 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (threadIdx.x == NW) sSeen = 0;                     // (defined also when wave 0 is the one that leaves before it stores the flag)
     if (ldsTab)
         for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
+    __shared__ int32_t sRun[RUNS ? 2 * QB_CTG : 1];       // runStart[0..nCtg], padded with INT_MAX to a power of two
+    __shared__ int sK[2];                                 // RUNS: contig of the batch's first and last query
+    int runLevels = 0;
+    if (RUNS) {
+        int badRuns = 0;
+        while ((1 << runLevels) < db.nCtg + 1) runLevels++;
+        for (int c = threadIdx.x; c < (1 << runLevels); c += WGT) {
+            const int r0 = c <= db.nCtg ? ichr[c] : INT_MAX;
+            sRun[c] = r0;
+            if (c < db.nCtg) badRuns |= r0 > ichr[c + 1] ? 1 : 0;
+            if (c == 0) badRuns |= (r0 != 0 || ichr[db.nCtg] != nq) ? 1 : 0;
+        }
+        if (__syncthreads_or(badRuns)) {                  // not a run table of this batch: the order promise is broken
+            if (threadIdx.x == 0) { ctl[CTL_UNSORTED] = epoch; if (promised) ctl[CTL_BROKEN] = epoch; }
+            return;
+        }
+    } else
     __syncthreads();
+    // contig of query i: the number of run starts 1..nCtg that are <= i (an empty run shares its start with the next one)
+    auto contig_of = [&](int i) -> int {
+        int pos = 0;                                      // entries sRun[1..] taken so far
+        for (int S = 1 << runLevels >> 1; S > 0; S >>= 1) pos += sRun[pos + S] <= i ? S : 0;
+        return pos;
+    };
+    if (RUNS) {
+        const int wv_ = (int)(threadIdx.x >> 6);
+        if (wv_ == 0 && nq > 0) { const int c0_ = contig_of(0); if (threadIdx.x == 0) sK[0] = c0_; }
+        if (wv_ == NW - 1 && nq > 0) { const int c1_ = contig_of(nq - 1); if ((threadIdx.x & 63) == 0) sK[1] = c1_; }
+        const int cl = i0 < nq ? contig_of(i0) : db.nCtg;                 // the thread's first query
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            int c = cl;
+            while (c < db.nCtg && i0 + v >= sRun[c + 1]) c++;          // (only at a run boundary)
+            qc[v] = c;
+        }
+        if (i0 > 0 && i0 < nq) pc = i0 - 1 >= sRun[cl] ? cl : contig_of(i0 - 1);
+    }
 #define QB_BASE(c) (FAST ? sBase[c] : (ldsTab ? sBase[c] : db.ctgBase[c]))
 #define QB_NTILE(c) (FAST ? sNTile[c] : (ldsTab ? sNTile[c] : db.ctgNTile[c]))
 #define QB_TILE(x) (FAST ? tile_shift(x, db.shift) : tile_of(db, x))
@@ -658,13 +705,13 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
             if (n2 - n1 >= IGD_SHORT_TILES) {
                 // a long query: its last tile is walked exactly, the tiles n1+4 .. n2-1 are covered from end to end (IGD_COV_*)
-                fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_LAST);
+                fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_LAST | (qc[v] << 4));   // (the walk finds the contig here)
                 if (n2 - n1 > IGD_SHORT_TILES && !(rule == IGD_HIP_RULE_NEST && db.tileCnt[g0] == 0)) {   // (rule NEST: an empty first tile ends the query)
                     cover_tiles(db, ctl, 0, epoch, g0 + IGD_SHORT_TILES, g0 + (n2 - n1));
                 }
             }
             const bool needExact = packed && e0 <= T0;
-            if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST);
+            if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST | (qc[v] << 4));
             if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
             else {
                 // rule NEST (an empty first tile ends the query, :468) needs no look-up here: the first tile's own
@@ -778,7 +825,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // first three tiles after the last query's (all that a query can still reach) = the entries of the last block, if the
     // queries end inside it: written by that block's own workgroup.
     if (nq > 0) {
-        const int k0 = tile_key(db, ichr[0], qs[0]), kl = tile_key(db, ichr[nq - 1], qs[nq - 1]);
+        const int k0 = tile_key(db, RUNS ? sK[0] : ichr[0], qs[0]), kl = tile_key(db, RUNS ? sK[1] : ichr[nq - 1], qs[nq - 1]);
         const int nth = gridDim.x * WGT;
         for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; lpos[tt] = 0; }
         for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;
@@ -2719,9 +2766,9 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
         int vq = 0, vkind = -1, vqs = 0, vqe = 0, vn1 = 0, vj1 = -1, vbase = 0, vcnt = 0, voffLo = 0, voffHi = 0, vlob = 0;
         if (lane < cnt) {
             const int2 ent = list[l0 + lane];
-            vq = ent.x; vkind = ent.y;
+            vq = ent.x; vkind = ent.y & 15;
             vqs = a.q_qs[vq]; vqe = a.q_qe[vq];
-            const int cc = a.q_ichr[vq];
+            const int cc = sortedPath ? ent.y >> 4 : a.q_ichr[vq];     // (k_query_bounds' entries carry the contig: a batch given as runs has no ichr[])
             vn1 = tile_of(db, vqs);
             int n2 = tile_of(db, (int)((unsigned)vqe - 1u));
             const int mT = db.ctgNTile[cc] - 1;
@@ -3307,7 +3354,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
-                    db->d_spTable, db->d_spT};
+                    db->d_spTable, db->d_spT, db->d_runIchr};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
@@ -3875,6 +3922,21 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     return K;
 }
 
+// One launch of the merge join's kernel.  A timed launch (igd_hip_profile_begin) of a promised-sorted batch passes its event
+// pair to the launch itself: hipExtLaunchKernel stamps them with the dispatch's own start and end -- the figures a profiler
+// reads (rocprofv3 --kernel-trace) -- where two hipEventRecord packets around the kernel also time the two packet gaps
+// (3-6 % of a 70 us kernel) and put two more packets between the step's kernels.
+template <typename F>
+static void launch_sorted(igd_hip_db *db, F kernel, int grid, int block, size_t lds, hipStream_t st, const SortK &K)
+{
+    if (db->evStart) {
+        SortK k = K;
+        void *args[] = {&k};
+        (void)hipExtLaunchKernel((const void *)kernel, dim3(grid), dim3(block), args, lds, st, db->evStart, db->evStop, 0);
+        db->evStart = db->evStop = nullptr;              // (one kernel per pair)
+    } else kernel<<<grid, block, lds, st>>>(K);
+}
+
 // win >= 0: pass `win` of a batch against a database with more files than LDS counters (igd_hip_db::winN)
 template <bool USE_V, bool LDS_HITS, bool PACKED>
 static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st, int win = -1)
@@ -3903,18 +3965,18 @@ static void launch_scan(igd_hip_db *db, const ScanArgs &a, hipStream_t st, int w
         // <USE_V, LDS_HITS, CNT32, BIG, RANK>: workgroups with LDS counters keep them in 32 bits (igd_scan_sorted guards the range itself)
         // (a database of one file / of up to eight: builds whose lanes do not all add to the same few LDS counters)
         const int few = (LDS_HITS && !big) ? (win >= 0 ? 3 : db->nFiles == 1 ? 1 : db->nFiles <= 8 ? 2 : 0) : 0;
-        if (big) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, true, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+        if (big) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, true, true>, db->grid, IGD_WG_RANK, ldsS, st, K);
         else if (lean) {
             const size_t l = LDS_HITS ? ldsS : 0;         // (the lean build's only LDS is its counters)
-            if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
-            else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
-            else if (few == 3) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 3 : 0><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
-            else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false><<<db->grid, IGD_WG_LEAN, l, st>>>(K);
+            if (few == 1) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 1 : 0>, db->grid, IGD_WG_LEAN, l, st, K);
+            else if (few == 2) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 2 : 0>, db->grid, IGD_WG_LEAN, l, st, K);
+            else if (few == 3) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false, LDS_HITS ? 3 : 0>, db->grid, IGD_WG_LEAN, l, st, K);
+            else launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, false>, db->grid, IGD_WG_LEAN, l, st, K);
         } else {
-            if (few == 1) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 1 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-            else if (few == 2) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 2 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-            else if (few == 3) igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 3 : 0><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
-            else igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true><<<db->grid, IGD_WG_RANK, ldsS, st>>>(K);
+            if (few == 1) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 1 : 0>, db->grid, IGD_WG_RANK, ldsS, st, K);
+            else if (few == 2) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 2 : 0>, db->grid, IGD_WG_RANK, ldsS, st, K);
+            else if (few == 3) launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true, LDS_HITS ? 3 : 0>, db->grid, IGD_WG_RANK, ldsS, st, K);
+            else launch_sorted(db, igd_scan_sorted<USE_V, LDS_HITS, LDS_HITS, false, true>, db->grid, IGD_WG_RANK, ldsS, st, K);
         }
     } else
     if (a.mode != 2) {
@@ -3936,9 +3998,41 @@ static void launch_scan_any(igd_hip_db *db, const ScanArgs &a, bool useV, bool p
     }
 }
 
+// runs -> one contig number per query (only for the batches k_query_bounds' RUNS build does not take: see search_dev_impl)
+__global__ void k_expand_runs(const int32_t *__restrict__ runs, int nCtg, int32_t *__restrict__ ichr, int nq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int lo = 0, hi = nCtg;                               // largest c with runs[c] <= i
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (runs[mid] <= i) lo = mid; else hi = mid; }
+    ichr[i] = lo;
+}
+
+static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_runs, const int32_t *d_qs,
+                           const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
+                           int64_t *d_hits, int64_t *d_total, void *stream);
+
 extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
                                   const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                                   int64_t *d_hits, int64_t *d_total, void *stream)
+{
+    return search_dev_impl(db, d_ichr, nullptr, d_qs, d_qe, nq, v, rule, flags, d_hits, d_total, stream);
+}
+
+extern "C" int igd_hip_search_runs_dev(igd_hip_db *db, const int32_t *d_run_start, const int32_t *d_qs,
+                                       const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
+                                       int64_t *d_hits, int64_t *d_total, void *stream)
+{
+    if (!d_run_start || (flags & IGD_HIP_FLAG_BUCKET)) {
+        snprintf(g_err, sizeof g_err, "igd_hip_search_runs_dev: bad argument");
+        return IGD_HIP_ERR_ARG;
+    }
+    return search_dev_impl(db, nullptr, d_run_start, d_qs, d_qe, nq, v, rule, flags | IGD_HIP_FLAG_SORTED, d_hits, d_total, stream);
+}
+
+static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_runs, const int32_t *d_qs,
+                           const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
+                           int64_t *d_hits, int64_t *d_total, void *stream)
 {
     if (!db || !d_hits || nq < 0 || nq > IGD_MAX_BATCH || (rule != IGD_HIP_RULE_NEST && rule != IGD_HIP_RULE_FLAT) ||
         ((flags & IGD_HIP_FLAG_SORTED) && (flags & IGD_HIP_FLAG_BUCKET))) {
@@ -3988,12 +4082,32 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         // a small batch: one query per thread (more waves share the gaps between its queries), and enough workgroups for
         // the head and tail of firstQ[] -- 10^3 queries left 190 000 entries to ONE workgroup: 90 us
         if (nq < 65536) vec = false;
+        // a batch given as contig runs: k_query_bounds' RUNS build takes it as it is when it is the usual kind (compact image,
+        // power-of-two tiles, four queries per thread); any other batch gets its contig numbers written out first
+        bool runsK = d_runs != nullptr && vec && fast;
+        if (d_runs && !runsK) {
+            if (nq > db->runCap) {
+                HIPCHK(hipStreamSynchronize(st));
+                if (db->d_runIchr) (void)hipFree(db->d_runIchr);
+                db->d_runIchr = nullptr; db->runCap = 0;
+                if ((rc = dalloc(&db->d_runIchr, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
+                db->runCap = nq;
+            }
+            k_expand_runs<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_runs, db->nCtg, db->d_runIchr, (int)nq);
+            d_ichr = db->d_runIchr;
+            vec = vec && (((uintptr_t)d_ichr) & 15) == 0;
+        }
         const int fillBlocks = (int)((db->nT >> 10) < 256 ? (db->nT >> 10) + 1 : 256);
         // large batches: later blocks of 4096 queries (workgroups of 1024 threads), so that the candidate range of a tile --
         // the queries of three tiles -- spans at most two blocks even at hundreds of queries per tile
         const bool wide = vec && nq >= ((int64_t)1 << 22);
 #define QB_GRID(PER_) ((int)((nq + (PER_) - 1) / (PER_)) > fillBlocks ? (int)((nq + (PER_) - 1) / (PER_)) : fillBlocks)
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
+    if (runsK && VEC_ == 4 && FAST_)                                                                                                  \
+        k_query_bounds<4, true, WGT_, true><<<QB_GRID(WGT_ * 4), WGT_, 0, st>>>(db->v, d_runs, d_qs, d_qe, (int)nq, rule,            \
+        packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
+        (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0);                                                                                  \
+    else                                                                                                                             \
     k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
@@ -4017,7 +4131,9 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
                                       mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         if (rc != IGD_HIP_OK) return rc;                 // (guard: covStale)
     }
-    if (slot >= 0) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
+    // (a promised-sorted batch over the compact image in one pass: the scan kernel's own dispatch carries the pair)
+    const bool extEv = slot >= 0 && mode == 1 && packed && db->ldsHits && db->nWin == 1;
+    if (slot >= 0 && !extEv) HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st));
     ScanArgs a;
     a.firstQ = db->d_firstQ; a.pairN = db->d_pairN; a.pairPos = db->d_pairPos; a.pairs = (const int2 *)db->d_pairs;
     a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe; a.q_w = db->d_qw;
@@ -4037,8 +4153,13 @@ extern "C" int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const i
         for (int win = 0; win < db->nWin; win++) {
             const bool last = win == db->nWin - 1;
             const int fileLo = win * db->winN, fileN = db->nWin == 1 ? db->nFiles : (db->nFiles - fileLo < db->winN ? db->nFiles - fileLo : db->winN);
+            if (extEv) { db->evStart = db->ev[4 * slot + 1]; db->evStop = db->ev[4 * slot + 2]; }
             launch_scan_any<true>(db, a, useV, packed, st, db->nWin > 1 ? win : -1);
-            if (slot >= 0 && last) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+            if (extEv && db->evStart) {                  // (no merge-join launch took the pair: cannot happen for this kind of batch)
+                db->evStart = db->evStop = nullptr;
+                HIPCHK(hipEventRecord(db->ev[4 * slot + 1], st)); HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
+            }
+            if (slot >= 0 && last && !extEv) HIPCHK(hipEventRecord(db->ev[4 * slot + 2], st));
             // slab rows -> hits[]; the listed exact walks (same launch) add straight into hits[] and total
             ScanArgs w = a;
             w.out = (u64 *)d_hits;

@@ -134,6 +134,25 @@ class Database:
         _chk(self._H.igd_hip_search_dev(self.dev, d_ichr, d_qs, d_qe, int(nq), vf, rule, int(flags), d_hits,
                                         d_total, stream), "igd_hip_search_dev")
 
+    def search_runs_dev(self, d_run_start, d_qs, d_qe, nq, d_hits, d_total=None, v=0, rule=None,
+                        value_filter=None, stream=None, flags=0):
+        """Resident position-sorted batch given as contig runs (device int32[nctg + 1]: queries [run[c], run[c + 1]) lie on
+        contig c) instead of one contig number per query.  Asynchronous; implies the order promise."""
+        if rule is None:
+            rule, vf = self.cli_dispatch(self.gtype, v)
+        else:
+            vf = N.IGD_HIP_NO_VALUE_FILTER if value_filter is None else int(value_filter)
+        _chk(self._H.igd_hip_search_runs_dev(self.dev, d_run_start, d_qs, d_qe, int(nq), vf, rule, int(flags), d_hits,
+                                             d_total, stream), "igd_hip_search_runs_dev")
+
+    @staticmethod
+    def contig_runs(ichr, nctg):
+        """run_start[nctg + 1] of a batch whose contig numbers are non-decreasing (host, numpy)."""
+        ichr = np.ascontiguousarray(ichr, dtype=np.int32)
+        if len(ichr) and (np.any(np.diff(ichr) < 0) or ichr[0] < 0 or ichr[-1] >= nctg):
+            raise IgdError("contig_runs: the batch is not grouped by ascending contig number")
+        return np.searchsorted(ichr, np.arange(nctg + 1, dtype=np.int32), side="left").astype(np.int32)
+
     def sync(self, stream=None, spin=False):
         """Wait for the stream (spin: polling instead of sleeping on the completion signal) and surface asynchronous errors."""
         _chk((self._H.igd_hip_sync_spin if spin else self._H.igd_hip_sync)(self.dev, stream), "igd_hip_sync")

@@ -121,6 +121,14 @@ int igd_hip_search_ex(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, co
 int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs,
                        const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                        int64_t *d_hits, int64_t *d_total, void *stream);
+/* The same for a position-sorted batch given as contig RUNS instead of one contig number per query: d_run_start (device,
+ * nCtg + 1 int32) with run_start[0] = 0, run_start[nCtg] = nq and the queries [run_start[c], run_start[c + 1]) lying on contig c
+ * in non-decreasing order of start -- what a position-sorted BED is (the command line tool's reader keeps its queries that
+ * way, igdc_queries_group_contigs).  The grouping kernel then reads 8 instead of 12 bytes per query.  Implies
+ * IGD_HIP_FLAG_SORTED (IGD_HIP_FLAG_BUCKET is refused); a table that is not monotone or does not cover [0, nq), like queries out
+ * of order, is a broken promise: the batch adds nothing and igd_hip_sync returns IGD_HIP_ERR_UNSORTED. */
+int igd_hip_search_runs_dev(igd_hip_db *db, const int32_t *d_run_start, const int32_t *d_qs, const int32_t *d_qe,
+                            int64_t nq, int32_t v, int rule, int flags, int64_t *d_hits, int64_t *d_total, void *stream);
 int64_t igd_hip_max_batch(void);   /* queries per call of the host-buffer entry points (2^24; test-only IGD_HIP_MAX_BATCH lowers it) */
 int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
 int  igd_hip_sync_spin(igd_hip_db *db, void *stream); /* the same, polling hipStreamQuery instead of sleeping on the signal */
