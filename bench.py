@@ -203,6 +203,41 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
         out[name + "_seconds"] = best
         if ok is not None:
             out["q_total_matches_gpu"] = ok
+    # Small query files: the reference starts cheaply (header only, then the tiles the queries touch); files of at most
+    # IGD_HOST_MAX_QUERIES lines are counted on the host by product code (igd_hostpath.c), larger ones go to the engine.
+    # Wall time of `search -q` at every size, the reference binary's beside it, stdout compared byte for byte.
+    try:
+        ref = os.path.join(ROOT, "oracle", "_ref", "igd")
+        synth_exe = os.path.join(ROOT, "bin", "igd_synth")
+        rows = []
+        for n in (1000, 10000, 100000, 300000):
+            q = os.path.join(os.path.dirname(bed_path), "q%d.bed" % n)
+            if not os.path.exists(q):
+                subprocess.check_call([synth_exe, "queries", q, "--n", str(n)], stdout=subprocess.DEVNULL)
+            row = {"queries": n}
+            outs = {}
+            for who, cmd, env in (("reference", [ref], None), ("product", [exe], None),
+                                  ("product_engine_only", [exe], dict(os.environ, IGD_HOST_MAX_QUERIES="0"))):
+                if who == "reference" and not os.path.exists(ref):
+                    continue
+                best = None
+                for _ in range(5):
+                    t = time.perf_counter()
+                    p = subprocess.run(cmd + ["search", igd_path, "-q", q], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+                    dt = time.perf_counter() - t
+                    if p.returncode != 0:
+                        best = None
+                        break
+                    best = dt if best is None else min(best, dt)
+                    outs[who] = p.stdout
+                row[who + "_seconds"] = best
+            row["stdout_identical"] = len(set(outs.values())) == 1 and len(outs) >= 2
+            rows.append(row)
+        out["small_files"] = rows
+        out["small_files_note"] = ("files of at most IGD_HOST_MAX_QUERIES queries (default 25 000 per usable host thread, 50 000 .. 400 000) "
+                                   "are counted on the host (igd_hostpath.c, product code); product_engine_only = the same file sent to the GPU")
+    except Exception as e:
+        out["small_files"] = {"error": str(e)}
     return out
 
 
@@ -490,6 +525,10 @@ def extra_configs(db, dev, stream, args, box):
              ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30, "config4_share_q12500000_v0"),
              ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30,
               "config4_slab0_of_8_v0"),
+             ("config 4 as one of 4 GPUs sees it: slab 0 (1.25e7 queries) of 5e7 position-sorted queries",
+              synth.make_queries_slab(4 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, None),
+             ("config 4 as one of 2 GPUs sees it: slab 0 (1.25e7 queries) of 2.5e7 position-sorted queries",
+              synth.make_queries_slab(2 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, "config4_slab0_of_2_v0"),
              ("small batch: 10^3 position-sorted queries per step (latency of one pass)",
               synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, None),
              ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
@@ -564,6 +603,29 @@ def extra_configs(db, dev, stream, args, box):
                                  "peak_source": "pinned device->host hipMemcpyAsync of 256 MiB measured in this run"}})
     except Exception as e:
         out.append({"workload": "config 5: -f", "error": str(e)})
+    return out
+
+
+def scale_anchor(extras):
+    """The weak-scaling curve of BASELINE config 4 as ONE GPU can measure it: rank r of an N-GPU job runs slab r of one
+    position-sorted set of N x 1.25e7 queries, so its step is what `--slab-of N` times here; N = 1 is the unsharded 1.25e7-query
+    batch.  (The default N = 1 line is BASELINE config 2 -- 10^6 queries per step -- and no anchor for that curve.)"""
+    def find(word):
+        for e in extras:
+            if word in e.get("workload", "") and e.get("ms_per_step"):
+                return e
+        return None
+    pts = {1: find("config 4 per-GPU share"), 2: find("one of 2 GPUs"), 4: find("one of 4 GPUs"), 8: find("one of 8 GPUs")}
+    if not pts[1]:
+        return {"error": "the config-4 share was not measured"}
+    out = {"per_gpu_queries": CONFIG4_PER_GPU,
+           "what": "ms per step of ONE GPU on its share of an N-GPU config-4 job (slab 0 of N x 1.25e7 position-sorted queries); "
+                   "the all-reduce of int64[nFiles] (15 KB, once per job) is not in these single-GPU figures",
+           "step_ms": {str(n): e["ms_per_step"] for n, e in pts.items() if e},
+           "predicted_value": {str(n): n * CONFIG4_PER_GPU / (e["ms_per_step"] * 1e-3) for n, e in pts.items() if e},
+           "predicted_efficiency_vs_n1": {str(n): pts[1]["ms_per_step"] / e["ms_per_step"] for n, e in pts.items() if e},
+           "note": "efficiency above 1 is expected: a slab of a larger sorted set touches fewer tiles (N = 8: one tile in eight, "
+                   "530 queries per tile), so a rank's step gets SHORTER as N grows"}
     return out
 
 
@@ -659,8 +721,25 @@ def main():
                               "/slab0of%d" % args.slab_of if (world == 1 and args.slab_of > 1) else "")
     rl = job.roofline(prof, tkey if world == 1 else None)     # outside the timed region
 
+    anchor = None
+    if rank == 0 and world > 1:
+        try:                                                # the N = 1 anchor of the weak-scaling curve: the same per-GPU batch size, unsharded
+            a_q = synth.make_queries_slab(Q, 0, Q, seed=7, genome=synth.HG38)
+            a_job = Job(db, dev, stream, a_q[0], a_q[1], a_q[2], args.v, gflags, args.query_layout)
+            a_el, _ = a_job.run(30, 3)
+            anchor = {"workload": "ONE GPU, %d position-sorted queries per step (seed 7): what N = 1 of this weak-scaling job is" % Q,
+                      "steps": 30, "ms_per_step": 1e3 * a_el / 30, "value": Q * 30 / a_el, "unit": "query-intervals/s",
+                      "measured": "by rank 0 on its GPU after the job's timed region"}
+            del a_job
+        except Exception as e:
+            anchor = {"error": str(e)}
     if rank == 0:
         box = measure_rates(local)
+        # what `frac` is a fraction of, three ways: compulsory bytes over the kernel's time (frac), the bytes the PMC counters saw
+        # over the same time (frac_pmc), and compulsory bytes over the whole step -- all three kernels and their launch gaps
+        rl["frac_of"] = "compulsory bytes of the launch (igd_hip_batch_traffic) / kernel_ms / 8 TB/s"
+        rl["frac_pmc"] = (rl["traffic"] / (rl["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (rl.get("traffic") and rl["kernel_ms"] > 0) else None
+        rl["step_frac"] = rl["bytes_per_launch"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS
         rl["box"] = dict(box, note="measured in this run by igd_hip_measure_rates: float4 copy kernel (read+write bytes), "
                                    "float4 read-only kernel, pinned D2H / H2D copies")
         value = world * Q * args.steps / elapsed
@@ -738,6 +817,13 @@ def main():
                     line["cpu_baseline"]["all_cores_large"] = {"error": str(e)}
         if world == 1 and not args.no_extra:
             line["extra_configs"] = extra_configs(db, dev, stream, args, box)
+            line["scale_anchor"] = scale_anchor(line["extra_configs"])
+        if world > 1 and anchor is not None:
+            # like for like: N ranks x 1.25e7 queries against ONE GPU running 1.25e7 queries of the same generator (measured by rank 0
+            # right after the job, outside its timed region) -- the N = 1 line of bench.py runs BASELINE config 2 (10^6 queries per
+            # step), another workload, so a ratio of the two lines' `value` says nothing about scaling
+            line["scale_anchor"] = anchor
+            line["efficiency_vs_anchor"] = value / (world * anchor["value"]) if anchor.get("value") else None
         print(json.dumps(line), flush=True)
     del job
     db.close()

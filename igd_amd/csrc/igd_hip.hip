@@ -78,7 +78,11 @@
 #define IGD_SCAN_BLOCK 256
 #define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
 #ifndef IGD_TAIL_WGS
-#define IGD_TAIL_WGS 2048                    // workgroups (256 threads) of the batch's last launch
+#define IGD_TAIL_WGS 512                     // workgroups (IGD_TAIL_WG threads) of the batch's last launch
+#endif
+#ifndef IGD_TAIL_WG
+#define IGD_TAIL_WG 1024                     // ... 8192 waves as before, in workgroups of 16: what the long queries' work counts in a workgroup's LDS
+                                             // leaves it as one global atomic per dataset, and 2048 workgroups of 4 waves made 3.9 x 10^6 of those
 #endif
 #ifndef IGD_REDUCE_GROUPS
 #define IGD_REDUCE_GROUPS 64                 // (32-bit slab rows: 6.2 us with 128 groups, 5.4 with 64, 6.4 with 32, 10.1 with 16)
@@ -189,7 +193,8 @@ struct __attribute__((aligned(16))) Unit {
                       // flag bit 0: first unit of its tile; bit k (1..3): tile j-k of the contig is EMPTY
     uint32_t W[6];    // compact image: summary word of each 64-record slot (k_pack_units): the component-wise
                       // maximum of the slot's record words = (65535 - smallest s') | largest e' << 16
-    int32_t pad;
+    int32_t pre;      // compact image: the unit's records that start BEFORE its tile (s' = 0) -- the first `pre` of it, the tile
+                      // being ordered by start; a tile covered from end to end counts the others without looking at them
 };
 #define UNIT_J(u) ((u).jf >> 4)
 #define UNIT_FLAGS(u) ((u).jf & 15)
@@ -447,6 +452,7 @@ __device__ __forceinline__ int query_word(int qs, int qe, bool first, int T, int
 }
 #define IGD_NEVER 0xFFFFFFFFu     // a query word no record word can match (e' <= W <= 32768 < 65535)
 #define QB_CTG 1024               // contigs whose tile tables k_query_bounds keeps in LDS
+#define QB_COVW 128               // tiles in a wave's LDS window of coverage differences
 
 // What k_query_bounds leaves per query for the merge join (sorted path):
 //   compact image (packed != 0):
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (i0 > 0 && i0 < nq) { if (!RUNS) pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
-    __shared__ int sCnt[NW];
+    __shared__ int sCnt[NW], sFixCnt[NW], sFixBase;
     const bool ldsTab = FAST || db.nCtg <= QB_CTG;
     const int packed = FAST ? 1 : packed_;
     // Has any wave found the batch unordered already?  ONE device-scope load per workgroup (an L1-cached one would keep
@@ -532,10 +538,12 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     __shared__ int sSeen;
     int seen = 0;
     if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
-    if (threadIdx.x < NW) sCnt[threadIdx.x] = 0;          // (a wave that leaves early counts as one without entries)
+    if (threadIdx.x < NW) { sCnt[threadIdx.x] = 0; sFixCnt[threadIdx.x] = 0; }   // (a wave that leaves early counts as one without entries)
     if (threadIdx.x == NW) sSeen = 0;                     // (defined also when wave 0 is the one that leaves before it stores the flag)
     if (ldsTab)
         for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
+    __shared__ int32_t sCovW[NW * QB_COVW];               // per wave: coverage differences of its long queries (see step 3)
+    for (int k = threadIdx.x; k < NW * QB_COVW; k += WGT) sCovW[k] = 0;
     __shared__ int32_t sRun[RUNS ? 2 * QB_CTG : 1];       // runStart[0..nCtg], padded with INT_MAX to a power of two
     __shared__ int sK[2];                                 // RUNS: contig of the batch's first and last query
     int runLevels = 0;
@@ -593,6 +601,9 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // worked through to the end, gap filling included, took 50 instead of 5 us).
     int w0v[VEC], w1v[VEC];
     int key[VEC], lo[VEC];
+    int pend[VEC];                                          // what the scan leaves to the exact walk: list entry of query i0 + v (0: none)
+#pragma unroll
+    for (int v = 0; v < VEC; v++) pend[v] = 0;
     bool quick = false;
     if (FAST && VEC == 4) {
         // ---- the short path: the wave's 256 queries and the one before them lie in one contig, inside its tiles, with
@@ -691,6 +702,9 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         }
     }
     // 3. the words the scan reads
+    int covA[VEC], covB[VEC];                               // what it leaves to the coverage arrays (covA < 0: nothing)
+#pragma unroll
+    for (int v = 0; v < VEC; v++) { covA[v] = -1; covB[v] = -1; }
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
@@ -705,13 +719,13 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             // what the scan kernel leaves to k_exact_walk (the walk applies the visiting rule itself)
             if (n2 - n1 >= IGD_SHORT_TILES) {
                 // a long query: its last tile is walked exactly, the tiles n1+4 .. n2-1 are covered from end to end (IGD_COV_*)
-                fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_LAST | (qc[v] << 4));   // (the walk finds the contig here)
+                pend[v] = WALK_LAST | (qc[v] << 4);     // (the walk finds the contig here)
                 if (n2 - n1 > IGD_SHORT_TILES && !(rule == IGD_HIP_RULE_NEST && db.tileCnt[g0] == 0)) {   // (rule NEST: an empty first tile ends the query)
-                    cover_tiles(db, ctl, 0, epoch, g0 + IGD_SHORT_TILES, g0 + (n2 - n1));
+                    covA[v] = g0 + IGD_SHORT_TILES; covB[v] = g0 + (n2 - n1);    // covered from end to end: tiles covA .. covB - 1
                 }
             }
             const bool needExact = packed && e0 <= T0;
-            if (needExact) fix[atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], 1)] = make_int2(i, WALK_FIRST | (qc[v] << 4));
+            if (needExact) pend[v] = WALK_FIRST | (qc[v] << 4);
             if (!packed) w0v[v] = (g0 << 4) | (span < 15 ? span : 15);
             else {
                 // rule NEST (an empty first tile ends the query, :468) needs no look-up here: the first tile's own
@@ -726,6 +740,42 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                     for (int kk = 1; kk <= sp; kk++) spill[g0 + kk] = epoch;
                 }
             }
+        }
+    }
+    // The coverage differences of the wave's long queries.  A position-sorted batch puts the +1 / -1 of neighbouring queries on
+    // the same few entries of the difference array: one global atomic per query end made 7 x 10^5 requests to the memory side
+    // for 10^6 queries of 100-200 kbp (this kernel: 250 us; 10 without long queries).  They are summed in a window of the
+    // wave's own LDS first -- QB_COVW tiles from the first tile its queries cover -- and every entry of the window that is
+    // not zero goes out as one atomic, neighbouring entries in one request; an end beyond the window (a sparse batch, a very
+    // long query) takes the direct way.  The coarse level (a query crossing a block of 1024 tiles) stays direct: it is rare.
+    {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) any |= __ballot(covA[v] >= 0);
+        if (any) {
+            int32_t *win = sCovW + (threadIdx.x >> 6) * QB_COVW;
+            int first = INT_MAX;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) if (covA[v] >= 0 && covA[v] < first) first = covA[v];
+            for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(first, o); first = x < first ? x : first; }
+            int32_t *diff = db.cov + (size_t)(0 * 2 + (epoch & 1)) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                if (covA[v] < 0) continue;
+                const int ta = covA[v], tb = covB[v];
+                if ((unsigned)(ta - first) < (unsigned)QB_COVW) atomicAdd(&win[ta - first], 1); else atomicAdd(&diff[ta], 1);
+                if ((unsigned)(tb - first) < (unsigned)QB_COVW) atomicAdd(&win[tb - first], -1); else atomicAdd(&diff[tb], -1);
+                if ((ta >> IGD_COV_SHIFT) != (tb >> IGD_COV_SHIFT)) { atomicAdd(&coarse[ta >> IGD_COV_SHIFT], 1); atomicAdd(&coarse[tb >> IGD_COV_SHIFT], -1); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < QB_COVW; k += IGD_WAVE) {
+                const int d = win[k];
+                if (d != 0) { win[k] = 0; if (first + k <= db.nT + 1) atomicAdd(&diff[first + k], d); }
+            }
+            if (lane == 0) ctl[CTL_COV + 0 * 2 + (epoch & 1)] = epoch;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     }
@@ -745,6 +795,11 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     for (int v = 0; v < VEC; v++) c += w1v[v] != 0 ? 1 : 0;
     const int inc = wave_inclusive_sum(c);
     if (lane == 63) sCnt[threadIdx.x >> 6] = inc;
+    // the queries listed for the exact walk: counted per wave here, appended per WORKGROUP below
+    int myFix = 0;
+#pragma unroll
+    for (int v = 0; v < VEC; v++) myFix += __popcll(__ballot(pend[v] != 0));
+    if (lane == 0 && myFix) sFixCnt[threadIdx.x >> 6] = myFix;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read (the merge join is
     // off, the bucket path keeps its own lists): workgroups that see the mark stop here, before they store anything (an
     // unordered batch worked through to the end, gap filling included, took 50 instead of 5 us).
@@ -752,6 +807,29 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     __syncthreads();
     const bool marked = sSeen == epoch;
     if (marked) return;
+    {
+        // ONE returning atomic per workgroup for the list of the exact walk.  Requests for one address are served one after
+        // the other by its memory channel, ~12 ns each: one per long query -- and still one per wave and pass -- made this
+        // kernel take 190-250 us for 10^6 queries of which a quarter or all are long (10 us without).
+        const int fm = lane < NW ? sFixCnt[lane] : 0;
+        const int fr = wave_inclusive_sum(fm);
+        const int ftotal = __builtin_amdgcn_readlane(fr, NW - 1);
+        if (ftotal) {                                       // (the same number in every wave of the workgroup)
+            const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            const int before = wv > 0 ? __builtin_amdgcn_readlane(fr, wv - 1) : 0;
+            // (asked for by the first wave that has entries: it is certainly still here -- wave 0 may have left the kernel
+            // when it saw the batch out of order)
+            if (lane == 0 && before == 0 && myFix > 0) sFixBase = atomicAdd(&ctl[CTL_NFIX + (epoch & 1)], ftotal);
+            __syncthreads();
+            int at = sFixBase + before;
+#pragma unroll
+            for (int v = 0; v < VEC; v++) {
+                const unsigned long long m = __ballot(pend[v] != 0);
+                if (pend[v] != 0) fix[at + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(i0 + v, pend[v]);
+                at += __popcll(m);
+            }
+        }
+    }
     if (blockLive && !(IGD_EXP & 8192)) {
         // entries of the waves before this one / of the whole block: one LDS read per lane and a wave scan (the numbers
         // are the same for all lanes of a wave)
@@ -1211,6 +1289,7 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict_
         const Unit u = unitsOut[ui];
         const int T = (int)((unsigned)UNIT_J(u) * (unsigned)db.nbp);
         unsigned mx[6] = {0u, 0u, 0u, 0u, 0u, 0u};        // summary words of the unit's slots
+        int npre = 0;
         for (int i0 = 0; i0 < u.n; i0 += IGD_WAVE) {
             const int i = i0 + lane;
             unsigned edv = 0u, spv = 65535u;
@@ -1237,11 +1316,14 @@ __global__ __launch_bounds__(256) void k_pack_units(DbView db, Unit *__restrict_
                 const unsigned y = (unsigned)__shfl_xor((int)edv, o);
                 edv = y > edv ? y : edv;
             }
+            npre += __popcll(__ballot(spv == 0u));
             const unsigned s0 = (unsigned)__shfl((int)spv, 0);      // the tile is sorted by start: the slot's first record has its smallest s'
             if (i0 / IGD_WAVE < 6) mx[i0 / IGD_WAVE] = (65535u - s0) | (edv << 16);
         }
-        if (lane == 0)
+        if (lane == 0) {
             for (int r = 0; r < 6; r++) unitsOut[ui].W[r] = mx[r];
+            unitsOut[ui].pre = npre;
+        }
     }
     if (wide) atomicOr(flag, wide);
 }
@@ -1273,14 +1355,14 @@ struct Raw {
 };
 
 // A Unit held one-per-lane in VGPRs, and its wave-uniform broadcast.
-struct UnitRegs { int32_t offLo, offHi, tile, n, jf, w[6]; };
+struct UnitRegs { int32_t offLo, offHi, tile, n, jf, w[6], pre; };
 __device__ __forceinline__ UnitRegs load_unit_regs(const Unit *p)
 {
     const int4 a = ((const int4 *)p)[0], b = ((const int4 *)p)[1], c = ((const int4 *)p)[2];
     UnitRegs r;
     r.offLo = a.x; r.offHi = a.y; r.tile = a.z; r.n = a.w;
     r.jf = b.x; r.w[0] = b.y; r.w[1] = b.z; r.w[2] = b.w;
-    r.w[3] = c.x; r.w[4] = c.y; r.w[5] = c.z;
+    r.w[3] = c.x; r.w[4] = c.y; r.w[5] = c.z; r.pre = c.w;
     return r;
 }
 
@@ -1298,6 +1380,7 @@ struct ScanArgs {
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
     u64 *total;                  // k_exact_walk: batch total (may be null)
     u64 *hitsOut;                // the caller's hits[] (the skew kernels add to it directly)
+    int packedWalk;              // the exact walk of a long query's LAST tile may read the compact image: 1 (pse + px), 2 (pse + pxv: `-v`), 0 (no image)
 };
 
 // Issue the loads of unit kk.  BRANCH-FREE on purpose: every call issues exactly the same
@@ -2764,6 +2847,12 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
     for (int l0 = gwave * per; l0 < nList; l0 += nwaves * per) {
         const int cnt = nList - l0 < per ? nList - l0 : per;
         int vq = 0, vkind = -1, vqs = 0, vqe = 0, vn1 = 0, vj1 = -1, vbase = 0, vcnt = 0, voffLo = 0, voffHi = 0, vlob = 0;
+        int vu0 = 0, vnu = 0, vqe2 = 0;                  // WALK_LAST over the compact image: the last tile's units, the query's qe'
+        UnitRegs vur;
+        vur.offLo = vur.offHi = vur.tile = vur.n = vur.jf = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) vur.w[r] = 0;
+        const bool cimg = USE_V ? a.packedWalk == 2 : a.packedWalk != 0;
         if (lane < cnt) {
             const int2 ent = list[l0 + lane];
             vq = ent.x; vkind = ent.y & 15;
@@ -2778,6 +2867,14 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[vbase + vn1] == 0) vj1 = -1;   // :468 -- nothing to walk
             if (vj1 >= 0) {                              // ... and the first tile of the walk (the only one of WALK_LAST and WALK_FIRST)
                 const int jf = vkind == WALK_LAST ? vj1 : vn1;
+                if (jf <= vj1 && cimg && vkind == WALK_LAST) {
+                    vu0 = db.tileUnit0[vbase + jf]; vnu = db.tileUnit0[vbase + jf + 1] - vu0;
+                    vcnt = vnu;                          // (0: an empty tile)
+                    if (vnu > 0) vur = load_unit_regs(db.units + vu0);     // the tile's first unit (mostly its only one)
+                    const int T0 = (int)((unsigned)jf * (unsigned)db.nbp);
+                    vqe2 = vqe - T0;
+                    vqe2 = (vqe2 < db.nbp ? vqe2 : db.nbp) + 1;
+                } else
                 if (jf <= vj1) {
                     vcnt = db.tileCnt[vbase + jf];
                     const int64_t o = db.tileOff[vbase + jf];
@@ -2786,11 +2883,90 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                 }
             }
         }
+        if (cimg) {
+            // The LAST tile of the group's long queries over the COMPACT image.  Such a query covers the tile from its start up
+            // to qe, so a record counts iff it starts in the tile (s' >= 1: the copy that counts, :510-511) before qe (s' < qe');
+            // its end is beyond the query's start by construction.  Records are ordered by start and every 64-record slot's
+            // smallest s' is in the unit's descriptor -- fetched one per lane with the group's other look-ups -- so the slots at or
+            // beyond qe' are never loaded (on average half the tile) and a record is 6 bytes (12 in the exact arrays).  What
+            // bounds a walk is the round trip for its records: TWO walks are in flight per wave.
+            struct Walk { uint32_t pa[IGD_SLOTS], px[IGD_SLOTS]; int qe2, live; };
+            auto issue = [&](int e, Walk &w) {
+                w.qe2 = __builtin_amdgcn_readlane(vqe2, e);
+                const int n = __builtin_amdgcn_readlane(vur.n, e);
+                const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(vur.offHi, e) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane(vur.offLo, e));
+                w.live = 0;
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int i = r * IGD_WAVE + lane;
+                    const bool on = r * IGD_WAVE < n && (int)(65535u - ((unsigned)__builtin_amdgcn_readlane(vur.w[r], e) & 0xFFFFu)) < w.qe2;   // wave-uniform
+                    w.pa[r] = 0xFFFFu; w.px[r] = 0u;     // (s' = 0: counts nothing)
+                    if (on) {
+                        w.live |= 1 << r;
+                        if (i < n) { w.pa[r] = db.pse[off + i]; w.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                    }
+                }
+            };
+            auto count = [&](const Walk &w) {
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    if (!(w.live & (1 << r))) continue;
+                    const int s2 = (int)(65535u - (w.pa[r] & 0xFFFFu));
+                    bool hit = s2 >= 1 && s2 < w.qe2;
+                    if (USE_V) hit = hit && ((int)w.px[r] >> 16) >= a.v;
+                    const int ix = (int)(w.px[r] & 0xFFFFu);
+                    found += __popcll(__ballot(hit));
+                    if (hit) { if (hist) atomicAdd(&hist[ix], 1ull); else atomicAdd(&a.out[ix], 1ull); }
+                }
+            };
+            unsigned long long m = __ballot(lane < cnt && vkind == WALK_LAST && vj1 >= 0 && vnu > 0);
+            // the further chunks of a tile of more than 320 records (rare): one after the other
+            auto more = [&](int e) {
+                for (int u = __builtin_amdgcn_readlane(vu0, e) + 1, ue = __builtin_amdgcn_readlane(vu0, e) + __builtin_amdgcn_readlane(vnu, e); u < ue; u++) {
+                    const UnitRegs ur = load_unit_regs(db.units + u);          // the same unit in every lane
+                    const int qe2 = __builtin_amdgcn_readlane(vqe2, e);
+                    if ((int)(65535u - ((unsigned)__builtin_amdgcn_readfirstlane(ur.w[0]) & 0xFFFFu)) >= qe2) break;   // sorted: nothing here or behind
+                    const int n = __builtin_amdgcn_readfirstlane(ur.n);
+                    const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ur.offHi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(ur.offLo));
+                    Walk C;
+                    C.qe2 = qe2; C.live = 0;
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int i = r * IGD_WAVE + lane;
+                        C.pa[r] = 0xFFFFu; C.px[r] = 0u;
+                        if (r * IGD_WAVE < n) {
+                            C.live |= 1 << r;
+                            if (i < n) { C.pa[r] = db.pse[off + i]; C.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                        }
+                    }
+                    count(C);
+                }
+            };
+            // FOUR walks in flight per wave (the tail's long-query work runs on a quarter of the launch's workgroups, see batch_tail)
+            Walk W0, W1, W2, W3;
+            int e0 = -1, e1 = -1, e2 = -1, e3 = -1;
+#define IGD_WALK_NEXT(E, W) do { E = -1; if (m) { E = __builtin_ctzll(m); m &= m - 1; issue(E, W); } } while (0)
+            IGD_WALK_NEXT(e0, W0); IGD_WALK_NEXT(e1, W1); IGD_WALK_NEXT(e2, W2); IGD_WALK_NEXT(e3, W3);
+            while (e0 >= 0) {
+                count(W0); more(e0); IGD_WALK_NEXT(e0, W0);
+                if (e1 >= 0) { count(W1); more(e1); IGD_WALK_NEXT(e1, W1); }
+                if (e2 >= 0) { count(W2); more(e2); IGD_WALK_NEXT(e2, W2); }
+                if (e3 >= 0) { count(W3); more(e3); IGD_WALK_NEXT(e3, W3); }
+                if (e0 < 0) {                              // slot 0 ran dry first: the others hold what is left
+                    if (e1 >= 0) { count(W1); more(e1); e1 = -1; }
+                    if (e2 >= 0) { count(W2); more(e2); e2 = -1; }
+                    if (e3 >= 0) { count(W3); more(e3); e3 = -1; }
+                }
+            }
+#undef IGD_WALK_NEXT
+        }
         for (int e = 0; e < cnt; e++) {
             const int kind = __builtin_amdgcn_readlane(vkind, e), qs = __builtin_amdgcn_readlane(vqs, e), qe = __builtin_amdgcn_readlane(vqe, e);
             const int n1 = __builtin_amdgcn_readlane(vn1, e), base = __builtin_amdgcn_readlane(vbase, e);
             int j1 = __builtin_amdgcn_readlane(vj1, e);
             if (j1 < 0) continue;
+            if (kind == WALK_LAST && cimg) continue;       // (done above, over the compact image)
             int j0 = n1;
             if (kind == WALK_LAST) j0 = j1;              // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
             if (kind == WALK_FIRST) j1 = n1;
@@ -2845,7 +3021,7 @@ __device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int 
     }
 }
 
-#define IGD_COV_CHUNK 32      // units a wave takes at a time (strided over the launch's waves: long queries may all lie in one region)
+#define IGD_COV_CHUNK 16      // units a wave takes at a time (32 left a quarter of the last launch's 8192 waves without a chunk of the benchmark's 190 000 units) (strided over the launch's waves: long queries may all lie in one region)
 template <bool USE_V>
 __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
                                               u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
@@ -2890,29 +3066,69 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
         }
         const int since = wave_inclusive_sum(d);          // (every lane takes part)
         const int cv = lane < cnt ? p0 + since : 0;
-        if (__ballot(cv > 0) == 0) continue;             // nothing of this chunk is covered
-        for (int e = 0; e < cnt; e++) {
-            const int c = __builtin_amdgcn_readlane(cv, e);
-            if (c <= 0) continue;
-            const int n = __builtin_amdgcn_readlane(ur.n, e), lob = __builtin_amdgcn_readlane(bd, e);
+        unsigned long long m = __ballot(cv > 0);
+        if (m == 0) continue;                            // nothing of this chunk is covered
+        // What bounds a covered unit is the round trip for its records: TWO units are in flight per wave (the loads of the
+        // next covered unit are issued before the current one is counted).
+        struct Cov { int st[IGD_SLOTS], ix[IGD_SLOTS], va[USE_V ? IGD_SLOTS : 1]; int c, lob; };
+        // (compact image: the records that start in the tile are the unit's records from number `pre` on -- Unit::pre -- so
+        // only their dataset numbers are read: 2 bytes a record, 4 with the value, where the exact arrays cost 8 and 12)
+        const bool cimg = USE_V ? a.packedWalk == 2 : a.packedWalk != 0;
+        auto issue = [&](int e, Cov &w) {
+            w.c = __builtin_amdgcn_readlane(cv, e);
+            w.lob = __builtin_amdgcn_readlane(bd, e);
+            const int n = __builtin_amdgcn_readlane(ur.n, e);
             const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ur.offHi, e) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane(ur.offLo, e));
-            int st[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];   // the whole unit's loads in flight together
+            if (cimg) {
+                const int pre = __builtin_amdgcn_readlane(ur.pre, e);
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int i = r * IGD_WAVE + lane;
+                    const bool in = i >= pre && i < n;
+                    w.st[r] = in ? INT_MAX : INT_MIN;            // (>= lob / < lob)
+                    w.ix[r] = 0;
+                    if (USE_V) w.va[r] = INT_MIN;
+                    if (in && (r + 1) * IGD_WAVE > pre && r * IGD_WAVE < n) {
+                        if (USE_V) { const uint32_t x = db.pxv[off + i]; w.ix[r] = (int)(x & 0xFFFFu); w.va[r] = (int)x >> 16; }
+                        else w.ix[r] = (int)db.px[off + i];
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 const int i = r * IGD_WAVE + lane;
-                st[r] = i < n ? db.start[off + i] : INT_MIN;
-                ix[r] = i < n ? db.idx[off + i] : 0;
-                if (USE_V) va[r] = i < n ? db.value[off + i] : INT_MIN;
+                w.st[r] = i < n ? db.start[off + i] : INT_MIN;
+                w.ix[r] = i < n ? db.idx[off + i] : 0;
+                if (USE_V) w.va[r] = i < n ? db.value[off + i] : INT_MIN;
             }
+        };
+        auto count = [&](const Cov &w) {
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
-                bool in = st[r] >= lob;                  // the copy of the record that counts (:510-511)
-                if (USE_V) in = in && va[r] >= a.v;
-                found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)c;
-                if (in) { if (hist) atomicAdd(&hist[ix[r]], (u64)(unsigned)c); else atomicAdd(&d_hits[ix[r]], (u64)(unsigned)c); }
+                bool in = w.st[r] >= w.lob;              // the copy of the record that counts (:510-511)
+                if (USE_V) in = in && w.va[r] >= a.v;
+                found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)w.c;
+                if (in) { if (hist) atomicAdd(&hist[w.ix[r]], (u64)(unsigned)w.c); else atomicAdd(&d_hits[w.ix[r]], (u64)(unsigned)w.c); }
+            }
+        };
+        Cov C0, C1, C2, C3;                              // FOUR covered units in flight per wave
+        int e0 = -1, e1 = -1, e2 = -1, e3 = -1;
+#define IGD_COV_NEXT(E, C) do { E = -1; if (m) { E = __builtin_ctzll(m); m &= m - 1; issue(E, C); } } while (0)
+        IGD_COV_NEXT(e0, C0); IGD_COV_NEXT(e1, C1); IGD_COV_NEXT(e2, C2); IGD_COV_NEXT(e3, C3);
+        while (e0 >= 0) {
+            count(C0); IGD_COV_NEXT(e0, C0);
+            if (e1 >= 0) { count(C1); IGD_COV_NEXT(e1, C1); }
+            if (e2 >= 0) { count(C2); IGD_COV_NEXT(e2, C2); }
+            if (e3 >= 0) { count(C3); IGD_COV_NEXT(e3, C3); }
+            if (e0 < 0) {
+                if (e1 >= 0) { count(C1); e1 = -1; }
+                if (e2 >= 0) { count(C2); e2 = -1; }
+                if (e3 >= 0) { count(C3); e3 = -1; }
             }
         }
+#undef IGD_COV_NEXT
     }
     if (d_total && lane == 0 && found) atomicAdd(d_total, found);
 }
@@ -2941,6 +3157,8 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
             __syncthreads();
         }
     }
+    // (Tried: the long queries' work on a quarter of the launch's workgroups, to quarter the 3.9 x 10^6 atomics with which 2048
+    // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
     exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
     coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
     if (hist) {
@@ -2972,9 +3190,9 @@ __global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const i
     batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
 }
 
-// slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/256), IGD_REDUCE_GROUPS)
+// slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/IGD_TAIL_WG), IGD_REDUCE_GROUPS)
 template <bool USE_V>
-__global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
+__global__ __launch_bounds__(IGD_TAIL_WG) void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
                                                       u64 *__restrict__ hits, u64 *__restrict__ total,
                                                       const int32_t *__restrict__ ctl, int brokenIf,
                                                       ScanArgs wa, const int2 *__restrict__ fixList,
@@ -2982,10 +3200,11 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
                                                       int rows32 /* != 0: igd_scan_sorted of epoch `rows32` wrote 32-bit rows (unless the batch went to the bucket path) */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ u64 red[4];
+    __shared__ u64 red[IGD_TAIL_WG / IGD_WAVE];
+    constexpr int WPB = IGD_TAIL_WG / IGD_WAVE;           // waves per workgroup
     // the batch's control words, word i in lane i: one load, in flight together with the slab rows
     const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? ctl[threadIdx.x & 63] : 0;
-    int f = blockIdx.x * 256 + threadIdx.x;
+    int f = blockIdx.x * IGD_TAIL_WG + threadIdx.x;
     u64 s = 0;
     if (f < nFiles && blockIdx.y < IGD_REDUCE_GROUPS) {  // (the workgroups beyond are there for the batch's tail only, see the launch)
         // (both kinds of rows are read before the control words say which kind this batch left: the loads are in flight
@@ -3003,7 +3222,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     }
     // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
     // scan kernel wrote no slab, so nothing may be added
-    if (valves >= 0) coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * 4, ctlv);
+    if (valves >= 0) coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * WPB + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * WPB, ctlv);
     if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
     if (s) atomicAdd(&hits[f], s);
     if (total) {
@@ -3011,7 +3230,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            u64 t = red[0] + red[1] + red[2] + red[3];
+            u64 t = 0;
+            for (int k = 0; k < WPB; k++) t += red[k];
             if (t) atomicAdd(total, t);
         }
     }
@@ -3019,8 +3239,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(SortK K, const u64 *__rest
     // ... and the batch's exact-walk list and skew valves (normally empty) ride in the same launch
     const int nb = gridDim.x * gridDim.y;
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    const int gwave = bid * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, wa.out, total, smem, gwave, nb * 4, ctlv);   // (wa.out: the caller's hits[]; `hits` is a window of it in a windowed batch)
+    const int gwave = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, wa.out, total, smem, gwave, nb * WPB, ctlv);   // (wa.out: the caller's hits[]; `hits` is a window of it in a windowed batch)
 }
 
 // without LDS counters the batch total is the growth of sum(hits): measured around the launch
@@ -3517,7 +3737,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                     u.tile = (int32_t)t;
                     u.n = cnt - r0 < IGD_CHUNK ? cnt - r0 : IGD_CHUNK;
                     for (int r = 0; r < 6; r++) u.W[r] = 0;
-                    u.pad = 0;
+                    u.pre = 0;
                     int fl = r0 == 0 ? 1 : 0;
                     for (int k = 1; k < IGD_SHORT_TILES && k <= j; k++)
                         if (d->nCnt[t - k] <= 0) fl |= 1 << k;
@@ -3761,6 +3981,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                                  (const void *)igd_scan_sorted<true, true, true, false, false, 3>, (const void *)igd_scan_sorted<true, true, true, false, true, 3>};
             for (const void *fn : wfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
         }
+    }
+    {   // the batch's last launch: its workgroups of 16 waves carry 16 rank-method areas (the skew valves) and the 64-bit counters
+        // of the long queries' work (up to 48 KiB): beyond the 64 KiB a kernel gets without asking
+        const void *tfn[] = {(const void *)k_reduce_slabs<false>, (const void *)k_reduce_slabs<true>};
+        for (const void *fn : tfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     }
 #undef TRY
 #undef TRYHIP
@@ -4139,11 +4364,12 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     a.walkList = nullptr; a.ctl = db->d_ctl; a.q_ichr = d_ichr; a.q_qs = d_qs; a.q_qe = d_qe; a.q_w = db->d_qw;
     a.total = (u64 *)d_total; a.hitsOut = (u64 *)d_hits;
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
+    a.packedWalk = packed ? (useV ? 2 : 1) : 0;
     // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
     const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
                        (db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
     // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
-    size_t tailLds = (valves & 2) ? (size_t)4 * (size_t)IGD_WLDS_BYTES : 0;
+    size_t tailLds = (valves & 2) ? (size_t)(db->ldsHits ? IGD_TAIL_WG / IGD_WAVE : 4) * (size_t)IGD_WLDS_BYTES : 0;   // (k_exact_walk: workgroups of 4 waves)
     int tailHistOff = -1;                                // u64 counters for the exact walks and the coverage, when the files fit
     if ((size_t)db->nFiles * 8 <= (size_t)48 * 1024) { tailHistOff = (int)tailLds; tailLds += (size_t)db->nFiles * 8; }
     if (db->ldsHits) {
@@ -4168,14 +4394,14 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
             // IGD_REDUCE_GROUPS row groups sum the slab; the launch is filled up to IGD_TAIL_WGS workgroups (8 waves per SIMD),
             // which find out from the batch's control words that the tail has nothing for them -- or share a long
             // exact-walk list and the coverage of long queries, whose loops are chains of dependent loads
-            const int gx = (fileN + 255) / 256;
+            const int gx = (fileN + IGD_TAIL_WG - 1) / IGD_TAIL_WG;
             dim3 rg(gx, (!last || IGD_REDUCE_GROUPS * gx >= IGD_TAIL_WGS) ? IGD_REDUCE_GROUPS : (IGD_TAIL_WGS + gx - 1) / gx);
             const int rows32 = (mode != 2 && packed) ? db->epoch : 0;      // the merge join's kernel leaves 32-bit rows (CNT32)
             if (useV)
-                k_reduce_slabs<true><<<rg, 256, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
+                k_reduce_slabs<true><<<rg, IGD_TAIL_WG, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
                                                                db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, last ? valves : -1, rows32);
             else
-                k_reduce_slabs<false><<<rg, 256, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
+                k_reduce_slabs<false><<<rg, IGD_TAIL_WG, last ? tailLds : 0, st>>>(Kt, db->d_slab, db->grid, fileN, (u64 *)d_hits + fileLo, (u64 *)d_total,
                                                                 db->d_ctl, mode == 1 ? db->epoch : 0, w, db->d_fix, db->d_long, db->d_heavy, last ? valves : -1, rows32);
         }
     } else {
