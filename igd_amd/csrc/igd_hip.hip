@@ -216,6 +216,15 @@ struct DbView {
     const int32_t *ctgNTile;                    // [nCtg]
     const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
     int32_t *cov;                               // workspace: 4 sets of coverage difference arrays (IGD_COV_*)
+    // A database whose file is bucketed with another tile width than the image likes (-b 11..13, 16..19) is searched over a
+    // RE-TILED copy: the same records in tiles of 2^14 bp (igd_hip_db::inner).  Which records a query counts does not depend on
+    // the tile width -- every record that overlaps it, once -- with two exceptions that are properties of the FILE's tiles: a
+    // query whose first tile lies outside the contig's tiles counts nothing (:462), and under rule NEST neither does one whose
+    // first tile is empty (:468).  vshift >= 0 marks such a copy: log2 of the file's tile width; rNTile / rBase / rEmpty describe
+    // the file's tiles (per contig: their number and the number of the first one; one bit per tile: it holds no record).
+    int32_t vshift;
+    const int32_t *rNTile, *rBase;
+    const uint32_t *rEmpty;
     int32_t fileLo;                             // scan kernels, WIN builds: the pass counts the files [fileLo, fileLo + nFiles) (see igd_hip_db::winN)
 };
 
@@ -241,6 +250,9 @@ struct igd_hip_db {
     int32_t *d_lpos;              // [nT+1] lpos[]: entries of its later block before query firstQ[t] (k_query_bounds)
     int32_t *d_cov;               // coverage of long queries (IGD_COV_*): 4 sets (path x batch parity) of { diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2] }
     bool covStale;                // a batch returned an error after its first kernel: clear d_cov before the next one
+    igd_hip_db *inner;            // the re-tiled copy the counting searches run on (file bucketed with -b 11..13 / 16..19), else null
+    uint32_t *d_rEmpty;           // ... and its bitmap of the FILE's empty tiles
+    int vnest;                    // (set on a re-tiled copy by the call that forwards to it: rule NEST of that call)
     int32_t *d_runIchr;           // igd_hip_search_runs_dev: contig numbers written out for the batches the RUNS build does not take
     int64_t runCap;
     int32_t *d_qw;                // [wsQueries] per-query word of the merge join (k_query_bounds: qw0)
@@ -347,6 +359,16 @@ __device__ __forceinline__ int tile_of(const DbView &db, int x)
     return x / db.nbp;
 }
 
+// Re-tiled copy (DbView::vshift >= 0): does the FILE's tiling let this query count anything?  nest: rule NEST of the call.
+__device__ __forceinline__ bool real_gate(const DbView &db, int c, int qs, bool nest)
+{
+    const int n1 = tile_shift(qs, db.vshift);            // C division by the file's tile width (:459)
+    if (n1 < 0 || n1 >= db.rNTile[c]) return false;      // (:462; n1 < 0: out of bounds in the reference)
+    if (!nest) return true;
+    const unsigned g = (unsigned)(db.rBase[c] + n1);
+    return ((db.rEmpty[g >> 5] >> (g & 31)) & 1u) == 0u; // (:468)
+}
+
 // Tile span of one query = the prologue of every reference kernel (src/igd_search.c:455-467):
 // n1=qs/nbp, n2=(qe-1)/nbp (C division), n1>mTile -> nothing, n2 clamped, and for rule NEST an
 // empty first tile ends the query (:468).  Returns false when the query visits nothing.
@@ -354,6 +376,11 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
                                            int &gt0, int &ntl)
 {
     if (c < 0 || c >= db.nCtg) return false;
+    if (db.vshift >= 0) {                     // a re-tiled copy: the file's tiles decide whether the query counts at all ...
+        if (!real_gate(db, c, qs, (rule >> 8) & 1)) return false;
+        if (qs < 0) qs = 0;                   // ... and a start before the contig (above -nbp of the file) lies in tile 0
+        rule &= 0xff;                         // (the copy's own tiles are visited under rule FLAT)
+    }
     int n1 = tile_of(db, qs);
     int n2 = tile_of(db, (int)((unsigned)qe - 1u));
     int mT = db.ctgNTile[c] - 1;
@@ -507,6 +534,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                                                       int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
     constexpr int NW = WGT / IGD_WAVE;
+    const bool vnest = (rule >> 8) & 1;                   // a re-tiled copy (DbView::vshift): rule NEST of the call, applied to the FILE's tiles
+    rule &= 0xff;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
     // and the batch's state is looked up (a workgroup that then leaves at once has read 12 KiB for nothing).
     const int i0 = (int)(blockIdx.x * WGT + threadIdx.x) * VEC;
@@ -605,7 +634,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
 #pragma unroll
     for (int v = 0; v < VEC; v++) pend[v] = 0;
     bool quick = false;
-    if (FAST && VEC == 4) {
+    if (FAST && VEC == 4 && db.vshift < 0) {
         // ---- the short path: the wave's 256 queries and the one before them lie in one contig, inside its tiles, with
         // non-negative starts in non-decreasing order, and none is inverted over its tile's start or longer than four tiles
         const int W = db.nbp, sh = db.shift;
@@ -658,7 +687,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             if (pc < 0) prevKey = 0;
             else if (pc >= db.nCtg) prevKey = db.nT - 1;
             else {
-                const int n1 = tile_shift(ps, db.shift), mT = sNTile[pc] - 1;
+                const int n1 = tile_shift(ps, db.shift), mT = sNTile[pc] - 1;     // (negative: clamped to tile 0 either way)
                 prevKey = sBase[pc] + (n1 < 0 ? 0 : (n1 > mT ? mT : n1));
             }
         } else prevKey = tile_key(db, pc, ps);
@@ -675,7 +704,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const int c = qc[v], s0 = qs_[v];
             const bool cOk = c >= 0 && c < db.nCtg;
             const int cb = cOk ? QB_BASE(c) : 0, cm = cOk ? QB_NTILE(c) - 1 : 0;
-            const int n1r = QB_TILE(s0);
+            const int n1r = QB_TILE((db.vshift >= 0 && s0 < 0) ? 0 : s0);
             // key(i): global number of the first tile, clamped into the contig (tile_key)
             const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
             const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cb + n1c);
@@ -708,8 +737,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
-        const int s0 = qs_[v], n1 = QB_TILE(s0);
-        if (i < nq && n1 >= 0 && n1 <= cMT[v]) {
+        const int s0 = qs_[v], n1 = QB_TILE((db.vshift >= 0 && s0 < 0) ? 0 : s0);   // (re-tiled copy: a start above -nbp of the FILE lies in tile 0)
+        if (i < nq && n1 >= 0 && n1 <= cMT[v] && (db.vshift < 0 || real_gate(db, qc[v], s0, vnest))) {
             const int e0 = qe_[v];
             int n2 = QB_TILE((int)((unsigned)e0 - 1u));
             if (n2 > cMT[v]) n2 = cMT[v];
@@ -918,6 +947,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
 // queries with qe <= tile start.  Returns the exact-walk kind or -1.
 __device__ __forceinline__ int walk_kind(const DbView &db, int qs, int qe, int ntl, int packed)
 {
+    if (db.vshift >= 0 && qs < 0) qs = 0;                 // (re-tiled copy: see query_span)
     if (ntl > IGD_SHORT_TILES) return WALK_ALL;
     if (packed && qe <= (int)((unsigned)tile_of(db, qs) * (unsigned)db.nbp)) return WALK_FIRST;
     return -1;
@@ -2858,7 +2888,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             vq = ent.x; vkind = ent.y & 15;
             vqs = a.q_qs[vq]; vqe = a.q_qe[vq];
             const int cc = sortedPath ? ent.y >> 4 : a.q_ichr[vq];     // (k_query_bounds' entries carry the contig: a batch given as runs has no ichr[])
-            vn1 = tile_of(db, vqs);
+            vn1 = tile_of(db, (db.vshift >= 0 && vqs < 0) ? 0 : vqs);     // (re-tiled copy: see query_span)
             int n2 = tile_of(db, (int)((unsigned)vqe - 1u));
             const int mT = db.ctgNTile[cc] - 1;
             if (n2 > mT) n2 = mT;
@@ -3568,7 +3598,9 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     }
 #endif
     if (t_arenaOwner == db) t_arenaOwner = nullptr;
+    if (db->inner) { igd_hip_close(db->inner); db->inner = nullptr; }
     (void)hipSetDevice(db->device);
+    if (db->d_rEmpty) (void)hipFree(db->d_rEmpty);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
                     db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
@@ -3595,7 +3627,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
 
 extern "C" int igd_hip_device(const igd_hip_db *db) { return db ? db->device : -1; }
 extern "C" int32_t igd_hip_nfiles(const igd_hip_db *db) { return db ? db->nFiles : 0; }
-extern "C" int64_t igd_hip_resident_bytes(const igd_hip_db *db) { return db ? db->resident : 0; }
+extern "C" int64_t igd_hip_resident_bytes(const igd_hip_db *db) { return db ? db->resident + (db->inner ? db->inner->resident : 0) : 0; }
 // Enumeration results are returned in PINNED host memory (the D2H copy of ~16 bytes per overlap is
 // the slowest step of `-f`; pageable memory runs it at a fifth of the PCIe rate).  Pinning is
 // expensive, so one released buffer is kept for the next call.
@@ -3636,6 +3668,7 @@ extern "C" const char *igd_hip_scan_kernel_name(void) { return "igd_scan_sorted"
 // which scan kernel the last batch of `db` ran on (waits for it: the device decides for an IGD_HIP_FLAG default batch)
 extern "C" const char *igd_hip_last_scan_kernel(igd_hip_db *db)
 {
+    if (db && db->inner) return igd_hip_last_scan_kernel(db->inner);
     if (!db || db->epoch == 0) return "";
     if (db->lastMode == 2) return "igd_scan_tiles";
     int32_t uns = 0;
@@ -3652,6 +3685,72 @@ static double wall_s(void)
     return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 #define OPEN_PHASE(name) do { if (tim) { double t_ = wall_s(); fprintf(stderr, "[igd timing]   open: %-22s %8.1f ms\n", name, 1e3 * (t_ - t0)); t0 = t_; } } while (0)
+
+// see igd_hip_open: the records of `db` once each, bucketed again in tiles of 2^14 bp, as a database of its own
+static int build_retiled(igd_hip_db *db, const igd_hip_desc *d, int realShift, const std::vector<Unit> &units, int device)
+{
+    const int64_t n = db->nRec;
+    std::vector<int32_t> st((size_t)n), en((size_t)n), ix((size_t)n), va;
+    HIPCHK(hipMemcpy(st.data(), db->d_start, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(en.data(), db->d_end, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ix.data(), db->d_idx, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (db->gType == 1) { va.resize((size_t)n); HIPCHK(hipMemcpy(va.data(), db->d_value, (size_t)n * 4, hipMemcpyDeviceToHost)); }
+    // every record ONCE: of its copies (one per tile it reaches into) the one in the tile it starts in
+    std::vector<int32_t> uc, us, ue, uv, uf;
+    uc.reserve((size_t)n); us.reserve((size_t)n); ue.reserve((size_t)n); uf.reserve((size_t)n);
+    if (db->gType == 1) uv.reserve((size_t)n);
+    const int32_t W = d->nbp;
+    int64_t t = 0, r = 0;
+    for (int32_t c = 0; c < d->nCtg; c++)
+        for (int32_t j = 0; j < d->nTile[c]; j++, t++) {
+            const int64_t T0 = (int64_t)j * W;
+            for (int32_t k = 0; k < d->nCnt[t]; k++, r++) {
+                if ((int64_t)st[(size_t)r] < T0) continue;              // begins in an earlier tile: counted there
+                if (st[(size_t)r] < 0 || st[(size_t)r] >= en[(size_t)r]) continue;   // (cannot be in a file `create` wrote)
+                uc.push_back(c); us.push_back(st[(size_t)r]); ue.push_back(en[(size_t)r]); uf.push_back(ix[(size_t)r]);
+                if (db->gType == 1) uv.push_back(va[(size_t)r]);
+            }
+        }
+    (void)units;
+    igd_hip_create_desc cd;
+    memset(&cd, 0, sizeof cd);
+    cd.nbp = 1 << 14; cd.gType = db->gType; cd.nCtg = d->nCtg; cd.n = (int64_t)us.size();
+    cd.ctg = uc.data(); cd.start = us.data(); cd.end = ue.data(); cd.value = db->gType == 1 ? uv.data() : nullptr; cd.file = uf.data();
+    cd.ctgName = nullptr; cd.out_fd = -1;
+    igd_hip_created made;
+    memset(&made, 0, sizeof made);
+    int rc = igd_hip_create(&cd, device, &made);
+    if (rc != IGD_HIP_OK) return rc;
+    igd_hip_desc vd;
+    memset(&vd, 0, sizeof vd);
+    vd.nbp = 1 << 14; vd.gType = db->gType; vd.nCtg = d->nCtg; vd.nFiles = d->nFiles;
+    // (a contig without records has no tile in what `create` returns; the loaders want one)
+    std::vector<int32_t> vnT((size_t)d->nCtg), vCnt;
+    {
+        int64_t at = 0;
+        for (int32_t c = 0; c < d->nCtg; c++) {
+            const int32_t k = made.nTile[c];
+            vnT[(size_t)c] = k > 0 ? k : 1;
+            if (k > 0) { vCnt.insert(vCnt.end(), made.nCnt + at, made.nCnt + at + k); at += k; }
+            else vCnt.push_back(0);
+        }
+    }
+    vd.nTile = vnT.data(); vd.nCnt = vCnt.data(); vd.records = made.records; vd.nRecords = made.nRecords; vd.fd = -1;
+    igd_hip_db *inner = nullptr;
+    rc = igd_hip_open(&vd, device, &inner);
+    igd_hip_created_free(&made);
+    if (rc != IGD_HIP_OK) return rc;
+    HIPCHK(hipSetDevice(db->device));
+    // the file's tiles: which of them are empty (rule NEST, :468)
+    std::vector<uint32_t> bits((size_t)((db->nT + 31) / 32) + 1, 0u);
+    for (int64_t g = 0; g < db->nT; g++) if (d->nCnt[g] == 0) bits[(size_t)(g >> 5)] |= 1u << (g & 31);
+    if ((rc = dalloc(&db->d_rEmpty, bits.size(), nullptr)) != IGD_HIP_OK) { igd_hip_close(inner); return rc; }
+    HIPCHK(hipMemcpy(db->d_rEmpty, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+    inner->v.vshift = realShift;
+    inner->v.rNTile = db->d_ctgNTile; inner->v.rBase = db->d_ctgBase; inner->v.rEmpty = db->d_rEmpty;
+    db->inner = inner;
+    return IGD_HIP_OK;
+}
 
 extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 {
@@ -3991,6 +4090,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
 #undef TRYHIP
     DbView &v = db->v;
     v.nbp = db->nbp; v.nCtg = db->nCtg; v.nT = db->nT; v.nFiles = db->nFiles;
+    v.vshift = -1; v.rNTile = nullptr; v.rBase = nullptr; v.rEmpty = nullptr;
     v.shift = -1;
     for (int b = 0; b < 31; b++)
         if (db->nbp == (1 << b)) v.shift = b;
@@ -4035,6 +4135,22 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     }
     OPEN_PHASE("compact image");
     t_arenaOwner = nullptr;
+    // A file bucketed with another tile width than the image is made for (the reference accepts -b 11..19,
+    // src/igd_create.c:454-457): tiles of 2^16 .. 2^19 bp do not fit the compact image's 16-bit offsets, tiles of 2^11 .. 2^13 bp
+    // make units of a few dozen records whose fixed cost dominates.  The counting searches of such a database run on a
+    // RE-TILED copy -- the same records bucketed again in tiles of 2^14 bp by the engine's own `create` path -- which is a
+    // database of its own (db->inner) plus what the file's tiling decides (DbView::vshift).  Enumeration, the hit map and
+    // Seqpare depend on the file's tiles and record order and stay on this image.
+    {
+        int sh = -1;
+        for (int b = 0; b < 31; b++) if (d->nbp == (1 << b)) sh = b;
+        const bool want = sh >= 0 && sh != 14 && sh != 15 && n > 0 && !getenv("IGD_HIP_NO_RETILE") && d->nFiles > 0;
+        if (want) {
+            const int rc3 = build_retiled(db, d, sh, units, device);
+            if (rc3 != IGD_HIP_OK) { igd_hip_close(db); return rc3; }
+            OPEN_PHASE("re-tiled copy (2^14 bp)");
+        }
+    }
     *out = db;
     return IGD_HIP_OK;
 }
@@ -4265,6 +4381,11 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
         return IGD_HIP_ERR_ARG;
     }
     if (db->nFiles == 0) return IGD_HIP_OK;
+    if (db->inner) {                                     // a file of another tile width: counted on the re-tiled copy (igd_hip_open)
+        db->inner->vnest = rule == IGD_HIP_RULE_NEST ? 1 : 0;
+        return search_dev_impl(db->inner, d_ichr, d_runs, d_qs, d_qe, nq, v, IGD_HIP_RULE_FLAT, flags, d_hits, d_total,
+                               stream ? stream : (void *)db->stream);
+    }
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = stream ? (hipStream_t)stream : db->stream;
     if (nq == 0 || db->nT == 0) {
@@ -4278,6 +4399,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     if (rc != IGD_HIP_OK) return rc;
     const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);   // gType 0 has no value field
     const int mode = (flags & IGD_HIP_FLAG_SORTED) ? 1 : (flags & IGD_HIP_FLAG_BUCKET) ? 2 : 0;
+    const int krule = rule | ((db->v.vshift >= 0 && db->vnest) ? 0x100 : 0);   // what the grouping kernels get: bit 8 = rule NEST on the FILE's tiles (a re-tiled copy)
     const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
     if (db->epoch >= 0x3fffffff || db->covStale) {       // the epoch stamps start over (or a batch ended before its last launch)
         HIPCHK(hipMemsetAsync(db->d_spill, 0, ((size_t)db->nT + 2) * 4, st));
@@ -4329,11 +4451,11 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
 #define QB_GRID(PER_) ((int)((nq + (PER_) - 1) / (PER_)) > fillBlocks ? (int)((nq + (PER_) - 1) / (PER_)) : fillBlocks)
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
     if (runsK && VEC_ == 4 && FAST_)                                                                                                  \
-        k_query_bounds<4, true, WGT_, true><<<QB_GRID(WGT_ * 4), WGT_, 0, st>>>(db->v, d_runs, d_qs, d_qe, (int)nq, rule,            \
+        k_query_bounds<4, true, WGT_, true><<<QB_GRID(WGT_ * 4), WGT_, 0, st>>>(db->v, d_runs, d_qs, d_qe, (int)nq, krule,            \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0);                                                                                  \
     else                                                                                                                             \
-    k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, rule,               \
+    k_query_bounds<VEC_, FAST_, WGT_><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, krule,               \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0)
 #ifndef IGD_QB_WIDE
@@ -4349,10 +4471,10 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     if (mode != 1) {
         static const bool oldBucket = getenv("IGD_HIP_ATOMIC_BUCKETS") != nullptr;   // A/B: the counting sort with global atomics
         if (db->spShift >= 0 && !oldBucket)
-            rc = launch_split(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+            rc = launch_split(db, d_ichr, d_qs, d_qe, (int)nq, krule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                               mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         else
-            rc = launch_bucket(db, d_ichr, d_qs, d_qe, (int)nq, rule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
+            rc = launch_bucket(db, d_ichr, d_qs, d_qe, (int)nq, krule, mode == 2 ? 0 : db->epoch, packed ? 1 : 0, st,
                                       mode == 2 ? zh : nullptr, mode == 2 ? zt : nullptr);
         if (rc != IGD_HIP_OK) return rc;                 // (guard: covStale)
     }
@@ -4431,6 +4553,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
 extern "C" int igd_hip_sync(igd_hip_db *db, void *stream)
 {
     if (!db) return IGD_HIP_ERR_ARG;
+    if (db->inner) return igd_hip_sync(db->inner, stream ? stream : (void *)db->stream);   // (the promise is kept track of where the batch ran)
     HIPCHK(hipSetDevice(db->device));
     HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : db->stream));
     HIPCHK(hipGetLastError());
@@ -5307,6 +5430,10 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
                                      int64_t nq, int32_t v, int rule, int flags, igd_hip_traffic *out)
 {
     if (!db || !out || nq < 0 || nq > IGD_MAX_BATCH) return IGD_HIP_ERR_ARG;
+    if (db->inner) {                                     // (the kernels of such a database run on its re-tiled copy)
+        db->inner->vnest = rule == IGD_HIP_RULE_NEST ? 1 : 0;
+        return igd_hip_batch_traffic(db->inner, d_ichr, d_qs, d_qe, nq, v, IGD_HIP_RULE_FLAT, flags, out);
+    }
     memset(out, 0, sizeof *out);
     if (nq == 0 || db->nT == 0 || db->nFiles == 0) return IGD_HIP_OK;
     HIPCHK(hipSetDevice(db->device));
@@ -5463,6 +5590,7 @@ extern "C" int igd_hip_measure_rates(int device, double rates[4])
 extern "C" int igd_hip_profile_begin(igd_hip_db *db, int max_launches)
 {
     if (!db || max_launches <= 0) return IGD_HIP_ERR_ARG;
+    if (db->inner) return igd_hip_profile_begin(db->inner, max_launches);
     HIPCHK(hipSetDevice(db->device));
     while ((int)db->ev.size() < 4 * max_launches) {
         hipEvent_t e;
@@ -5479,6 +5607,7 @@ extern "C" int igd_hip_profile_begin(igd_hip_db *db, int max_launches)
 extern "C" int igd_hip_profile_sampling(igd_hip_db *db, int every)
 {
     if (!db || every < 1) return IGD_HIP_ERR_ARG;
+    if (db->inner) return igd_hip_profile_sampling(db->inner, every);
     db->evEvery = every;
     return IGD_HIP_OK;
 }
@@ -5486,6 +5615,7 @@ extern "C" int igd_hip_profile_sampling(igd_hip_db *db, int every)
 extern "C" int igd_hip_profile_end(igd_hip_db *db, int *n_launches, double *avg_scan_ms, double *avg_pipeline_ms)
 {
     if (!db) return IGD_HIP_ERR_ARG;
+    if (db->inner) return igd_hip_profile_end(db->inner, n_launches, avg_scan_ms, avg_pipeline_ms);
     HIPCHK(hipSetDevice(db->device));
     db->evOn = false;
     int n = db->evUsed;
