@@ -38,11 +38,19 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 11 and not any("error" in e for e in x), x
+        assert len(x) == 13 and not any("error" in e for e in x), x
         assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
         assert sum(e["workload"].startswith("stress:") for e in x) == 4
         assert r["cold"]["kernel_ms"] > 0 and 0 < r["cold"]["frac"] <= 1.0
+        # what the fraction is a fraction of, and the like-for-like anchors of the weak-scaling curve
+        assert r["frac_of"] and r["step_frac"] > 0 and r["step_frac"] <= r["frac"] and "frac_pmc" in r
+        sa = j["scale_anchor"]
+        assert set(sa["step_ms"]) == {"1", "2", "4", "8"} and all(v > 0 for v in sa["step_ms"].values()) and sa["predicted_value"]["8"] > 0
+        assert "query_layout" in j["config"]
         e2e = j["cli_end_to_end"]
+        small = e2e["small_files"]
+        assert [row["queries"] for row in small] == [1000, 10000, 100000, 300000] and all(row["product_seconds"] > 0 for row in small)
+        assert all(row["stdout_identical"] for row in small if "reference_seconds" in row)
         assert e2e["q_seconds"] > 0 and e2e["q_v500_seconds"] > 0 and e2e["q_f_seconds"] > 0 and e2e["q_total_matches_gpu"] is True
         assert c["host"]["cpu_model"] and c["host"]["logical_cpus"] >= 1
         c = j["cpu_baseline"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/fuzz_engine.py [cases] [seed0] -- GPU box: the ENGINE (igd_hip_search through igd_amd.Database) against the oracle on
-random databases (tile size 2^10 .. 2^15 and one that is no power of two is left to tests/, 1 .. 300 files and 21 000 (windows of files), gType 0/1,
+random databases (tile size 2^10 .. 2^19 -- all but 2^14 / 2^15 searched over the re-tiled copy -- one that is no power of two is left to tests/, 1 .. 300 files and 21 000 (windows of files), gType 0/1,
 clustered or not) and random batches that mix what the kernels treat differently: short queries, queries of many
 tiles, inverted ones, unknown contigs, starts beyond the contig, duplicates, a hot tile with 10^3 .. 10^5 queries --
 position-sorted (order promise and device decides), unordered (device decides, bucket path), both builds of the merge
@@ -26,6 +26,9 @@ def batch(rng, n, genome_len, nbp):
     c = np.where(rng.random(n) < 0.01, -1, c)                    # unknown contig
     c = np.where(rng.random(n) < 0.005, 99, c)
     qs = np.where(rng.random(n) < 0.01, qs + 3 * genome_len, qs)  # beyond the contig
+    neg = rng.random(n) < 0.01                                    # before the contig: (-nbp, 0) is tile 0 by C division, below is nothing
+    qs = np.where(neg, -rng.integers(1, 2 * nbp, n), qs)
+    qe = np.where(neg, qs + rng.integers(1, 5 * nbp, n), qe)
     if rng.random() < 0.6:                                       # a hot tile
         m = int(rng.choice([1000, 20000, 100000])); m = min(m, n)
         t0 = int(rng.integers(0, max(1, genome_len // nbp - 2))) * nbp
@@ -45,7 +48,7 @@ def main():
         rng = np.random.default_rng(seed0 + ci)
         d = tempfile.mkdtemp(prefix="ige", dir="/tmp")
         try:
-            b = int(rng.choice([10, 11, 12, 13, 14, 15])); files = int(rng.choice([1, 7, 60, 300, 300, 21000]))
+            b = int(rng.choice([10, 11, 12, 13, 14, 15, 16, 17, 18, 19])); files = int(rng.choice([1, 7, 60, 300, 300, 21000]))
             per = int(rng.choice([200, 3000, 20000])); gtype = int(rng.choice([0, 1, 1])); cl = bool(rng.random() < 0.3)
             if files > 10000: per = int(rng.choice([15, 150]))        # (more files than LDS counters: windows of files)
             path = os.path.join(d, "f.igd")
