@@ -71,9 +71,10 @@ def parse_args(argv=None):
                     help="N=1 only: this GPU's step is slab 0 of a G-GPU config-4 job (G x --queries position-sorted queries) -- "
                          "what one of G GPUs would run, measured without the other G-1")
     ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
-    ap.add_argument("--query-layout", choices=["runs", "ichr"], default="runs",
-                    help="how a position-sorted batch under the order promise is resident: contig runs + starts + ends (8 B/query) or "
-                         "one contig number per query (12 B/query)")
+    ap.add_argument("--query-layout", choices=["runs", "ichr"], default="ichr",
+                    help="how a position-sorted batch under the order promise is resident: one contig number per query (12 B/query, the "
+                         "default) or contig runs + starts + ends (8 B/query, igd_hip_search_runs_dev: measured no faster -- the grouping "
+                         "kernel is not bound by the bytes it reads, DESIGN.md section 4)")
     ap.add_argument("--grouping", choices=["default", "auto", "sorted", "bucket"], default="default",
                     help="how the engine groups queries by tile.  auto: the device checks the query order and picks "
                          "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
@@ -404,7 +405,7 @@ def pmc_traffic(key):
 class Job:
     """One resident batch + the timed loop over it (shared by the headline run and extra_configs)."""
 
-    def __init__(self, db, dev, stream, ichr, qs, qe, v, gflags, layout="runs"):
+    def __init__(self, db, dev, stream, ichr, qs, qe, v, gflags, layout="ichr"):
         import torch
         self.db, self.dev, self.stream, self.v, self.gflags = db, dev, stream, v, gflags
         self.Q = len(qs)

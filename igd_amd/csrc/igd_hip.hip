@@ -78,10 +78,11 @@
 #define IGD_SCAN_BLOCK 256
 #define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
 #ifndef IGD_TAIL_WGS
-#define IGD_TAIL_WGS 512                     // workgroups (IGD_TAIL_WG threads) of the batch's last launch
+#define IGD_TAIL_WGS 256                     // workgroups (IGD_TAIL_WG threads) of the batch's last launch: one per CU -- with the ~100 registers of the
+                                             // long queries' four-deep walks a CU holds one anyway, and a second round of workgroups cost every batch 1 us
 #endif
 #ifndef IGD_TAIL_WG
-#define IGD_TAIL_WG 1024                     // ... 8192 waves as before, in workgroups of 16: what the long queries' work counts in a workgroup's LDS
+#define IGD_TAIL_WG 1024                     // ... in workgroups of 16 waves: what the long queries' work counts in a workgroup's LDS
                                              // leaves it as one global atomic per dataset, and 2048 workgroups of 4 waves made 3.9 x 10^6 of those
 #endif
 #ifndef IGD_REDUCE_GROUPS
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (i0 > 0 && i0 < nq) { if (!RUNS) pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
-    __shared__ int sCnt[NW], sFixCnt[NW], sFixBase;
+    __shared__ int sCnt[NW], sFixCnt[NW], sFixBase, sFixAny;
     const bool ldsTab = FAST || db.nCtg <= QB_CTG;
     const int packed = FAST ? 1 : packed_;
     // Has any wave found the batch unordered already?  ONE device-scope load per workgroup (an L1-cached one would keep
@@ -568,11 +569,10 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     int seen = 0;
     if (threadIdx.x == 0) seen = __hip_atomic_load(&ctl[CTL_UNSORTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (looked at further down)
     if (threadIdx.x < NW) { sCnt[threadIdx.x] = 0; sFixCnt[threadIdx.x] = 0; }   // (a wave that leaves early counts as one without entries)
-    if (threadIdx.x == NW) sSeen = 0;                     // (defined also when wave 0 is the one that leaves before it stores the flag)
+    if (threadIdx.x == NW) { sSeen = 0; sFixAny = 0; }                     // (defined also when wave 0 is the one that leaves before it stores the flag)
     if (ldsTab)
         for (int c = threadIdx.x; c < db.nCtg; c += WGT) { sBase[c] = db.ctgBase[c]; sNTile[c] = db.ctgNTile[c]; }
-    __shared__ int32_t sCovW[NW * QB_COVW];               // per wave: coverage differences of its long queries (see step 3)
-    for (int k = threadIdx.x; k < NW * QB_COVW; k += WGT) sCovW[k] = 0;
+    __shared__ int32_t sCovW[NW * QB_COVW];               // per wave: coverage differences of its long queries (see step 3; cleared by the wave that uses it)
     __shared__ int32_t sRun[RUNS ? 2 * QB_CTG : 1];       // runStart[0..nCtg], padded with INT_MAX to a power of two
     __shared__ int sK[2];                                 // RUNS: contig of the batch's first and last query
     int runLevels = 0;
@@ -601,7 +601,19 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         const int wv_ = (int)(threadIdx.x >> 6);
         if (wv_ == 0 && nq > 0) { const int c0_ = contig_of(0); if (threadIdx.x == 0) sK[0] = c0_; }
         if (wv_ == NW - 1 && nq > 0) { const int c1_ = contig_of(nq - 1); if ((threadIdx.x & 63) == 0) sK[1] = c1_; }
-        const int cl = i0 < nq ? contig_of(i0) : db.nCtg;                 // the thread's first query
+        // the thread's first query.  Up to 63 contigs: the wave's first query finds its run with ONE look at the table, a run
+        // start per lane and a ballot, and the lanes inside that run -- all of them unless the wave straddles a run boundary
+        // -- are done (the five dependent LDS reads of a bisection per thread made this build slower than the one that loads
+        // a contig number per query: 10.9 against 9.5 us at 10^6 queries)
+        int cl;
+        if (db.nCtg < IGD_WAVE) {
+            const int ln_ = (int)(threadIdx.x & 63);
+            const int iw = __builtin_amdgcn_readfirstlane(i0);
+            const int tv = ln_ <= db.nCtg ? sRun[ln_] : INT_MAX;
+            const int cu = __popcll(__ballot(ln_ >= 1 && tv <= iw));       // (sRun[nCtg] = nq > iw whenever iw < nq)
+            const int lo_ = __builtin_amdgcn_readlane(tv, cu < db.nCtg ? cu : db.nCtg), hi_ = __builtin_amdgcn_readlane(tv, cu < db.nCtg ? cu + 1 : db.nCtg);
+            cl = i0 >= nq ? db.nCtg : ((i0 >= lo_ && i0 < hi_) ? cu : contig_of(i0));
+        } else cl = i0 < nq ? contig_of(i0) : db.nCtg;
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             int c = cl;
@@ -783,6 +795,9 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         for (int v = 0; v < VEC; v++) any |= __ballot(covA[v] >= 0);
         if (any) {
             int32_t *win = sCovW + (threadIdx.x >> 6) * QB_COVW;
+            for (int k = lane; k < QB_COVW; k += IGD_WAVE) win[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             int first = INT_MAX;
 #pragma unroll
             for (int v = 0; v < VEC; v++) if (covA[v] >= 0 && covA[v] < first) first = covA[v];
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             __builtin_amdgcn_wave_barrier();
             for (int k = lane; k < QB_COVW; k += IGD_WAVE) {
                 const int d = win[k];
-                if (d != 0) { win[k] = 0; if (first + k <= db.nT + 1) atomicAdd(&diff[first + k], d); }
+                if (d != 0 && first + k <= db.nT + 1) atomicAdd(&diff[first + k], d);
             }
             if (lane == 0) ctl[CTL_COV + 0 * 2 + (epoch & 1)] = epoch;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -826,9 +841,11 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (lane == 63) sCnt[threadIdx.x >> 6] = inc;
     // the queries listed for the exact walk: counted per wave here, appended per WORKGROUP below
     int myFix = 0;
+    if (!quick) {                                           // (a wave on the short path lists nothing)
 #pragma unroll
-    for (int v = 0; v < VEC; v++) myFix += __popcll(__ballot(pend[v] != 0));
-    if (lane == 0 && myFix) sFixCnt[threadIdx.x >> 6] = myFix;
+        for (int v = 0; v < VEC; v++) myFix += __popcll(__ballot(pend[v] != 0));
+        if (lane == 0 && myFix) { sFixCnt[threadIdx.x >> 6] = myFix; sFixAny = 1; }
+    }
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read (the merge join is
     // off, the bucket path keeps its own lists): workgroups that see the mark stop here, before they store anything (an
     // unordered batch worked through to the end, gap filling included, took 50 instead of 5 us).
@@ -840,10 +857,11 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         // ONE returning atomic per workgroup for the list of the exact walk.  Requests for one address are served one after
         // the other by its memory channel, ~12 ns each: one per long query -- and still one per wave and pass -- made this
         // kernel take 190-250 us for 10^6 queries of which a quarter or all are long (10 us without).
+        if (sFixAny) {                                      // (the same answer in every wave of the workgroup; no: the usual batch)
         const int fm = lane < NW ? sFixCnt[lane] : 0;
         const int fr = wave_inclusive_sum(fm);
         const int ftotal = __builtin_amdgcn_readlane(fr, NW - 1);
-        if (ftotal) {                                       // (the same number in every wave of the workgroup)
+        {
             const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
             const int before = wv > 0 ? __builtin_amdgcn_readlane(fr, wv - 1) : 0;
             // (asked for by the first wave that has entries: it is certainly still here -- wave 0 may have left the kernel
@@ -857,6 +875,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                 if (pend[v] != 0) fix[at + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(i0 + v, pend[v]);
                 at += __popcll(m);
             }
+        }
         }
     }
     if (blockLive && !(IGD_EXP & 8192)) {
