@@ -287,11 +287,14 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
     else if (q.unsorted && timing_on())                                   /* one out-of-place line is enough */
         fprintf(stderr, "[igd timing] the query file is not position-sorted: the engine groups it (bucket path)\n");
     igdc_map *hm = q.n > 0 ? host_map(q.n) : NULL;
+    int onHost = 0;
     if (hm) {
-        if (igdc_search_host(g_core, hm, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total) != 0) total = 0;
+        onHost = igdc_search_host(g_core, hm, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total) == 0;   // (fails only on a read error: hits[] untouched)
         igdc_map_close(hm);
-        phase("search on the host (small file)", &t0);
-    } else if (q.n > 0) {
+        if (onHost) phase("search on the host (small file)", &t0);
+        else total = 0;
+    }
+    if (!onHost && q.n > 0) {
         igd_hip_db *dev = engine();
         t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
@@ -579,16 +582,20 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
     print_ctx P;
     P.q = q; P.names = names; P.G = G; P.flen = flen; P.maxL = maxL; P.nt = nt;
     memset(P.keep, 0, sizeof P.keep);
+    int onHost = 0;
     if (hm) {                                                    /* small file: the overlaps come from the host, the text as always */
         igd_hip_hit *hit = NULL;
         P.q0 = 0;
         if (igdc_enumerate_host(g_core, hm, q->ichr, q->qs, q->qe, q->n, qoff, &hit, &total) == 0) {
             print_chunk(&P, 0, q->n, qoff, hit);
             grand = total;
+            onHost = 1;
         }
         free(hit);
         igdc_map_close(hm);
-    } else
+        if (!onHost) dev = engine();                             /* (a read error on the host path: the engine reads the file its own way) */
+    }
+    if (!onHost && dev)
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
         P.q0 = q0;

@@ -4166,7 +4166,13 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         const bool want = sh >= 0 && sh != 14 && sh != 15 && n > 0 && !getenv("IGD_HIP_NO_RETILE") && d->nFiles > 0;
         if (want) {
             const int rc3 = build_retiled(db, d, sh, units, device);
-            if (rc3 != IGD_HIP_OK) { igd_hip_close(db); return rc3; }
+            if (rc3 != IGD_HIP_OK) {
+                // (out of memory for the second copy, say: the database still works over its own tiles, only slower)
+                const char *force = getenv("IGD_HIP_RETILE");
+                if (force && !strcmp(force, "force")) { igd_hip_close(db); return rc3; }
+                if (tim) fprintf(stderr, "[igd timing]   open: no re-tiled copy (%s): searching the file's own tiles\n", g_err);
+                if (db->inner) { igd_hip_close(db->inner); db->inner = nullptr; }
+            }
             OPEN_PHASE("re-tiled copy (2^14 bp)");
         }
     }
