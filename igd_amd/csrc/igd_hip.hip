@@ -270,6 +270,7 @@ struct igd_hip_db {
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
     SpTuple *d_spT;               // regions: the pairs of each k_split_local workgroup, grouped by coarse bucket
+    uint32_t *d_spSub;            // piled-up buckets: [nCoarse][SPF_S][2^spShift] pairs per (bucket, share, tile), then bucketBase[nCoarse], bucketLong[nCoarse]
     int spShift, spCoarse;        // coarse bucket = tile >> spShift; spShift < 0: split path not applicable
     char *arena;                  // one hipMalloc holds the whole resident image (carved by dalloc)
     size_t arenaSize, arenaUsed;
@@ -439,6 +440,7 @@ static_assert(IGD_LEAN_FIRST <= IGD_HEAVY_FIRST, "the list of heavy_sorted_body 
 #define IGD_COV_SHIFT 10          // coarse level of the difference array: sums over 1024 tiles
 #define CTL_COV 16         // + set * 2 + parity (set 0: merge join, 1: bucket path): the epoch whose long queries wrote the set
 #define IGD_COV_LEN(nT_) ((size_t)(nT_) + 2 + ((size_t)(nT_) >> IGD_COV_SHIFT) + 2)   // one set: diff[nT + 2], coarse[(nT >> IGD_COV_SHIFT) + 2]                // + (epoch & 1): epoch of the batch that put something into the parity's difference arrays
+#define CTL_PILED 20       // epoch of the last batch in which k_split_local saw a piled-up coarse bucket (k_split_fine_b has work)
 #define IGD_CTL_WORDS 32
 
 // Sorted path, step 1.  key(i) = global tile id of query i's FIRST tile, clamped into the
@@ -1026,6 +1028,7 @@ __global__ void k_count_pairs(DbView db, const int32_t *__restrict__ ichr,
 #define SPF_WG 256           // threads of k_split_fine
 #endif
 #define SP_CAP (SP_Q * IGD_SHORT_TILES)
+#define SP_LONG (SP_Q / 4)     // pairs of one k_split_local workgroup in one coarse bucket from which the bucket counts as piled up
 #define SP_MAXC 1024
 
 __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t *__restrict__ ichr,
@@ -1033,7 +1036,8 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
                                                        int nq, int rule, int packed, int shift, int nCoarse,
                                                        uint32_t *__restrict__ table, SpTuple *__restrict__ reg,
                                                        int2 *__restrict__ longList, int32_t *__restrict__ ctl, int gate,
-                                                       int epoch, u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
+                                                       int epoch, u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
+                                                       int32_t *__restrict__ bucketLong)
 {
     {
         const int gi = blockIdx.x * SP_WG + threadIdx.x;
@@ -1095,6 +1099,7 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         for (int k = 0; k < SP_MAXC / SP_WG; k++) {
             if (b0 + k < nCoarse) {
                 table[(size_t)blockIdx.x * nCoarse + b0 + k] = run | (c[k] << 16);
+                if (c[k] >= SP_LONG && bucketLong) { bucketLong[b0 + k] = epoch; ctl[CTL_PILED] = epoch; }   // a quarter of this workgroup's queries in ONE bucket: a piled-up batch
                 cur[b0 + k] = run;
             }
             run += c[k];
@@ -1114,18 +1119,17 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
 }
 
 #define SP_ROWS 4     // table rows a thread keeps in flight
-__global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
+__device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
                                                       const SpTuple *__restrict__ reg,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
                                                       int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
                                                       int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
 {
-    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
     extern __shared__ uint32_t sp_lds[];
     const int F = 1 << shift;
     uint32_t *cnt = sp_lds, *start = sp_lds + F;
     __shared__ uint32_t wsum[SPF_WG / IGD_WAVE], baseSh;
-    const int b = blockIdx.x, t0 = b << shift;
+    const int t0 = b << shift;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
     {   // first pair of this bucket = pairs of all earlier buckets = the sum over the table's rows of each row's own
@@ -1208,6 +1212,148 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
         const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
         pairs[pos] = make_int2(tu.s, tu.e);
     });
+}
+
+__global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
+                                                      const SpTuple *__restrict__ reg,
+                                                      int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
+                                                      int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
+                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+{
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    split_fine_whole((int)blockIdx.x, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy);
+}
+
+// Several workgroups per coarse bucket for the buckets of a PILED-UP batch (round 4).  One workgroup per bucket walks ALL pairs
+// of the bucket twice: an unordered batch piled up in a few tiles puts 10^6 pairs into one bucket, and that one workgroup
+// streams 12 MB of tuples at what a single CU keeps in flight -- 1.7 ms where the whole batch otherwise takes 0.13.  A bucket
+// in which k_split_local has seen a long segment (bucketLong[b] == epoch) is shared by SPF_S workgroups of SPF_W waves, each
+// wave taking every (SPF_S * SPF_W)-th segment, and the step that needs all of them -- where a tile's pairs start -- sits
+// between two kernels: _a counts (bucket, share, tile), _b adds the shares up, places its own and scatters.  Every other
+// bucket is grouped by its first workgroup in _a exactly as before (split_fine_whole) and costs the other seven one load.
+#ifndef SPF_S
+#define SPF_S 8                // workgroups per piled-up coarse bucket ...
+#endif
+#define SPF_W (SPF_WG / IGD_WAVE)   // ... of this many waves each
+template <typename FN>
+__device__ __forceinline__ void split_walk_share(int nWG, int nCoarse, int b, int part, int lane, const uint32_t *__restrict__ table,
+                                                 const SpTuple *__restrict__ reg, FN fn)
+{
+    constexpr int P = SPF_S * SPF_W;
+    for (int wb = part; wb < nWG; wb += P * IGD_WAVE) {
+        const int w = wb + lane * P;
+        const uint32_t e = w < nWG ? table[(size_t)w * nCoarse + b] : 0u;
+        const unsigned at = (unsigned)w * (unsigned)SP_CAP + (e & 0xFFFFu);
+        const int c = (int)(e >> 16);
+        const bool longSeg = c >= IGD_WAVE;
+        if (!longSeg) for (int j = 0; j < c; j++) fn(reg[(size_t)at + j]);
+        unsigned long long m = __ballot(longSeg);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned at2 = (unsigned)__builtin_amdgcn_readlane((int)at, src);
+            const int c2 = __builtin_amdgcn_readlane(c, src);
+            int j = lane;
+            for (; j + 3 * IGD_WAVE < c2; j += 4 * IGD_WAVE) {
+                const SpTuple a0 = reg[(size_t)at2 + j], a1 = reg[(size_t)at2 + j + IGD_WAVE];
+                const SpTuple a2 = reg[(size_t)at2 + j + 2 * IGD_WAVE], a3 = reg[(size_t)at2 + j + 3 * IGD_WAVE];
+                fn(a0); fn(a1); fn(a2); fn(a3);
+            }
+            for (; j < c2; j += IGD_WAVE) fn(reg[(size_t)at2 + j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(SPF_WG) void k_split_fine_a(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
+                                                        const SpTuple *__restrict__ reg, uint32_t *__restrict__ sub,
+                                                        uint32_t *__restrict__ bucketBase, const int32_t *__restrict__ bucketLong,
+                                                        int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
+                                                        int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
+                                                        int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+{
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    const int b = blockIdx.x % nCoarse, share = blockIdx.x / nCoarse;   // (workgroups go round-robin to the 8 XCDs: share = blockIdx & 7 put every first share -- all the work of an ordinary batch -- on ONE of them: 121 instead of 25 us)
+    if (__builtin_amdgcn_readfirstlane(bucketLong[b]) != epoch) {      // the usual bucket: one workgroup, one kernel
+        if (share == 0) split_fine_whole(b, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy);
+        return;
+    }
+    extern __shared__ uint32_t sp_lds[];
+    __shared__ uint32_t wsumA[SPF_W];
+    const int F = 1 << shift;
+    uint32_t *cnt = sp_lds;
+    const int t0 = b << shift, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
+    if (share == 0) {           // pairs of all earlier buckets: the sum over the table's rows of each row's own exclusive prefix at this column
+        uint32_t x = 0;
+        for (int w = threadIdx.x; w < nWG; w += SPF_WG) x += table[(size_t)w * nCoarse + b] & 0xFFFFu;
+        for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
+        if (lane == 0) wsumA[wv] = x;
+    }
+    __syncthreads();
+    if (share == 0 && threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < SPF_W; k++) t += wsumA[k]; bucketBase[b] = t; }
+    split_walk_share(nWG, nCoarse, b, share * SPF_W + wv, lane, table, reg, [&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
+    __syncthreads();
+    uint32_t *mine = sub + (((size_t)b * SPF_S + share) << shift);
+    for (int f = threadIdx.x; f < F; f += SPF_WG) mine[f] = cnt[f];
+}
+
+__global__ __launch_bounds__(SPF_WG) void k_split_fine_b(int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
+                                                        const SpTuple *__restrict__ reg, const uint32_t *__restrict__ sub,
+                                                        const uint32_t *__restrict__ bucketBase, const int32_t *__restrict__ bucketLong,
+                                                        int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
+                                                        int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
+                                                        int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+{
+    if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    if (__builtin_amdgcn_readfirstlane(ctl[CTL_PILED]) != epoch) return;  // no piled-up bucket in this batch (the usual case: an empty launch of a few hundred workgroups)
+    extern __shared__ uint32_t sp_lds[];
+    __shared__ uint32_t wsumB[SPF_W], carry;
+    const int F = 1 << shift;
+    uint32_t *start = sp_lds;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int item = blockIdx.x; item < nCoarse * SPF_S; item += gridDim.x) {
+    const int b = item % nCoarse, share = item / nCoarse;
+    if (__builtin_amdgcn_readfirstlane(bucketLong[b]) != epoch) continue;  // done by k_split_fine_a
+    const int t0 = b << shift;
+    __syncthreads();                                     // (the previous item's LDS is done with)
+    if (threadIdx.x == 0) carry = bucketBase[b];
+    __syncthreads();
+    // per tile: all shares' pairs (where the next tile starts) and those of the shares before this one (where this one's go)
+    for (int f0 = 0; f0 < F; f0 += SPF_WG) {
+        const int f = f0 + (int)threadIdx.x;
+        uint32_t all = 0, before = 0;
+        if (f < F) {
+            const uint32_t *col = sub + (((size_t)b * SPF_S) << shift) + f;
+#pragma unroll
+            for (int k = 0; k < SPF_S; k++) { const uint32_t c = col[(size_t)k << shift]; all += c; before += k < share ? c : 0u; }
+        }
+        uint32_t x = all;                                 // inclusive prefix over the round's tiles: inside the wave, then over the waves
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, o); if (lane >= o) x += y; }
+        if (lane == 63) wsumB[wv] = x;
+        __syncthreads();
+        uint32_t first = carry + x - all;
+        for (int k = 0; k < wv; k++) first += wsumB[k];
+        if (f < F) {
+            start[f] = first + before;
+            if (share == 0 && t0 + f < nT) {
+                pairPos[t0 + f] = (int32_t)(first + all);
+                int32_t pn = (int32_t)all;
+                if (heavy && all > IGD_HEAVY_PAIRS) {     // too many pairs for one wave: heavy_bucket_body shares the tile out
+                    const int at = atomicAdd(&ctlw[CTL_NHEAVY + (epoch & 1)], 1);
+                    if (at < IGD_HEAVY_MAX) { heavy[at] = t0 + f; pn = -pn; }
+                }
+                pairN[t0 + f] = pn;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t t = carry; for (int k = 0; k < SPF_W; k++) t += wsumB[k]; carry = t; }
+        __syncthreads();
+    }
+    split_walk_share(nWG, nCoarse, b, share * SPF_W + wv, lane, table, reg, [&](const SpTuple &tu) {
+        const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
+        pairs[pos] = make_int2(tu.s, tu.e);
+    });
+    }
 }
 
 // step 2: exclusive scan of pairCnt -> pairPos (two kernels, no inter-block protocol).  The
@@ -3625,7 +3771,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
-                    db->d_spTable, db->d_spT, db->d_runIchr};
+                    db->d_spTable, db->d_spT, db->d_runIchr, db->d_spSub};
     for (void *p : ptrs)
         if (p && !(db->arena && (char *)p >= db->arena && (char *)p < db->arena + db->arenaSize)) (void)hipFree(p);
     if (db->arena) (void)hipFree(db->arena);
@@ -4205,9 +4351,9 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     const int64_t cap = nq > db->wsBucket ? nq : db->wsBucket;
     const int pb = pairBytes > db->pairBytes ? pairBytes : db->pairBytes;
     {
-        void *ws[] = { db->d_pairs, db->d_long, db->d_spTable, db->d_spT };
+        void *ws[] = { db->d_pairs, db->d_long, db->d_spTable, db->d_spT, db->d_spSub };
         for (void *q : ws) if (q) (void)hipFree(q);
-        db->d_pairs = nullptr; db->d_long = nullptr; db->d_spTable = nullptr; db->d_spT = nullptr;
+        db->d_pairs = nullptr; db->d_long = nullptr; db->d_spTable = nullptr; db->d_spT = nullptr; db->d_spSub = nullptr;
     }
     db->wsBucket = 0;
     if ((rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr)) != IGD_HIP_OK) return rc;
@@ -4221,6 +4367,9 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
             const size_t nWG = (size_t)((cap + SP_Q - 1) / SP_Q);
             if ((rc = dalloc(&db->d_spTable, nWG * (size_t)db->spCoarse, nullptr)) != IGD_HIP_OK) return rc;
             if ((rc = dalloc(&db->d_spT, nWG * SP_CAP, nullptr)) != IGD_HIP_OK) return rc;
+            const size_t subN = (((size_t)db->spCoarse * SPF_S) << db->spShift) + 2 * (size_t)db->spCoarse + 16;
+            if ((rc = dalloc(&db->d_spSub, subN, nullptr)) != IGD_HIP_OK) return rc;
+            HIPCHK(hipMemset(db->d_spSub, 0, subN * 4));           // (bucketLong[] holds epoch stamps)
         }
     }
     db->wsBucket = cap;
@@ -4255,12 +4404,23 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
                         int nq, int rule, int gate, int packed, hipStream_t st, u64 *zeroHits, u64 *zeroTotal)
 {
     const int nWG = (nq + SP_Q - 1) / SP_Q;
+    static const bool oneWG = getenv("IGD_HIP_SPLIT_ONE") != nullptr;      // A/B: one workgroup per coarse bucket, whatever the batch (until round 4)
+    const bool shared = !oneWG && db->d_spSub != nullptr;
+    uint32_t *bases = shared ? db->d_spSub + (((size_t)db->spCoarse * SPF_S) << db->spShift) : nullptr;
+    int32_t *blong = shared ? (int32_t *)(bases + db->spCoarse) : nullptr;
     k_split_local<<<nWG, SP_WG, 0, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
-                                         db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal);
+                                         db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal, blong);
+    if (!shared)
     k_split_fine<<<db->spCoarse, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
                                                                           db->d_spT,
                                                                           db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs,
                                                                           db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
+    else {
+        k_split_fine_a<<<db->spCoarse * SPF_S, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable, db->d_spT,
+            db->d_spSub, bases, blong, db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs, db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
+        k_split_fine_b<<<db->spCoarse * SPF_S < 512 ? db->spCoarse * SPF_S : 512, SPF_WG, (size_t)4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable, db->d_spT,
+            db->d_spSub, bases, blong, db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs, db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
+    }
     HIPCHK(hipGetLastError());
     return IGD_HIP_OK;
 }
@@ -4430,6 +4590,8 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
         HIPCHK(hipMemsetAsync(db->d_spill, 0, ((size_t)db->nT + 2) * 4, st));
         HIPCHK(hipMemsetAsync(db->d_cov, 0, 4 * IGD_COV_LEN(db->nT) * 4, st));
         HIPCHK(hipMemsetAsync(db->d_ctl + CTL_COV, 0, 4 * 4, st));
+        if (db->d_spSub && db->spShift >= 0)                 // (the piled-up buckets' epoch stamps)
+            HIPCHK(hipMemsetAsync(db->d_spSub + (((size_t)db->spCoarse * SPF_S) << db->spShift) + db->spCoarse, 0, (size_t)db->spCoarse * 4, st));
         if (!db->covStale) db->epoch = 0;
         db->covStale = false;
     }
