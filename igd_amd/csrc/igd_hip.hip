@@ -559,6 +559,10 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     } else if (i0 < nq) { qc[0] = RUNS ? 0 : ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
     int pc = -1, ps = INT_MIN;
     if (i0 > 0 && i0 < nq) { if (!RUNS) pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
+    // the batch's first and last query (head and tail of firstQ[], at the end of the kernel): asked for HERE -- four scalar
+    // loads -- so that the kernel's last step is not two more dependent round trips in every wave
+    int edgeC0 = 0, edgeS0 = 0, edgeC1 = 0, edgeS1 = 0;
+    if (nq > 0) { if (!RUNS) { edgeC0 = ichr[0]; edgeC1 = ichr[nq - 1]; } edgeS0 = qs[0]; edgeS1 = qs[nq - 1]; }
     // the two per-contig tables every query looks up: from LDS (one latency instead of a dependent global gather)
     __shared__ int32_t sBase[QB_CTG], sNTile[QB_CTG];
     __shared__ int sCnt[NW], sFixCnt[NW], sFixBase, sFixAny;
@@ -953,7 +957,17 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // first three tiles after the last query's (all that a query can still reach) = the entries of the last block, if the
     // queries end inside it: written by that block's own workgroup.
     if (nq > 0) {
-        const int k0 = tile_key(db, RUNS ? sK[0] : ichr[0], qs[0]), kl = tile_key(db, RUNS ? sK[1] : ichr[nq - 1], qs[nq - 1]);
+        // (tile_key over the staged tables when there are any: no look-up in global memory on the way out)
+        auto edge_key = [&](int c, int q) -> int {
+            if (!ldsTab) return tile_key(db, c, q);
+            if (c < 0) return 0;
+            if (c >= db.nCtg) return db.nT - 1;
+            int n1 = tile_of(db, q);
+            const int mT = sNTile[c] - 1;
+            n1 = n1 < 0 ? 0 : (n1 > mT ? mT : n1);
+            return sBase[c] + n1;
+        };
+        const int k0 = edge_key(RUNS ? sK[0] : edgeC0, edgeS0), kl = edge_key(RUNS ? sK[1] : edgeC1, edgeS1);
         const int nth = gridDim.x * WGT;
         for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; lpos[tt] = 0; }
         for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;

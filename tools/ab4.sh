@@ -3,7 +3,7 @@
 # for the three batches that matter: headline (10^6), config 4's per-GPU share (1.25e7) and slab 0 of 8
 out=gpurun_out/$1; mkdir -p $out
 python tools/prep.py > /dev/null 2>&1
-for cfg in "headline:" "headline_ichr:--query-layout ichr" "dense:--queries 12500000" "dense_ichr:--queries 12500000 --query-layout ichr" "slab8:--slab-of 8" "slab8_ichr:--slab-of 8 --query-layout ichr"; do
+for cfg in "headline:" "dense:--queries 12500000" "slab8:--slab-of 8" "small:--queries 100000"; do
   tag=${cfg%%:*}; args=${cfg#*:}
   for d in igd_amd/lib igd_amd/libv_*; do
     [ -f $d/libigd_hip.so ] || continue
