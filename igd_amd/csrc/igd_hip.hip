@@ -3884,8 +3884,13 @@ static int build_retiled(igd_hip_db *db, const igd_hip_desc *d, int realShift, c
         for (int32_t j = 0; j < d->nTile[c]; j++, t++) {
             const int64_t T0 = (int64_t)j * W;
             for (int32_t k = 0; k < d->nCnt[t]; k++, r++) {
+                // (a file `create` did not write -- a record outside its tile, empty or starting before the contig -- keeps its own
+                // tiles: what the reference makes of such a record depends on where it was put)
+                if (!((int64_t)st[(size_t)r] < T0 + W && (int64_t)en[(size_t)r] > T0) || st[(size_t)r] < 0 || st[(size_t)r] >= en[(size_t)r]) {
+                    snprintf(g_err, sizeof g_err, "a record that `igd create` would not have written (contig %d, tile %d)", c, j);
+                    return IGD_HIP_ERR_ARG;
+                }
                 if ((int64_t)st[(size_t)r] < T0) continue;              // begins in an earlier tile: counted there
-                if (st[(size_t)r] < 0 || st[(size_t)r] >= en[(size_t)r]) continue;   // (cannot be in a file `create` wrote)
                 uc.push_back(c); us.push_back(st[(size_t)r]); ue.push_back(en[(size_t)r]); uf.push_back(ix[(size_t)r]);
                 if (db->gType == 1) uv.push_back(va[(size_t)r]);
             }
