@@ -24,7 +24,7 @@ all: $(LIB)/libigd_hip.so $(LIB)/libigd.so $(LIB)/libigd_py.so $(LIB)/libigdr.so
 $(LIB) bin:
 	mkdir -p $@
 
-$(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip $(SRC)/igd_create.hip $(SRC)/igd_sortscan.hpp include/igd_hip.h | $(LIB)
+$(LIB)/libigd_hip.so: $(SRC)/igd_hip.hip $(wildcard $(SRC)/engine/*.hpp) $(SRC)/igd_create.hip $(SRC)/igd_sortscan.hpp include/igd_hip.h | $(LIB)
 	$(HIPCC) $(HIPFLAGS) $(INC) -shared -o $@ $(SRC)/igd_hip.hip $(SRC)/igd_create.hip -lpthread -Wl,-Bsymbolic-functions
 
 CORE_SRC := $(SRC)/igd_core.c $(SRC)/igd_hostpath.c $(SRC)/igd_create.c

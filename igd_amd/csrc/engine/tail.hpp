@@ -1,0 +1,439 @@
+// engine/tail.hpp -- part of igd_hip.hip (included there once; not a stand-alone header).
+// exact walks, coverage, k_reduce_slabs (last launch of a batch), k_sum_hits
+// ------------------------------------------------------------------------------------------
+// exact_walk_body: what the scan kernel leaves out (the exact-walk list of the batch's path): a wave walks a listed
+// query's tiles (WALK_*: which of them) on the EXACT arrays, 5 slots at a time, and adds into the workgroup's LDS
+// counters of the batch's last launch -- the caller's global hits[] where the files do not fit -- and the batch total.
+// Rare for the benchmark's queries; a batch of long ones lists every query (its last tile).
+template <bool USE_V>
+__device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
+                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv, u64 *hist)
+{
+    // ctlv: the batch's control words, word i in lane i (ONE load by the caller: the walk and the two skew valves
+    // would otherwise each wait for their own, one after the other, to find out that there is nothing to do)
+    const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch;
+    if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
+    const bool sortedPath = a.mode == 1 || (a.mode == 0 && !uns);
+    const int2 *list = sortedPath ? fixList : longList;
+    const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (a.epoch & 1));
+    const int lane = threadIdx.x & 63;
+    u64 found = 0;
+    // a wave takes `per` entries of the list at a time (one each while the list is shorter than the launch has waves): every
+    // lane reads one entry's query and contig first, so that the chain of dependent loads is paid once per group, not per query
+    int per = (nList + nwaves - 1) / nwaves;
+    per = per > IGD_WAVE ? IGD_WAVE : per;
+    for (int l0 = gwave * per; l0 < nList; l0 += nwaves * per) {
+        const int cnt = nList - l0 < per ? nList - l0 : per;
+        int vq = 0, vkind = -1, vqs = 0, vqe = 0, vn1 = 0, vj1 = -1, vbase = 0, vcnt = 0, voffLo = 0, voffHi = 0, vlob = 0;
+        int vu0 = 0, vnu = 0, vqe2 = 0;                  // WALK_LAST over the compact image: the last tile's units, the query's qe'
+        UnitRegs vur;
+        vur.offLo = vur.offHi = vur.tile = vur.n = vur.jf = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) vur.w[r] = 0;
+        const bool cimg = USE_V ? a.packedWalk == 2 : a.packedWalk != 0;
+        if (lane < cnt) {
+            const int2 ent = list[l0 + lane];
+            vq = ent.x; vkind = ent.y & 15;
+            vqs = a.q_qs[vq]; vqe = a.q_qe[vq];
+            const int cc = sortedPath ? ent.y >> 4 : a.q_ichr[vq];     // (k_query_bounds' entries carry the contig: a batch given as runs has no ichr[])
+            vn1 = tile_of(db, (db.vshift >= 0 && vqs < 0) ? 0 : vqs);     // (re-tiled copy: see query_span)
+            int n2 = tile_of(db, (int)((unsigned)vqe - 1u));
+            const int mT = db.ctgNTile[cc] - 1;
+            if (n2 > mT) n2 = mT;
+            vbase = db.ctgBase[cc];
+            vj1 = n2 > vn1 ? n2 : vn1;
+            if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[vbase + vn1] == 0) vj1 = -1;   // :468 -- nothing to walk
+            if (vj1 >= 0) {                              // ... and the first tile of the walk (the only one of WALK_LAST and WALK_FIRST)
+                const int jf = vkind == WALK_LAST ? vj1 : vn1;
+                if (jf <= vj1 && cimg && vkind == WALK_LAST) {
+                    vu0 = db.tileUnit0[vbase + jf]; vnu = db.tileUnit0[vbase + jf + 1] - vu0;
+                    vcnt = vnu;                          // (0: an empty tile)
+                    if (vnu > 0) vur = load_unit_regs(db.units + vu0);     // the tile's first unit (mostly its only one)
+                    const int T0 = (int)((unsigned)jf * (unsigned)db.nbp);
+                    vqe2 = vqe - T0;
+                    vqe2 = (vqe2 < db.nbp ? vqe2 : db.nbp) + 1;
+                } else
+                if (jf <= vj1) {
+                    vcnt = db.tileCnt[vbase + jf];
+                    const int64_t o = db.tileOff[vbase + jf];
+                    voffLo = (int)o; voffHi = (int)(o >> 32);
+                    vlob = db.tileBd[vbase + jf];
+                }
+            }
+        }
+        if (cimg) {
+            // The LAST tile of the group's long queries over the COMPACT image.  Such a query covers the tile from its start up
+            // to qe, so a record counts iff it starts in the tile (s' >= 1: the copy that counts, :510-511) before qe (s' < qe');
+            // its end is beyond the query's start by construction.  Records are ordered by start and every 64-record slot's
+            // smallest s' is in the unit's descriptor -- fetched one per lane with the group's other look-ups -- so the slots at or
+            // beyond qe' are never loaded (on average half the tile) and a record is 6 bytes (12 in the exact arrays).  What
+            // bounds a walk is the round trip for its records: TWO walks are in flight per wave.
+            struct Walk { uint32_t pa[IGD_SLOTS], px[IGD_SLOTS]; int qe2, live; };
+            auto issue = [&](int e, Walk &w) {
+                w.qe2 = __builtin_amdgcn_readlane(vqe2, e);
+                const int n = __builtin_amdgcn_readlane(vur.n, e);
+                const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(vur.offHi, e) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane(vur.offLo, e));
+                w.live = 0;
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int i = r * IGD_WAVE + lane;
+                    const bool on = r * IGD_WAVE < n && (int)(65535u - ((unsigned)__builtin_amdgcn_readlane(vur.w[r], e) & 0xFFFFu)) < w.qe2;   // wave-uniform
+                    w.pa[r] = 0xFFFFu; w.px[r] = 0u;     // (s' = 0: counts nothing)
+                    if (on) {
+                        w.live |= 1 << r;
+                        if (i < n) { w.pa[r] = db.pse[off + i]; w.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                    }
+                }
+            };
+            auto count = [&](const Walk &w) {
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    if (!(w.live & (1 << r))) continue;
+                    const int s2 = (int)(65535u - (w.pa[r] & 0xFFFFu));
+                    bool hit = s2 >= 1 && s2 < w.qe2;
+                    if (USE_V) hit = hit && ((int)w.px[r] >> 16) >= a.v;
+                    const int ix = (int)(w.px[r] & 0xFFFFu);
+                    found += __popcll(__ballot(hit));
+                    if (hit) { if (hist) atomicAdd(&hist[ix], 1ull); else atomicAdd(&a.out[ix], 1ull); }
+                }
+            };
+            unsigned long long m = __ballot(lane < cnt && vkind == WALK_LAST && vj1 >= 0 && vnu > 0);
+            // the further chunks of a tile of more than 320 records (rare): one after the other
+            auto more = [&](int e) {
+                for (int u = __builtin_amdgcn_readlane(vu0, e) + 1, ue = __builtin_amdgcn_readlane(vu0, e) + __builtin_amdgcn_readlane(vnu, e); u < ue; u++) {
+                    const UnitRegs ur = load_unit_regs(db.units + u);          // the same unit in every lane
+                    const int qe2 = __builtin_amdgcn_readlane(vqe2, e);
+                    if ((int)(65535u - ((unsigned)__builtin_amdgcn_readfirstlane(ur.w[0]) & 0xFFFFu)) >= qe2) break;   // sorted: nothing here or behind
+                    const int n = __builtin_amdgcn_readfirstlane(ur.n);
+                    const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(ur.offHi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane(ur.offLo));
+                    Walk C;
+                    C.qe2 = qe2; C.live = 0;
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int i = r * IGD_WAVE + lane;
+                        C.pa[r] = 0xFFFFu; C.px[r] = 0u;
+                        if (r * IGD_WAVE < n) {
+                            C.live |= 1 << r;
+                            if (i < n) { C.pa[r] = db.pse[off + i]; C.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                        }
+                    }
+                    count(C);
+                }
+            };
+            // FOUR walks in flight per wave (the tail's long-query work runs on a quarter of the launch's workgroups, see batch_tail)
+            Walk W0, W1, W2, W3;
+            int e0 = -1, e1 = -1, e2 = -1, e3 = -1;
+#define IGD_WALK_NEXT(E, W) do { E = -1; if (m) { E = __builtin_ctzll(m); m &= m - 1; issue(E, W); } } while (0)
+            IGD_WALK_NEXT(e0, W0); IGD_WALK_NEXT(e1, W1); IGD_WALK_NEXT(e2, W2); IGD_WALK_NEXT(e3, W3);
+            while (e0 >= 0) {
+                count(W0); more(e0); IGD_WALK_NEXT(e0, W0);
+                if (e1 >= 0) { count(W1); more(e1); IGD_WALK_NEXT(e1, W1); }
+                if (e2 >= 0) { count(W2); more(e2); IGD_WALK_NEXT(e2, W2); }
+                if (e3 >= 0) { count(W3); more(e3); IGD_WALK_NEXT(e3, W3); }
+                if (e0 < 0) {                              // slot 0 ran dry first: the others hold what is left
+                    if (e1 >= 0) { count(W1); more(e1); e1 = -1; }
+                    if (e2 >= 0) { count(W2); more(e2); e2 = -1; }
+                    if (e3 >= 0) { count(W3); more(e3); e3 = -1; }
+                }
+            }
+#undef IGD_WALK_NEXT
+        }
+        for (int e = 0; e < cnt; e++) {
+            const int kind = __builtin_amdgcn_readlane(vkind, e), qs = __builtin_amdgcn_readlane(vqs, e), qe = __builtin_amdgcn_readlane(vqe, e);
+            const int n1 = __builtin_amdgcn_readlane(vn1, e), base = __builtin_amdgcn_readlane(vbase, e);
+            int j1 = __builtin_amdgcn_readlane(vj1, e);
+            if (j1 < 0) continue;
+            if (kind == WALK_LAST && cimg) continue;       // (done above, over the compact image)
+            int j0 = n1;
+            if (kind == WALK_LAST) j0 = j1;              // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
+            if (kind == WALK_FIRST) j1 = n1;
+            for (int j = j0; j <= j1; j = (kind == WALK_ALL && j < j1) ? j1 : j + 1) {   // (WALK_ALL: first and last tile, coverage_body has the rest)
+                const int t = base + j;
+                const int tcnt = j == j0 ? __builtin_amdgcn_readlane(vcnt, e) : db.tileCnt[t];
+                if (tcnt == 0) continue;
+                const int lob = (j == n1) ? INT_MIN : j == j0 ? __builtin_amdgcn_readlane(vlob, e) : db.tileBd[t];
+                const int64_t toff = j == j0 ? (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(voffHi, e) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane(voffLo, e))
+                                             : db.tileOff[t];
+                for (int rec0 = 0; rec0 < tcnt; rec0 += IGD_CHUNK) {
+                    int st[IGD_SLOTS], en[IGD_SLOTS], ix[IGD_SLOTS], va[IGD_SLOTS];
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        const int i = rec0 + r * IGD_WAVE + lane;
+                        const bool ok = i < tcnt;
+                        st[r] = ok ? db.start[toff + i] : INT_MAX;
+                        en[r] = ok ? db.end[toff + i] : INT_MIN;
+                        ix[r] = ok ? db.idx[toff + i] : 0;
+                        if (USE_V) va[r] = ok ? db.value[toff + i] : INT_MIN;
+                    }
+                    if (__builtin_amdgcn_readfirstlane(st[0]) >= qe) break;    // sorted: nothing further
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
+                        if (USE_V) hit = hit & (va[r] >= a.v);
+                        found += __popcll(__ballot(hit));
+                        if (hit) { if (hist) atomicAdd(&hist[ix[r]], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
+                    }
+                }
+            }
+        }
+    }
+    if (a.total && lane == 0 && found) atomicAdd(a.total, found);
+}
+
+// coverage_body: the tiles that long queries of a merge-join batch cover from end to end (IGD_COV_*).  Every wave takes
+// a contiguous run of units, finds how many long queries cover its first tile (coarse sums + the fine differences of
+// the tile's block) and keeps that count running from tile to tile; a unit of a covered tile adds count x 1 to hits[]
+// for each of its records that starts in the tile (and passes the value filter).  The same launch zeroes the
+// difference arrays the batch BEFORE this one used (its own last launch is done with them).
+// (the reset is its own step: a batch that breaks its promise of order still has to clean up after the one before it)
+__device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int gwave, int nwaves, int ctlv)
+{
+    const int other = (epoch & 1) ^ 1;
+    const size_t covLen = IGD_COV_LEN(db.nT);
+    for (int set = 0; set < 2; set++) {
+        if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + other) != epoch - 1) continue;
+        int32_t *old = db.cov + (size_t)(set * 2 + other) * covLen;
+        for (size_t k = (size_t)gwave * IGD_WAVE + (threadIdx.x & 63); k < covLen; k += (size_t)nwaves * IGD_WAVE) old[k] = 0;
+    }
+}
+
+#define IGD_COV_CHUNK 16      // units a wave takes at a time (32 left a quarter of the last launch's 8192 waves without a chunk of the benchmark's 190 000 units) (strided over the launch's waves: long queries may all lie in one region)
+template <bool USE_V>
+__device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
+                                              u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
+{
+    const int lane = threadIdx.x & 63;
+    const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch;
+    if (a.mode == 1 && uns) return;                      // broken promise: the batch adds nothing
+    const int set = (a.mode == 1 || (a.mode == 0 && !uns)) ? 0 : 1, par = a.epoch & 1;   // merge join / bucket path
+    if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + par) != a.epoch) return;     // no long query in this batch
+    const int32_t *diff = db.cov + (size_t)(set * 2 + par) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
+    u64 found = 0;
+    for (int u0 = gwave * IGD_COV_CHUNK; u0 < db.nUnits; u0 += nwaves * IGD_COV_CHUNK) {
+        const int cnt = db.nUnits - u0 < IGD_COV_CHUNK ? db.nUnits - u0 : IGD_COV_CHUNK;
+        // one unit per lane: its tile, and the number of long queries that cover that tile from end to end = (coarse +
+        // fine prefix at the chunk's first tile) + the differences of the tiles since -- no chain of loads from unit to unit
+        UnitRegs ur = load_unit_regs(db.units + u0 + (lane < cnt ? lane : 0));
+        const int tile = ur.tile, tile0 = __builtin_amdgcn_readfirstlane(tile);
+        const int bd = db.tileBd[tile];                  // (a covered tile is never the first of its contig)
+        int p0;
+        {
+            const int blk = tile0 >> IGD_COV_SHIFT;
+            int sum = 0;
+            for (int c = lane; c < blk; c += IGD_WAVE) sum += coarse[c];
+            for (int t = (blk << IGD_COV_SHIFT) + lane; t <= tile0; t += IGD_WAVE) sum += diff[t];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            p0 = sum;
+        }
+        const int before = __shfl_up(tile, 1);
+        const int gap = (lane == 0 || lane >= cnt) ? 0 : tile - before;   // tiles since the unit before (0: same tile; > 1: empty tiles between)
+        int d = 0;
+        if (gap <= 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) d += k < gap ? diff[tile - k] : 0;
+        }
+        for (unsigned long long m = __ballot(gap > 4); m; m &= m - 1) {   // a run of empty tiles (a centromere): summed by the whole wave
+            const int src = __builtin_ctzll(m);
+            const int hi = __builtin_amdgcn_readlane(tile, src), g = __builtin_amdgcn_readlane(gap, src);
+            int sum = 0;
+            for (int t = hi - g + 1 + lane; t <= hi; t += IGD_WAVE) sum += diff[t];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (lane == src) d = sum;
+        }
+        const int since = wave_inclusive_sum(d);          // (every lane takes part)
+        const int cv = lane < cnt ? p0 + since : 0;
+        unsigned long long m = __ballot(cv > 0);
+        if (m == 0) continue;                            // nothing of this chunk is covered
+        // What bounds a covered unit is the round trip for its records: TWO units are in flight per wave (the loads of the
+        // next covered unit are issued before the current one is counted).
+        struct Cov { int st[IGD_SLOTS], ix[IGD_SLOTS], va[USE_V ? IGD_SLOTS : 1]; int c, lob; };
+        // (compact image: the records that start in the tile are the unit's records from number `pre` on -- Unit::pre -- so
+        // only their dataset numbers are read: 2 bytes a record, 4 with the value, where the exact arrays cost 8 and 12)
+        const bool cimg = USE_V ? a.packedWalk == 2 : a.packedWalk != 0;
+        auto issue = [&](int e, Cov &w) {
+            w.c = __builtin_amdgcn_readlane(cv, e);
+            w.lob = __builtin_amdgcn_readlane(bd, e);
+            const int n = __builtin_amdgcn_readlane(ur.n, e);
+            const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ur.offHi, e) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane(ur.offLo, e));
+            if (cimg) {
+                const int pre = __builtin_amdgcn_readlane(ur.pre, e);
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    const int i = r * IGD_WAVE + lane;
+                    const bool in = i >= pre && i < n;
+                    w.st[r] = in ? INT_MAX : INT_MIN;            // (>= lob / < lob)
+                    w.ix[r] = 0;
+                    if (USE_V) w.va[r] = INT_MIN;
+                    if (in && (r + 1) * IGD_WAVE > pre && r * IGD_WAVE < n) {
+                        if (USE_V) { const uint32_t x = db.pxv[off + i]; w.ix[r] = (int)(x & 0xFFFFu); w.va[r] = (int)x >> 16; }
+                        else w.ix[r] = (int)db.px[off + i];
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                const int i = r * IGD_WAVE + lane;
+                w.st[r] = i < n ? db.start[off + i] : INT_MIN;
+                w.ix[r] = i < n ? db.idx[off + i] : 0;
+                if (USE_V) w.va[r] = i < n ? db.value[off + i] : INT_MIN;
+            }
+        };
+        auto count = [&](const Cov &w) {
+#pragma unroll
+            for (int r = 0; r < IGD_SLOTS; r++) {
+                bool in = w.st[r] >= w.lob;              // the copy of the record that counts (:510-511)
+                if (USE_V) in = in && w.va[r] >= a.v;
+                found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)w.c;
+                if (in) { if (hist) atomicAdd(&hist[w.ix[r]], (u64)(unsigned)w.c); else atomicAdd(&d_hits[w.ix[r]], (u64)(unsigned)w.c); }
+            }
+        };
+        Cov C0, C1, C2, C3;                              // FOUR covered units in flight per wave
+        int e0 = -1, e1 = -1, e2 = -1, e3 = -1;
+#define IGD_COV_NEXT(E, C) do { E = -1; if (m) { E = __builtin_ctzll(m); m &= m - 1; issue(E, C); } } while (0)
+        IGD_COV_NEXT(e0, C0); IGD_COV_NEXT(e1, C1); IGD_COV_NEXT(e2, C2); IGD_COV_NEXT(e3, C3);
+        while (e0 >= 0) {
+            count(C0); IGD_COV_NEXT(e0, C0);
+            if (e1 >= 0) { count(C1); IGD_COV_NEXT(e1, C1); }
+            if (e2 >= 0) { count(C2); IGD_COV_NEXT(e2, C2); }
+            if (e3 >= 0) { count(C3); IGD_COV_NEXT(e3, C3); }
+            if (e0 < 0) {
+                if (e1 >= 0) { count(C1); e1 = -1; }
+                if (e2 >= 0) { count(C2); e2 = -1; }
+                if (e3 >= 0) { count(C3); e3 = -1; }
+            }
+        }
+#undef IGD_COV_NEXT
+    }
+    if (d_total && lane == 0 && found) atomicAdd(d_total, found);
+}
+
+// The batch's last launch.  Besides its own job it hosts the exact walks and the two skew valves (`valves` bit 0:
+// bucket path, bit 1: merge join; bit 2: BIG image), all of which normally find nothing to do.  SortK comes first:
+// the merge join's code reads its rarer arguments from the kernel-argument segment (KARG).
+template <bool USE_V>
+__device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, const int2 *__restrict__ fixList,
+                                           const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves,
+                                           u64 *__restrict__ d_hits, u64 *__restrict__ d_total, unsigned char *smem, int gwave, int nwaves,
+                                           int ctlv /* the batch's control words, word i in lane i */)
+{
+    const int lane = threadIdx.x & 63;
+    // what the exact walks and the coverage find is counted in the workgroup's LDS first (when the files fit): a batch of
+    // long queries makes one addition per (query, record) pair here
+    u64 *hist = nullptr;
+    if (K.a.tailHistOff >= 0) {
+        const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == wa.epoch;
+        const bool sortedPath = wa.mode == 1 || (wa.mode == 0 && !uns);
+        const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (wa.epoch & 1));
+        const bool cov = __builtin_amdgcn_readlane(ctlv, CTL_COV + (sortedPath ? 0 : 2) + (wa.epoch & 1)) == wa.epoch;
+        if (!(wa.mode == 1 && uns) && (nList > 0 || cov)) {          // (the same answer in every wave of the launch)
+            hist = (u64 *)(smem + K.a.tailHistOff);
+            for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) hist[f] = 0;
+            __syncthreads();
+        }
+    }
+    // (Tried: the long queries' work on a quarter of the launch's workgroups, to quarter the 3.9 x 10^6 atomics with which 2048
+    // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
+    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
+    coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    if (hist) {
+        __syncthreads();
+        for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
+            const u64 c = hist[f];
+            if (c) atomicAdd(&d_hits[f], c);
+        }
+    }
+    if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane, ctlv);
+    if (valves & 2) {
+        unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
+        if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+        else {
+            if (!(IGD_EXP & 0x10000)) heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
+            if (!(IGD_EXP & 0x20000)) far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);   // (the lean build does not exist for BIG images)
+        }
+    }
+}
+
+template <bool USE_V>
+__global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const int2 *__restrict__ fixList,
+                                                    const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? a.ctl[threadIdx.x & 63] : 0;
+    coverage_reset(K.db, a.epoch, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
+    batch_tail<USE_V>(K, a, fixList, longList, heavyB, valves, a.out, nullptr, smem, gwave, gridDim.x * (blockDim.x >> 6), ctlv);
+}
+
+// slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/IGD_TAIL_WG), IGD_REDUCE_GROUPS)
+template <bool USE_V>
+__global__ __launch_bounds__(IGD_TAIL_WG) void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
+                                                      u64 *__restrict__ hits, u64 *__restrict__ total,
+                                                      const int32_t *__restrict__ ctl, int brokenIf,
+                                                      ScanArgs wa, const int2 *__restrict__ fixList,
+                                                      const int2 *__restrict__ longList, const int32_t *__restrict__ heavyB, int valves,
+                                                      int rows32 /* != 0: igd_scan_sorted of epoch `rows32` wrote 32-bit rows (unless the batch went to the bucket path) */)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u64 red[IGD_TAIL_WG / IGD_WAVE];
+    constexpr int WPB = IGD_TAIL_WG / IGD_WAVE;           // waves per workgroup
+    // the batch's control words, word i in lane i: one load, in flight together with the slab rows
+    const int ctlv = (threadIdx.x & 63) < IGD_CTL_WORDS ? ctl[threadIdx.x & 63] : 0;
+    int f = blockIdx.x * IGD_TAIL_WG + threadIdx.x;
+    u64 s = 0;
+    if (f < nFiles && blockIdx.y < IGD_REDUCE_GROUPS) {  // (the workgroups beyond are there for the batch's tail only, see the launch)
+        // (both kinds of rows are read before the control words say which kind this batch left: the loads are in flight
+        // together, and a row of either kind lies inside the slab)
+        u64 s64 = 0;
+        unsigned long long s32 = 0;
+        if (rows32) {
+            const unsigned int *slab32 = (const unsigned int *)slab;
+            for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s32 += slab32[(size_t)g * nFiles + f];
+            if (__builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == rows32)   // the bucket path's batch: 64-bit rows
+                for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s64 += slab[(size_t)g * nFiles + f];
+            s = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == rows32 ? s64 : s32;
+        } else
+            for (int g = blockIdx.y; g < rows; g += IGD_REDUCE_GROUPS) s += slab[(size_t)g * nFiles + f];
+    }
+    // brokenIf != 0: the batch ran under IGD_HIP_FLAG_SORTED; if the device found it unsorted the
+    // scan kernel wrote no slab, so nothing may be added
+    if (valves >= 0) coverage_reset(K.db, wa.epoch, (blockIdx.y * gridDim.x + blockIdx.x) * WPB + (int)(threadIdx.x >> 6), gridDim.x * gridDim.y * WPB, ctlv);
+    if (brokenIf != 0 && __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == brokenIf) return;
+    if (s) atomicAdd(&hits[f], s);
+    if (total) {
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 t = 0;
+            for (int k = 0; k < WPB; k++) t += red[k];
+            if (t) atomicAdd(total, t);
+        }
+    }
+    if (valves < 0) return;                              // an earlier pass of a windowed batch: the tail rides in the last pass's launch
+    // ... and the batch's exact-walk list and skew valves (normally empty) ride in the same launch
+    const int nb = gridDim.x * gridDim.y;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int gwave = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    batch_tail<USE_V>(K, wa, fixList, longList, heavyB, valves, wa.out, total, smem, gwave, nb * WPB, ctlv);   // (wa.out: the caller's hits[]; `hits` is a window of it in a windowed batch)
+}
+
+// without LDS counters the batch total is the growth of sum(hits): measured around the launch
+__global__ __launch_bounds__(256) void k_sum_hits(const u64 *__restrict__ hits, int nFiles,
+                                                  u64 *__restrict__ total, int sign)
+{
+    __shared__ u64 red[4];
+    u64 s = 0;
+    for (int f = threadIdx.x; f < nFiles; f += 256) s += hits[f];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = red[0] + red[1] + red[2] + red[3];
+        if (sign > 0) atomicAdd(total, t);
+        else atomicAdd(total, (u64)(-(int64_t)t));
+    }
+}

@@ -1,5 +1,5 @@
 """GPU: the seams between device batches.  The host-buffer entry points cut a query set into engine calls of at most
-igd_hip_max_batch() queries (2^24): the loop of igd_hip_search_ex (igd_hip.hip), the `-f` loop over
+igd_hip_max_batch() queries (2^24): the loop of igd_hip_search_ex (engine/host_search.hpp), the `-f` loop over
 igd_hip_enumerate_stream and the `-s` loop over igd_hip_seqpare_add (igd_cli_abi.c).  No fixture has 1.7e7 queries, so
 
   - the TEST-ONLY variable IGD_HIP_MAX_BATCH lowers the limit and the golden command lines (the real reference's stdout:
