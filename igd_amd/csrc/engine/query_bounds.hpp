@@ -562,7 +562,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // the batch is declared unsorted -- which it then certainly is -- once the budget is spent.
     // A wave that finds the batch already marked fills nothing: firstQ[] is not going to be used.  (One that saw
     // disorder itself has left above.)
-    if (!marked) {
+    if (!marked && !(IGD_EXP & 0x40000)) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
             const int i = i0 + v, l1 = lo[v], h1 = key[v], p1 = pos[v];
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // left to the first / last query's own wave they took longer than everything else in this kernel.  lpos[] of the
     // first three tiles after the last query's (all that a query can still reach) = the entries of the last block, if the
     // queries end inside it: written by that block's own workgroup.
-    if (nq > 0) {
+    if (nq > 0 && !(IGD_EXP & 0x80000)) {
         // (tile_key over the staged tables when there are any: no look-up in global memory on the way out)
         auto edge_key = [&](int c, int q) -> int {
             if (!ldsTab) return tile_key(db, c, q);
