@@ -165,9 +165,11 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
 // The queries of one batch of <= 64 candidates (word `P0` per lane, IGD_NEVER where there is none) against the
 // unit: per slot, the summary word picks the queries that can hit it at all (one compare for all 64), and only
 // those are broadcast and compared.  cnt[r] += hit; no exec masking, no LDS.
+template <bool ASM>
 __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS], const uint32_t (&W)[IGD_SLOTS], int P0)
 {
 #if IGD_ASM_MATCH && !(IGD_EXP & 2)
+    if (ASM) {
     // The loop over the picked queries, written out: the compiler keeps the mask in VCC but clears its bit with a shift and
     // an and-not and tests it with a compare -- 5 scalar + 4 vector instructions per (slot, query); here s_bitset0 and the
     // branch on VCC itself: 3 + 4.  Wait states (gfx950): a packed op's result read by the next VALU 1, an SGPR written by
@@ -196,7 +198,9 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
                      : [W] "s"(W[r]), [P0] "v"(P0), [rec] "v"(R.a[r])
                      : "vcc");
     }
-#else
+    return;
+    }
+#endif
     igd_u16x2 qv;
     __builtin_memcpy(&qv, &P0, 4);
 #pragma unroll
@@ -224,7 +228,6 @@ __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS]
             cnt[r] += mxw == R.a[r] ? 1 : 0;             // both halves already >= the query's
         }
     }
-#endif
 }
 
 // later-tile word (k_query_bounds: later[]) -> compare word for this tile (IGD_NEVER when the query does not reach it)
@@ -381,7 +384,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         for (int p = 0; p < nE; p += IGD_WAVE) {
             // the next 64 words are on their way while these are compared (a dense tile is a chain of such batches)
             const int wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
-            match_words(R, cnt, W, w);
+            match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, w);
             w = wn;
         }
         if (far)
@@ -389,7 +392,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 bool covers;
                 const int lw = later_word(db.nbp, e, g2, deadk, true, covers);
                 nLater += __popcll(__ballot(covers));
-                match_words(R, cnt, W, lw);
+                match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, lw);
             });
         // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
         // query, none of which may count them (the reference's tS skip, :510-511)
