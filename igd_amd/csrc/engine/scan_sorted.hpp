@@ -169,36 +169,10 @@ template <bool ASM>
 __device__ __forceinline__ void match_words(const Raw2 &R, int (&cnt)[IGD_SLOTS], const uint32_t (&W)[IGD_SLOTS], int P0)
 {
 #if IGD_ASM_MATCH && !(IGD_EXP & 2)
-    if (ASM) {
-    // The loop over the picked queries, written out: the compiler keeps the mask in VCC but clears its bit with a shift and
-    // an and-not and tests it with a compare -- 5 scalar + 4 vector instructions per (slot, query); here s_bitset0 and the
-    // branch on VCC itself: 3 + 4.  Wait states (gfx950): a packed op's result read by the next VALU 1, an SGPR written by
-    // a VALU (v_readlane, v_cmp) read by a VALU 2.
+    if (ASM) {                                           // (match_slot_asm, scan_tiles.hpp: the loop written out)
 #pragma unroll
-    for (int r = 0; r < IGD_SLOTS; r++) {
-        int t, q, x;
-        unsigned long long c;
-        asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
-                     "s_nop 0\n\t"
-                     "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
-                     "s_cbranch_vccz 2f\n"
-                     "1:\n\t"
-                     "s_ff1_i32_b64 %[t], vcc\n\t"
-                     "v_readlane_b32 %[q], %[P0], %[t]\n\t"
-                     "s_bitset0_b64 vcc, %[t]\n\t"
-                     "s_nop 0\n\t"
-                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
-                     "s_nop 0\n\t"
-                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
-                     "s_nop 1\n\t"
-                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
-                     "s_cbranch_vccnz 1b\n"
-                     "2:"
-                     : [cnt] "+v"(cnt[r]), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
-                     : [W] "s"(W[r]), [P0] "v"(P0), [rec] "v"(R.a[r])
-                     : "vcc");
-    }
-    return;
+        for (int r = 0; r < IGD_SLOTS; r++) match_slot_asm<false>(cnt[r], W[r], P0, R.a[r], 0ull);
+        return;
     }
 #endif
     igd_u16x2 qv;

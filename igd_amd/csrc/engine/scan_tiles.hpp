@@ -168,6 +168,60 @@ __device__ __forceinline__ void match_raw(const Raw &R, int (&cnt)[IGD_SLOTS], i
     }
 }
 
+// One slot of a unit against the queries of a batch of <= 64 (word P0 per lane) that pass against the slot's summary word
+// W (and are `live`): cnt += hit.  The loop over the picked queries is written out: left to the compiler it keeps the mask
+// in VCC but clears its bit with a shift and an and-not (or an add -1 and an and) and tests it with a compare -- 5 scalar
+// + 4 vector instructions per (slot, query); here s_bitset0 and the branch on VCC itself: 3 + 4, and the kernels that run
+// it are bound by instruction issue (the headline scan: 68.5 -> 65 us).  Wait states (gfx950): a packed op's result read
+// by the next VALU 1, an SGPR written by a VALU (v_readlane, v_cmp) read by a VALU 2.
+template <bool LIVE>
+__device__ __forceinline__ void match_slot_asm(int &cnt, uint32_t W, int P0, uint32_t rec, unsigned long long live)
+{
+    int t, q, x;
+    unsigned long long c;
+    if (LIVE)
+        asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
+                     "s_nop 0\n\t"
+                     "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
+                     "s_and_b64 vcc, vcc, %[live]\n\t"
+                     "s_cbranch_vccz 2f\n"
+                     "1:\n\t"
+                     "s_ff1_i32_b64 %[t], vcc\n\t"
+                     "v_readlane_b32 %[q], %[P0], %[t]\n\t"
+                     "s_bitset0_b64 vcc, %[t]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
+                     "s_nop 0\n\t"
+                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
+                     "s_nop 1\n\t"
+                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
+                     "s_cbranch_vccnz 1b\n"
+                     "2:"
+                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
+                     : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec), [live] "s"(live)
+                     : "vcc", "scc");
+    else
+        asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
+                     "s_nop 0\n\t"
+                     "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
+                     "s_cbranch_vccz 2f\n"
+                     "1:\n\t"
+                     "s_ff1_i32_b64 %[t], vcc\n\t"
+                     "v_readlane_b32 %[q], %[P0], %[t]\n\t"
+                     "s_bitset0_b64 vcc, %[t]\n\t"
+                     "s_nop 0\n\t"
+                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
+                     "s_nop 0\n\t"
+                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
+                     "s_nop 1\n\t"
+                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
+                     "s_cbranch_vccnz 1b\n"
+                     "2:"
+                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
+                     : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec)
+                     : "vcc");
+}
+
 // Compact image: the queries of `live` (one per lane, word P0) against the unit, slot by slot.  A
 // query is compared with the records of a slot only if its word passes against the slot's summary
 // W[r] -- the same packed test, done for 64 queries at once; on the benchmark that leaves 1.8 of
@@ -175,6 +229,11 @@ __device__ __forceinline__ void match_raw(const Raw &R, int (&cnt)[IGD_SLOTS], i
 __device__ __forceinline__ void match_slots(const Raw &R, int (&cnt)[IGD_SLOTS], const uint32_t (&W)[IGD_SLOTS], int P0,
                                             unsigned long long live)
 {
+#if IGD_ASM_MATCH && !IGD_EXP_NOMATCH
+#pragma unroll
+    for (int r = 0; r < IGD_SLOTS; r++) match_slot_asm<true>(cnt[r], W[r], P0, R.a[r], live);
+    return;
+#endif
     igd_u16x2 qv;
     __builtin_memcpy(&qv, &P0, 4);
 #pragma unroll
