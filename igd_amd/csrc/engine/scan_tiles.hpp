@@ -200,50 +200,7 @@ __device__ __forceinline__ void match_slot_asm(int &cnt, uint32_t W, int P0, uin
                      : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
                      : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec), [live] "s"(live)
                      : "vcc", "scc");
-    else if (IGD_ASM_MATCH == 3) {
-        // two picked queries per pass while there are two: the second one's instructions fill the first one's wait states
-        int t2, q2, x2, n;
-        unsigned long long c2;
-        asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
-                     "s_nop 0\n\t"
-                     "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
-                     "s_cbranch_vccz 9f\n\t"
-                     "s_bcnt1_i32_b64 %[n], vcc\n\t"
-                     "s_cmp_lt_u32 %[n], 2\n\t"
-                     "s_cbranch_scc1 3f\n"
-                     "2:\n\t"
-                     "s_ff1_i32_b64 %[t], vcc\n\t"
-                     "s_bitset0_b64 vcc, %[t]\n\t"
-                     "s_ff1_i32_b64 %[t2], vcc\n\t"
-                     "s_bitset0_b64 vcc, %[t2]\n\t"
-                     "v_readlane_b32 %[q], %[P0], %[t]\n\t"
-                     "v_readlane_b32 %[q2], %[P0], %[t2]\n\t"
-                     "s_sub_u32 %[n], %[n], 2\n\t"
-                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
-                     "v_pk_max_u16 %[x2], %[rec], %[q2]\n\t"
-                     "s_cmp_gt_u32 %[n], 1\n\t"
-                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
-                     "v_cmp_eq_u32_e64 %[c2], %[rec], %[x2]\n\t"
-                     "s_nop 0\n\t"
-                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
-                     "v_addc_co_u32_e64 %[cnt], %[c2], 0, %[cnt], %[c2]\n\t"
-                     "s_cbranch_scc1 2b\n\t"
-                     "s_cbranch_vccz 9f\n"
-                     "3:\n\t"
-                     "s_ff1_i32_b64 %[t], vcc\n\t"
-                     "v_readlane_b32 %[q], %[P0], %[t]\n\t"
-                     "s_nop 1\n\t"
-                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
-                     "s_nop 0\n\t"
-                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
-                     "s_nop 1\n\t"
-                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n"
-                     "9:"
-                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c), [t2] "=&s"(t2), [q2] "=&s"(q2),
-                       [x2] "=&v"(x2), [c2] "=&s"(c2), [n] "=&s"(n)
-                     : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec)
-                     : "vcc", "scc");
-    } else
+    else
         asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
                      "s_nop 0\n\t"
                      "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
