@@ -337,8 +337,8 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     }
     // (Tried: the long queries' work on a quarter of the launch's workgroups, to quarter the 3.9 x 10^6 atomics with which 2048
     // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
-    exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
-    coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
+    if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
     if (hist) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
