@@ -337,8 +337,16 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     }
     // (Tried: the long queries' work on a quarter of the launch's workgroups, to quarter the 3.9 x 10^6 atomics with which 2048
     // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
-    if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
-    if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    // The walks are chains of dependent loads (a query, its tile, the tile's units, their records), the coverage sums stream
+    // the covered tiles' dataset numbers into LDS atomics: every wave has a share of both, and half the waves of a SIMD
+    // (bit 2 of the wave's number: waves w, w + 4, w + 8, ... share a SIMD) take theirs in the other order, so that the two
+    // kinds of work overlap instead of following each other (10^5 queries of 100-200 kbp: walks 51 us + sums 48 us)
+    const bool covFirst = IGD_TAIL_MIX && ((threadIdx.x >> 8) & 1) != 0;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ph++) {
+        if ((ph == 0) != covFirst) { if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist); }
+        else if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
+    }
     if (hist) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
