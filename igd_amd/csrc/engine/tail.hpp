@@ -248,32 +248,36 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
         if (m == 0) continue;                            // nothing of this chunk is covered
         // What bounds a covered unit is the round trip for its records: TWO units are in flight per wave (the loads of the
         // next covered unit are issued before the current one is counted).
-        struct Cov { int st[IGD_SLOTS], ix[IGD_SLOTS], va[USE_V ? IGD_SLOTS : 1]; int c, lob; };
+        struct Cov { int st[IGD_SLOTS], ix[IGD_SLOTS], va[USE_V ? IGD_SLOTS : 1]; int c, lob, nrem; };
         // (compact image: the records that start in the tile are the unit's records from number `pre` on -- Unit::pre -- so
         // only their dataset numbers are read: 2 bytes a record, 4 with the value, where the exact arrays cost 8 and 12)
+        // This launch runs 4 waves per SIMD and was bound by the instructions it issues (120 per covered unit: 2 x 10^7 for a
+        // batch whose long queries cover the genome): the compact path asks for the records [pre, n) through a descriptor
+        // that ends at n -- lanes past it read 0 without a compare, slots past it are not visited -- and knows what the
+        // unit adds to the batch total without counting it (c x (n - pre)): ~50.
         const bool cimg = USE_V ? a.packedWalk == 2 : a.packedWalk != 0;
+        const int vo2 = lane * 2, vo4 = lane * 4;
         auto issue = [&](int e, Cov &w) {
             w.c = __builtin_amdgcn_readlane(cv, e);
-            w.lob = __builtin_amdgcn_readlane(bd, e);
             const int n = __builtin_amdgcn_readlane(ur.n, e);
             const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(ur.offHi, e) << 32) |
                                           (unsigned)__builtin_amdgcn_readlane(ur.offLo, e));
             if (cimg) {
                 const int pre = __builtin_amdgcn_readlane(ur.pre, e);
+                const int nrem = n > pre ? n - pre : 0;
+                w.nrem = nrem;
+                if (USE_V) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + off + pre), 0, nrem * 4, 0x00020000);
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) {
-                    const int i = r * IGD_WAVE + lane;
-                    const bool in = i >= pre && i < n;
-                    w.st[r] = in ? INT_MAX : INT_MIN;            // (>= lob / < lob)
-                    w.ix[r] = 0;
-                    if (USE_V) w.va[r] = INT_MIN;
-                    if (in && (r + 1) * IGD_WAVE > pre && r * IGD_WAVE < n) {
-                        if (USE_V) { const uint32_t x = db.pxv[off + i]; w.ix[r] = (int)(x & 0xFFFFu); w.va[r] = (int)x >> 16; }
-                        else w.ix[r] = (int)db.px[off + i];
-                    }
+                    for (int r = 0; r < IGD_SLOTS; r++) w.ix[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rs, vo4, r * 256, 0);
+                } else {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + off + pre), 0, nrem * 2, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) w.ix[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo2, r * 128, 0);
                 }
                 return;
             }
+            w.lob = __builtin_amdgcn_readlane(bd, e);
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 const int i = r * IGD_WAVE + lane;
@@ -283,6 +287,22 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
             }
         };
         auto count = [&](const Cov &w) {
+            if (cimg) {
+                if (!USE_V) found += (u64)(unsigned)w.nrem * (u64)(unsigned)w.c;
+#pragma unroll
+                for (int r = 0; r < IGD_SLOTS; r++) {
+                    if (r * IGD_WAVE >= w.nrem) break;   // (the same for all lanes)
+                    bool in = lane < w.nrem - r * IGD_WAVE;
+                    int ix = w.ix[r];
+                    if (USE_V) {
+                        in = in && (ix >> 16) >= a.v;    // (arithmetic shift: the signed 16-bit value)
+                        ix &= 0xFFFF;
+                        found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)w.c;
+                    }
+                    if (in) { if (hist) atomicAdd(&hist[ix], (u64)(unsigned)w.c); else atomicAdd(&d_hits[ix], (u64)(unsigned)w.c); }
+                }
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 bool in = w.st[r] >= w.lob;              // the copy of the record that counts (:510-511)
@@ -337,16 +357,10 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     }
     // (Tried: the long queries' work on a quarter of the launch's workgroups, to quarter the 3.9 x 10^6 atomics with which 2048
     // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
-    // The walks are chains of dependent loads (a query, its tile, the tile's units, their records), the coverage sums stream
-    // the covered tiles' dataset numbers into LDS atomics: every wave has a share of both, and half the waves of a SIMD
-    // (bit 2 of the wave's number: waves w, w + 4, w + 8, ... share a SIMD) take theirs in the other order, so that the two
-    // kinds of work overlap instead of following each other (10^5 queries of 100-200 kbp: walks 51 us + sums 48 us)
-    const bool covFirst = IGD_TAIL_MIX && ((threadIdx.x >> 8) & 1) != 0;
-#pragma unroll 1
-    for (int ph = 0; ph < 2; ph++) {
-        if ((ph == 0) != covFirst) { if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist); }
-        else if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
-    }
+    // (Tried: half the waves of a SIMD taking their coverage sums before their walks, so that the two kinds of work overlap:
+    // 108.5 vs 109.1 us for 10^5 queries of 100-200 kbp -- both are bound by the instructions the launch's 4 waves per SIMD issue.)
+    if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
+    if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
     if (hist) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {

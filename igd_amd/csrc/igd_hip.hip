@@ -85,9 +85,6 @@
 #define IGD_TAIL_WG 1024                     // ... in workgroups of 16 waves: what the long queries' work counts in a workgroup's LDS
                                              // leaves it as one global atomic per dataset, and 2048 workgroups of 4 waves made 3.9 x 10^6 of those
 #endif
-#ifndef IGD_TAIL_MIX
-#define IGD_TAIL_MIX 1                       // last launch: half the waves of a SIMD do the coverage sums before the exact walks (batch_tail)
-#endif
 #ifndef IGD_REDUCE_GROUPS
 #define IGD_REDUCE_GROUPS 64                 // (32-bit slab rows: 6.2 us with 128 groups, 5.4 with 64, 6.4 with 32, 10.1 with 16)
 #endif

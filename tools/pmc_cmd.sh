@@ -5,7 +5,7 @@ tag0=$1; pat=$2; shift 2
 root=$PWD; out=$root/gpurun_out/$tag0; rm -rf $out; mkdir -p $out
 python tools/prep.py > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_FLAT" "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum" "TCC_ATOMIC_sum TCC_WRITE_sum" "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"; do
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_INSTS_SMEM SQ_INSTS_FLAT" "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum" "TCC_ATOMIC_sum TCC_WRITE_sum" "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum" "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum" "SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_WAVES SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$tag -- python3 $root/"$@" > $out/$tag.log 2>&1 || true
 done
