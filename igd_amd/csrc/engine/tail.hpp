@@ -5,9 +5,20 @@
 // query's tiles (WALK_*: which of them) on the EXACT arrays, 5 slots at a time, and adds into the workgroup's LDS
 // counters of the batch's last launch -- the caller's global hits[] where the files do not fit -- and the batch total.
 // Rare for the benchmark's queries; a batch of long ones lists every query (its last tile).
+// The workgroup's LDS counters of the batch's last launch.  An LDS pointer by TYPE: through a plain `u64 *` (which may also
+// be null, or point at global memory) the compiler emitted flat_atomic_add_x2 -- 138 of them in k_reduce_slabs, not one
+// ds_add_u64 -- and a flat atomic that resolves to LDS goes the vector-memory way round (address check in the texture
+// path, both counters) instead of straight to the LDS: the long queries' last launch spent most of its time there.
+typedef __attribute__((address_space(3))) u64 igd_lds_u64;
+struct TailHist {
+    igd_lds_u64 *p;
+    bool on;
+    __device__ __forceinline__ void add(int ix, u64 v) const { (void)__hip_atomic_fetch_add(p + ix, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+
 template <bool USE_V>
 __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs &a, const int2 *__restrict__ fixList,
-                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv, u64 *hist)
+                                                const int2 *__restrict__ longList, int gwave, int nwaves, int ctlv, const TailHist hist)
 {
     // ctlv: the batch's control words, word i in lane i (ONE load by the caller: the walk and the two skew valves
     // would otherwise each wait for their own, one after the other, to find out that there is nothing to do)
@@ -95,7 +106,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                     if (USE_V) hit = hit && ((int)w.px[r] >> 16) >= a.v;
                     const int ix = (int)(w.px[r] & 0xFFFFu);
                     found += __popcll(__ballot(hit));
-                    if (hit) { if (hist) atomicAdd(&hist[ix], 1ull); else atomicAdd(&a.out[ix], 1ull); }
+                    if (hit) { if (hist.on) hist.add(ix, 1ull); else atomicAdd(&a.out[ix], 1ull); }
                 }
             };
             unsigned long long m = __ballot(lane < cnt && vkind == WALK_LAST && vj1 >= 0 && vnu > 0);
@@ -173,7 +184,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                         bool hit = (st[r] < qe) & (st[r] >= lob) & (en[r] > qs);
                         if (USE_V) hit = hit & (va[r] >= a.v);
                         found += __popcll(__ballot(hit));
-                        if (hit) { if (hist) atomicAdd(&hist[ix[r]], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
+                        if (hit) { if (hist.on) hist.add(ix[r], 1ull); else atomicAdd(&a.out[ix[r]], 1ull); }
                     }
                 }
             }
@@ -202,7 +213,7 @@ __device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int 
 #define IGD_COV_CHUNK 16      // units a wave takes at a time (32 left a quarter of the last launch's 8192 waves without a chunk of the benchmark's 190 000 units) (strided over the launch's waves: long queries may all lie in one region)
 template <bool USE_V>
 __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
-                                              u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, u64 *hist)
+                                              u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, const TailHist hist)
 {
     const int lane = threadIdx.x & 63;
     const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == a.epoch;
@@ -299,7 +310,7 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
                         ix &= 0xFFFF;
                         found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)w.c;
                     }
-                    if (in) { if (hist) atomicAdd(&hist[ix], (u64)(unsigned)w.c); else atomicAdd(&d_hits[ix], (u64)(unsigned)w.c); }
+                    if (in) { if (hist.on) hist.add(ix, (u64)(unsigned)w.c); else atomicAdd(&d_hits[ix], (u64)(unsigned)w.c); }
                 }
                 return;
             }
@@ -308,7 +319,7 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
                 bool in = w.st[r] >= w.lob;              // the copy of the record that counts (:510-511)
                 if (USE_V) in = in && w.va[r] >= a.v;
                 found += (u64)__popcll(__ballot(in)) * (u64)(unsigned)w.c;
-                if (in) { if (hist) atomicAdd(&hist[w.ix[r]], (u64)(unsigned)w.c); else atomicAdd(&d_hits[w.ix[r]], (u64)(unsigned)w.c); }
+                if (in) { if (hist.on) hist.add(w.ix[r], (u64)(unsigned)w.c); else atomicAdd(&d_hits[w.ix[r]], (u64)(unsigned)w.c); }
             }
         };
         Cov C0, C1, C2, C3;                              // FOUR covered units in flight per wave
@@ -343,15 +354,17 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     const int lane = threadIdx.x & 63;
     // what the exact walks and the coverage find is counted in the workgroup's LDS first (when the files fit): a batch of
     // long queries makes one addition per (query, record) pair here
-    u64 *hist = nullptr;
+    TailHist hist;
+    hist.p = (igd_lds_u64 *)(smem + (K.a.tailHistOff >= 0 ? K.a.tailHistOff : 0));
+    hist.on = false;
     if (K.a.tailHistOff >= 0) {
         const bool uns = __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) == wa.epoch;
         const bool sortedPath = wa.mode == 1 || (wa.mode == 0 && !uns);
         const int nList = __builtin_amdgcn_readlane(ctlv, (sortedPath ? CTL_NFIX : CTL_NLONG) + (wa.epoch & 1));
         const bool cov = __builtin_amdgcn_readlane(ctlv, CTL_COV + (sortedPath ? 0 : 2) + (wa.epoch & 1)) == wa.epoch;
         if (!(wa.mode == 1 && uns) && (nList > 0 || cov)) {          // (the same answer in every wave of the launch)
-            hist = (u64 *)(smem + K.a.tailHistOff);
-            for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) hist[f] = 0;
+            hist.on = true;
+            for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) hist.p[f] = 0;
             __syncthreads();
         }
     }
@@ -361,10 +374,10 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     // 108.5 vs 109.1 us for 10^5 queries of 100-200 kbp -- both are bound by the instructions the launch's 4 waves per SIMD issue.)
     if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
     if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
-    if (hist) {
+    if (hist.on) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
-            const u64 c = hist[f];
+            const u64 c = hist.p[f];
             if (c) atomicAdd(&d_hits[f], c);
         }
     }
