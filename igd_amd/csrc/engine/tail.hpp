@@ -210,7 +210,9 @@ __device__ __forceinline__ void coverage_reset(const DbView &db, int epoch, int 
     }
 }
 
-#define IGD_COV_CHUNK 16      // units a wave takes at a time (32 left a quarter of the last launch's 8192 waves without a chunk of the benchmark's 190 000 units) (strided over the launch's waves: long queries may all lie in one region)
+#ifndef IGD_COV_CHUNK
+#define IGD_COV_CHUNK 0       // units a wave takes at a time; 0: every wave's share in as few chunks as a wave holds descriptors for (<= 64 units each)
+#endif
 template <bool USE_V>
 __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &a, u64 *__restrict__ d_hits,
                                               u64 *__restrict__ d_total, int gwave, int nwaves, int ctlv, const TailHist hist)
@@ -222,8 +224,17 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
     if (__builtin_amdgcn_readlane(ctlv, CTL_COV + set * 2 + par) != a.epoch) return;     // no long query in this batch
     const int32_t *diff = db.cov + (size_t)(set * 2 + par) * IGD_COV_LEN(db.nT), *coarse = diff + db.nT + 2;
     u64 found = 0;
-    for (int u0 = gwave * IGD_COV_CHUNK; u0 < db.nUnits; u0 += nwaves * IGD_COV_CHUNK) {
-        const int cnt = db.nUnits - u0 < IGD_COV_CHUNK ? db.nUnits - u0 : IGD_COV_CHUNK;
+    // A chunk costs a chain of round trips before its first record arrives (the units' descriptors, their tiles' borders, the
+    // coverage count at its first tile), so a wave's share comes in as few chunks as possible: one, of nUnits / nwaves units,
+    // for the benchmark's 190 000 units on 4096 waves (16 at a time -- three chunks for most waves, two for the rest -- took as long
+    // as the longer chain: the launch's 4 waves per SIMD neither ran out of instructions to issue nor waited for the LDS).
+    int chunk = IGD_COV_CHUNK;
+    if (chunk == 0) {
+        chunk = (db.nUnits + nwaves - 1) / nwaves;
+        chunk = chunk < 16 ? 16 : (chunk > IGD_WAVE ? IGD_WAVE : chunk);
+    }
+    for (int u0 = gwave * chunk; u0 < db.nUnits; u0 += nwaves * chunk) {
+        const int cnt = db.nUnits - u0 < chunk ? db.nUnits - u0 : chunk;
         // one unit per lane: its tile, and the number of long queries that cover that tile from end to end = (coarse +
         // fine prefix at the chunk's first tile) + the differences of the tiles since -- no chain of loads from unit to unit
         UnitRegs ur = load_unit_regs(db.units + u0 + (lane < cnt ? lane : 0));
