@@ -15,3 +15,4 @@ q = synth.make_queries(nq, seed=7, genome=synth.HG38, min_len=lo, max_len=hi, so
 job = bench.Job(db, dev, st.cuda_stream, *q, 0, 1)
 el, prof = job.run(steps, 3)
 print("len %d..%d nq %d: step %.1f us scan %.1f us" % (lo, hi, nq, 1e6 * el / steps, 1e3 * prof["scan_ms"]))
+del job; db.close()
