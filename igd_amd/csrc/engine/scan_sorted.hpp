@@ -358,7 +358,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         for (int p = 0; p < nE; p += IGD_WAVE) {
             // the next 64 words are on their way while these are compared (a dense tile is a chain of such batches)
             const int wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
-            match_words<IGD_ASM_MATCH != 2 || !RANK>(R, cnt, W, w);
+            match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, w);
             w = wn;
         }
         if (far)
@@ -366,7 +366,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 bool covers;
                 const int lw = later_word(db.nbp, e, g2, deadk, true, covers);
                 nLater += __popcll(__ballot(covers));
-                match_words<IGD_ASM_MATCH != 2 || !RANK>(R, cnt, W, lw);
+                match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, lw);
             });
         // records that start before the tile (s' = 0, low half 65535) were matched by every "later tile"
         // query, none of which may count them (the reference's tS skip, :510-511)

@@ -177,81 +177,49 @@ __device__ __forceinline__ void match_raw(const Raw &R, int (&cnt)[IGD_SLOTS], i
 template <bool LIVE>
 __device__ __forceinline__ void match_slot_asm(int &cnt, uint32_t W, int P0, uint32_t rec, unsigned long long live)
 {
-    int t, q, x, n;
-#if IGD_ASM_MATCH == 5
-    // (the first written-out loop: hit = (max(rec, q) == rec) through v_cmp into an SGPR pair and v_addc from it)
+    int t, q, x;
     unsigned long long c;
-    asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
-                 "s_nop 0\n\t"
-                 "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
-                 "s_and_b64 vcc, vcc, %[live]\n\t"
-                 "s_cbranch_vccz 2f\n"
-                 "1:\n\t"
-                 "s_ff1_i32_b64 %[t], vcc\n\t"
-                 "v_readlane_b32 %[q], %[P0], %[t]\n\t"
-                 "s_bitset0_b64 vcc, %[t]\n\t"
-                 "s_nop 0\n\t"
-                 "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
-                 "s_nop 0\n\t"
-                 "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
-                 "s_nop 1\n\t"
-                 "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
-                 "s_cbranch_vccnz 1b\n"
-                 "2:"
-                 : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
-                 : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec), [live] "s"(LIVE ? live : ~0ull)
-                 : "vcc", "scc");
-    (void)n;
-#else
-    // Every picked query counts up front (s_bcnt1 of the mask); the loop takes the misses off again: the saturating packed
-    // difference q - rec is 0 in both halves iff the record word is >= the query's in both, min(., 1) makes that 0 / 1.  No
-    // v_cmp into a scalar register pair, no v_addc out of it -- vector instructions that touch scalar registers run at
-    // half rate and want two wait states (tools/issue_bench.hip: a lone wave gets through this body in 53 clocks, through
-    // the v_cmp / v_addc one in 76; what bounds the scan kernels is how fast a wave gets through its own chain).
     if (LIVE)
         asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
                      "s_nop 0\n\t"
                      "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
                      "s_and_b64 vcc, vcc, %[live]\n\t"
-                     "s_cbranch_vccz 2f\n\t"
-                     "s_bcnt1_i32_b64 %[n], vcc\n\t"
-                     "v_add_u32 %[cnt], %[n], %[cnt]\n"
+                     "s_cbranch_vccz 2f\n"
                      "1:\n\t"
                      "s_ff1_i32_b64 %[t], vcc\n\t"
                      "v_readlane_b32 %[q], %[P0], %[t]\n\t"
                      "s_bitset0_b64 vcc, %[t]\n\t"
                      "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[x], %[q], %[rec] clamp\n\t"
+                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
                      "s_nop 0\n\t"
-                     "v_min_u32 %[x], %[x], 1\n\t"
-                     "v_sub_u32 %[cnt], %[cnt], %[x]\n\t"
+                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
+                     "s_nop 1\n\t"
+                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
                      "s_cbranch_vccnz 1b\n"
                      "2:"
-                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [n] "=&s"(n)
+                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
                      : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec), [live] "s"(live)
                      : "vcc", "scc");
     else
         asm volatile("v_pk_max_u16 %[x], %[W], %[P0]\n\t"
                      "s_nop 0\n\t"
                      "v_cmp_eq_u32_e32 vcc, %[W], %[x]\n\t"
-                     "s_cbranch_vccz 2f\n\t"
-                     "s_bcnt1_i32_b64 %[n], vcc\n\t"
-                     "v_add_u32 %[cnt], %[n], %[cnt]\n"
+                     "s_cbranch_vccz 2f\n"
                      "1:\n\t"
                      "s_ff1_i32_b64 %[t], vcc\n\t"
                      "v_readlane_b32 %[q], %[P0], %[t]\n\t"
                      "s_bitset0_b64 vcc, %[t]\n\t"
                      "s_nop 0\n\t"
-                     "v_pk_sub_u16 %[x], %[q], %[rec] clamp\n\t"
+                     "v_pk_max_u16 %[x], %[rec], %[q]\n\t"
                      "s_nop 0\n\t"
-                     "v_min_u32 %[x], %[x], 1\n\t"
-                     "v_sub_u32 %[cnt], %[cnt], %[x]\n\t"
+                     "v_cmp_eq_u32_e64 %[c], %[rec], %[x]\n\t"
+                     "s_nop 1\n\t"
+                     "v_addc_co_u32_e64 %[cnt], %[c], 0, %[cnt], %[c]\n\t"
                      "s_cbranch_vccnz 1b\n"
                      "2:"
-                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [n] "=&s"(n)
+                     : [cnt] "+v"(cnt), [t] "=&s"(t), [q] "=&s"(q), [x] "=&v"(x), [c] "=&s"(c)
                      : [W] "s"(W), [P0] "v"(P0), [rec] "v"(rec)
-                     : "vcc", "scc");
-#endif
+                     : "vcc");
 }
 
 // Compact image: the queries of `live` (one per lane, word P0) against the unit, slot by slot.  A

@@ -112,7 +112,7 @@ typedef unsigned long long u64;
                        // far_units_body, 0x40000 / 0x80000 k_query_bounds without the firstQ[] fill / the head and tail fill, 0x100000 / 0x200000 the last launch without the exact walks / the coverage sums (WRONG counts); 0x400000 time stamps of the last launch's waves (tools/tail_stamps.py)
 #endif
 #ifndef IGD_ASM_MATCH
-#define IGD_ASM_MATCH 1 // igd_scan_sorted's pairwise compare loop written out in assembly (0: the compiler's everywhere, 2: written out in the lean build only, 5: the first written-out form, v_cmp / v_addc)
+#define IGD_ASM_MATCH 1 // igd_scan_sorted's pairwise compare loop written out in assembly (0: the compiler's everywhere, 2: written out in the lean build only)
 #endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)

@@ -30,10 +30,6 @@ __global__ __launch_bounds__(256) void k(int iters, unsigned *out, unsigned long
             asm volatile(REP8(REP8("v_pk_max_u16 %2, %0, %1\n s_nop 0\n v_cmp_eq_u32_e32 vcc, %0, %2\n s_nop 1\n v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n")) : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"vcc");
         } else if (MODE == 8) {   // the compare loop's body as shipped (no branch)
             asm volatile(REP8(REP8("s_ff1_i32_b64 %1, vcc\n v_readlane_b32 %2, %4, %1\n s_bitset0_b64 vcc, %1\n s_nop 0\n v_pk_max_u16 %5, %4, %2\n s_nop 0\n v_cmp_eq_u32_e64 s[20:21], %4, %5\n s_nop 1\n v_addc_co_u32_e64 %6, s[20:21], 0, %6, s[20:21]\n")) : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2)::"vcc", "s20", "s21");
-        } else if (MODE == 10) {  // the compare loop's body counting misses without a scalar register: saturating packed subtract, min, subtract
-            asm volatile(REP8(REP8("s_ff1_i32_b64 %1, vcc\n v_readlane_b32 %2, %4, %1\n s_bitset0_b64 vcc, %1\n s_nop 0\n v_pk_sub_u16 %5, %2, %4 clamp\n s_nop 0\n v_min_u32 %5, %5, 1\n v_sub_u32 %6, %6, %5\n")) : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2)::"vcc");
-        } else if (MODE == 11) {  // ... and with the packed op fed from a VGPR copy of the query (v_readlane -> v_mov not needed: just to see the SGPR operand's cost)
-            asm volatile(REP8(REP8("s_ff1_i32_b64 %1, vcc\n v_readlane_b32 %2, %4, %1\n s_bitset0_b64 vcc, %1\n s_nop 0\n v_pk_sub_u16 %5, %4, %6 clamp\n s_nop 0\n v_min_u32 %5, %5, 1\n v_sub_u32 %6, %6, %5\n")) : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2)::"vcc");
         } else if (MODE == 9) {   // scalar loads from the kernel arguments' page (SMEM issue)
             asm volatile(REP8(REP8("s_load_dword %0, %4, 0x0\n s_load_dword %1, %4, 0x4\n s_load_dword %2, %4, 0x8\n s_load_dword %3, %4, 0xc\n")) "s_waitcnt lgkmcnt(0)\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "s"(out));
         }
@@ -71,7 +67,7 @@ int main()
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     printf("%s, %d CUs\n", p.name, cus);
-    for (int w : {1, 4, 8}) {
+    for (int w : {1, 2, 4, 8}) {
         printf("--\n");
         run<0>("scalar adds, 4 independent chains", 4, w, cus);
         run<3>("scalar adds, one dependent chain", 4, w, cus);
@@ -82,8 +78,6 @@ int main()
         run<6>("2 x v_cmp -> SGPR pair, 2 x v_addc from it", 4, w, cus);
         run<7>("v_pk_max, v_cmp -> vcc, v_addc (3 VALU + nops)", 3, w, cus);
         run<8>("compare loop body as shipped (3 SALU + 4 VALU)", 7, w, cus);
-        run<10>("compare loop body, misses by pk_sub clamp/min/sub (3 SALU + 4 VALU)", 7, w, cus);
-        run<11>("... same, packed op without the SGPR operand", 7, w, cus);
         run<9>("s_load_dword x 4", 4, w, cus);
     }
     return 0;
