@@ -565,15 +565,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (!marked && !(IGD_EXP & 0x40000)) {
 #pragma unroll
         for (int v = 0; v < VEC; v++) {
-            const int i = i0 + v, h1 = key[v], p1 = pos[v];
-            int l1 = lo[v];
-            if (quick && IGD_QB_ONE) {
-                // the short path's queries are in order inside one contig: a query that opens a tile nearly always opens ONE
-                // (the one after its predecessor's) -- stored straight away, no loop; what is left of a longer gap goes the
-                // general way below, which most waves then skip with one ballot
-                if (h1 >= l1) { firstQ[l1] = i; lpos[l1] = p1; }
-                l1++;
-            }
+            const int i = i0 + v, l1 = lo[v], h1 = key[v], p1 = pos[v];
             const bool some = h1 >= l1;
             if (quick && __ballot(some) == 0) continue;     // (a dense batch: most queries share their tile with the one before)
             const bool big = h1 - l1 >= 8;

@@ -114,9 +114,6 @@ typedef unsigned long long u64;
 #ifndef IGD_ASM_MATCH
 #define IGD_ASM_MATCH 1 // igd_scan_sorted's pairwise compare loop written out in assembly (0: the compiler's everywhere, 2: written out in the lean build only)
 #endif
-#ifndef IGD_QB_ONE
-#define IGD_QB_ONE 1   // k_query_bounds, short path: the first tile a query opens is stored without a loop
-#endif
 #ifndef IGD_NT_AUX
 #define IGD_NT_AUX 0   // cache policy of igd_scan_sorted's record loads (measured: 2 = nt is 6 % slower -- consecutive batches find part of the image in the Infinity Cache)
 #endif
