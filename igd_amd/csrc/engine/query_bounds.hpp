@@ -569,7 +569,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const bool some = h1 >= l1;
             if (quick && __ballot(some) == 0) continue;     // (a dense batch: most queries share their tile with the one before)
             const bool big = h1 - l1 >= 8;
-            if (!big) for (int tt = l1; tt <= h1; tt++) { firstQ[tt] = i; lpos[tt] = p1; }
+            if (!big) for (int tt = l1; tt <= h1; tt++) { firstQ[tt] = i; if (!(IGD_EXP & 0x800000)) lpos[tt] = p1; }
             unsigned long long m = __ballot(big);
             if (m == 0) continue;
             // the budget is charged once for all long gaps of the wave's 64 queries (a returning atomic each made a small

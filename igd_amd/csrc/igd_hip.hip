@@ -109,7 +109,7 @@ typedef unsigned long long u64;
                        // term A / prefix sums, 512 later-tile queries found but not searched, 8192 k_query_bounds without the
                        // compaction of the later-tile words; 32 time stamps per wave (tools/stamps.py), 1024 section timers of the
                        // rank method (printed by igd_hip_close); 0x10000 / 0x20000 the last launch without heavy_sorted_body /
-                       // far_units_body, 0x40000 / 0x80000 k_query_bounds without the firstQ[] fill / the head and tail fill, 0x100000 / 0x200000 the last launch without the exact walks / the coverage sums (WRONG counts); 0x400000 time stamps of the last launch's waves (tools/tail_stamps.py)
+                       // far_units_body, 0x40000 / 0x80000 k_query_bounds without the firstQ[] fill / the head and tail fill, 0x100000 / 0x200000 the last launch without the exact walks / the coverage sums (WRONG counts); 0x400000 time stamps of the last launch's waves (tools/tail_stamps.py); 0x800000 k_query_bounds without the lpos[] stores of short gaps (WRONG counts)
 #endif
 #ifndef IGD_ASM_MATCH
 #define IGD_ASM_MATCH 1 // igd_scan_sorted's pairwise compare loop written out in assembly (0: the compiler's everywhere, 2: written out in the lean build only)
@@ -183,7 +183,7 @@ extern "C" int64_t igd_hip_max_batch(void) { return max_batch(); }
 // What this library was compiled as: bits 0..23 = IGD_EXP, bit 24 = IGD_EXP_NOMATCH.  A build with any bit of
 // IGD_HIP_BUILD_WRONG_COUNTS gives WRONG counts on purpose (measurement of kernel sections): igd_hip_open refuses to
 // work in such a build unless IGD_HIP_ALLOW_EXP_BUILD=1 says the caller knows (tools/valu_ab.sh does).
-#define IGD_EXP_WRONG_BITS (1 | 2 | 4 | 8 | 64 | 128 | 256 | 512 | 8192 | 0x10000 | 0x20000 | 0x40000 | 0x80000 | 0x100000 | 0x200000)
+#define IGD_EXP_WRONG_BITS (1 | 2 | 4 | 8 | 64 | 128 | 256 | 512 | 8192 | 0x10000 | 0x20000 | 0x40000 | 0x80000 | 0x100000 | 0x200000 | 0x800000)
 extern "C" unsigned igd_hip_build_flags(void) { return ((unsigned)IGD_EXP & 0xffffffu) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
 extern "C" unsigned igd_hip_build_wrong_counts(void) { return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
 
