@@ -41,6 +41,15 @@ extern "C" void igd_hip_close(igd_hip_db *db)
         fprintf(stderr, "[igd sect] waiting for records %.3f, compare phases of all visited units %.3f\n", (double)h[6] / h[5], (double)h[7] / h[5]);
     }
 #endif
+#if IGD_EXP & 0x1000000
+    {
+        std::vector<u64> h((size_t)8192 * 8);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(d_qbSt), h.size() * 8);
+        FILE *f = fopen("gpurun_out/qb_stamps.bin", "wb");
+        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+#endif
 #if IGD_EXP & 0x400000
     {
         std::vector<u64> h((size_t)16384 * 5);
