@@ -662,9 +662,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #ifndef IGD_XCD_REMAP
 #define IGD_XCD_REMAP 0         // 1: an XCD (blockIdx & 7) takes a contiguous eighth of every round of units
 #endif
-#ifndef IGD_LEAN_DEPTH
-#define IGD_LEAN_DEPTH 2        // units in flight per wave in the lean build
-#endif
 #ifndef IGD_WG_LEAN
 #define IGD_WG_LEAN IGD_WG      // ... and of the lean build
 #define IGD_WPE_LEAN IGD_WPE
@@ -818,34 +815,8 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
             }
             continue;
         }
-#if IGD_LEAN_DEPTH == 3
-        // three units in flight per wave (the lean build at 6 waves per SIMD has the registers for a third buffer):
-        // the kernel is bound by memory latency x units in flight, 24 x 3 per CU instead of 32 x 2
-        {
-            Raw2 C;
-            s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
-            s_issue<USE_V, BIG>(db, a, L, 1, 1 < cntU, lane, B);
-            for (int kk = 0; kk < cntU; kk += 3) {
-                s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, C);
-                s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
-                s_issue<USE_V, BIG>(db, a, L, kk + 3, kk + 3 < cntU, lane, A);
-                if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
-                s_issue<USE_V, BIG>(db, a, L, kk + 4, kk + 4 < cntU, lane, B);
-                if (kk + 2 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 2, lane, C, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
-#if IGD_OPT_PRIO
-                done += 3;
-                if (done >= prioAt) {
-                    prioAt += quarter;
-                    prioLevel--;
-                    if (prioLevel == 2) __builtin_amdgcn_s_setprio(2);
-                    else if (prioLevel == 1) __builtin_amdgcn_s_setprio(1);
-                    else __builtin_amdgcn_s_setprio(0);
-                }
-#endif
-            }
-            continue;
-        }
-#endif
+        // (three units in flight per wave -- the next unit's loads issued before the current one is compared -- need 74 registers,
+        // i.e. 6 waves per SIMD: measured twice, 68.3 against 64.9 us on the final build; the code is gone)
         s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
         for (int kk = 0; kk < cntU; kk += 2) {
             s_issue<USE_V, BIG>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
