@@ -52,6 +52,17 @@ __global__ __launch_bounds__(WG, 8) void k(const uint32_t *__restrict__ pse, con
                 x ^= (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, lane * 2, r * 128, 0);
             }
             a[b][5] = x; a[b][6] = 0; a[b][7] = 0;
+        } else if (MODE == 5) {                          // two records per lane: words as dwordx2 + dwordx2 + dword, dataset numbers as dword + dword + ushort (6 loads/unit)
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(pse + off), 0, RECS * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(px + off), 0, RECS * 2, 0x00020000);
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            const u2 v0 = __builtin_amdgcn_raw_buffer_load_b64(rsA, lane * 8, 0, 0);
+            const u2 v1 = __builtin_amdgcn_raw_buffer_load_b64(rsA, lane * 8, 512, 0);
+            a[b][4] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, 1024, 0);
+            a[b][5] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsX, lane * 4, 0, 0);
+            a[b][6] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsX, lane * 4, 256, 0);
+            a[b][7] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, lane * 2, 512, 0);
+            a[b][0] = v0.x; a[b][1] = v0.y; a[b][2] = v1.x; a[b][3] = v1.y;
         } else {                                         // MODE 2: one 32-byte block per lane: 2 x dwordx4
             const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(blk + (size_t)u * 512), 0, ((RECS + 4) / 5) * 32, 0x00020000);
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -80,12 +91,13 @@ int main()
     hipMalloc(&pse, nrec * 4); hipMalloc(&px, nrec * 2); hipMalloc(&blk, (size_t)UNITS * 2048 + 4096); hipMalloc(&out, 64);
     hipMemset(pse, 1, nrec * 4); hipMemset(px, 1, nrec * 2); hipMemset(blk, 1, (size_t)UNITS * 2048 + 4096);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const double bytes[5] = {UNITS * RECS * 6.0, UNITS * (RECS * 4.0 + ((RECS + 4) / 5) * 12.0), UNITS * ((RECS + 4) / 5) * 32.0, UNITS * RECS * 4.0, UNITS * RECS * 6.0};
-    const char *name[5] = {"slot-major 5 x dword + 5 x ushort (10 loads/unit)", "lane-major dwordx4 + dword + dwordx3 (3 loads/unit)",
+    const double bytes[6] = {UNITS * RECS * 6.0, UNITS * (RECS * 4.0 + ((RECS + 4) / 5) * 12.0), UNITS * ((RECS + 4) / 5) * 32.0, UNITS * RECS * 4.0, UNITS * RECS * 6.0, UNITS * RECS * 6.0};
+    const char *name[6] = {"slot-major 5 x dword + 5 x ushort (10 loads/unit)", "lane-major dwordx4 + dword + dwordx3 (3 loads/unit)",
                            "lane-major 32-B blocks, 2 x dwordx4 (2 loads/unit)", "slot-major 5 x dword only (5 loads/unit)",
-                           "slot-major, words and dataset numbers of a unit adjacent"};
+                           "slot-major, words and dataset numbers of a unit adjacent",
+                           "two records per lane: 2 x dwordx2 + dword, 2 x dword + ushort (6 loads/unit)"};
     for (int rep = 0; rep < 2; rep++)
-        for (int m = 0; m < 5; m++) {
+        for (int m = 0; m < 6; m++) {
             float best = 1e9f;
             for (int it = 0; it < 12; it++) {
                 hipEventRecord(e0);
@@ -93,7 +105,8 @@ int main()
                 else if (m == 1) k<1><<<512, WG>>>(pse, px, blk, UNITS, out);
                 else if (m == 2) k<2><<<512, WG>>>(pse, px, blk, UNITS, out);
                 else if (m == 3) k<3><<<512, WG>>>(pse, px, blk, UNITS, out);
-                else k<4><<<512, WG>>>(pse, px, blk, UNITS, out);
+                else if (m == 4) k<4><<<512, WG>>>(pse, px, blk, UNITS, out);
+                else k<5><<<512, WG>>>(pse, px, blk, UNITS, out);
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (it >= 2 && ms < best) best = ms;
