@@ -527,38 +527,52 @@ def extra_configs(db, dev, stream, args, box):
              ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30,
               "config4_slab0_of_8_v0"),
              ("config 4 as one of 4 GPUs sees it: slab 0 (1.25e7 queries) of 5e7 position-sorted queries",
-              synth.make_queries_slab(4 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, None),
+              synth.make_queries_slab(4 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, "config4_slab0_of_4_v0"),
              ("config 4 as one of 2 GPUs sees it: slab 0 (1.25e7 queries) of 2.5e7 position-sorted queries",
               synth.make_queries_slab(2 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, "config4_slab0_of_2_v0"),
              ("small batch: 10^3 position-sorted queries per step (latency of one pass)",
-              synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, None),
+              synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, "small_sorted_q1000_v0"),
              ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
-              0, 1, 200, None)]
+              0, 1, 200, "small_sorted_q100000_v0")]
     # stress shapes: queries piled up in one / ten tiles of the same database (the skew valves' work) ...
     rng = np.random.default_rng(5)
     for span in (1, 10):
         ps = np.sort((50000000 + rng.integers(0, 16384 * span, Q)).astype(np.int32))
         cases.append(("stress: 10^6 position-sorted queries inside %d tile%s of chr1 (skew valve)" % (span, "" if span == 1 else "s"),
-                      (np.zeros(Q, np.int32), ps, (ps + rng.integers(100, 2000, Q)).astype(np.int32)), 0, 1, 10, None))
+                      (np.zeros(Q, np.int32), ps, (ps + rng.integers(100, 2000, Q)).astype(np.int32)), 0, 1, 10,
+                      "piled_%s_q1000000_v0" % ("1tile" if span == 1 else "10tiles")))
     # ... queries of 6 .. 13 tiles each (difference arrays over the tiles they cover whole + an exact walk of the last tile) ...
     cases.append(("stress: 10^5 position-sorted queries of 100-200 kbp (6-13 tiles each: 2.4e8 overlaps per step)",
                   synth.make_queries(100000, seed=7, genome=synth.HG38, min_len=100000, max_len=200000, sorted_=True), 0, 1, 10,
                   "long_sorted_q100000_v0"))
     dbs = [db] * len(cases)
-    # ... and a clustered database (half of the intervals around 2000 hot spots: tiles of 10^3 .. 10^4 records, many chunks each)
-    cl = None
-    try:
-        from igd_amd import Database
-        clp = os.path.join(args.dir, "cl300x40000.igd")
-        if not os.path.exists(clp + ".done"):
-            synth.make_db(clp, files=300, per_file=40000, seed=77, genome=synth.HG38, clustered=True)
-            open(clp + ".done", "w").write("ok")
-        cl = Database(clp, device=dev.index or 0)
-        cases.append(("stress: clustered database (300 files x 40 000 intervals, half around 2000 hot spots: %d tile records) "
-                      "+ 10^6 position-sorted queries" % cl.nrecords, base, 0, 1, 30, None))
-        dbs.append(cl)
-    except Exception as e:
-        out.append({"workload": "stress: clustered database", "error": str(e)})
+    # ... a clustered database (half of the intervals around 2000 hot spots: tiles of 10^3 .. 10^4 records, many chunks each)
+    # and a sparse one (10^5 intervals: 59 % of the tiles are empty; queries of up to 40 kbp reach up to three tiles on, so
+    # rule NEST -- an empty first tile ends the query, src/igd_search.c:468 -- drops a third of what `-v 1`, rule FLAT, counts)
+    others = []
+    from igd_amd import Database
+    for tag, kw, rows in (("cl300x40000", dict(files=300, per_file=40000, seed=77, genome=synth.HG38, clustered=True),
+                           [("stress: clustered database (300 files x 40 000 intervals, half around 2000 hot spots: %d tile records) "
+                             "+ 10^6 position-sorted queries", base, 0, 1, 30, "clustered_q1000000_v0")]),
+                          ("sparse100x1000", dict(files=100, per_file=1000, seed=31, genome=synth.HG38),
+                           [("stress: sparse database (100 files x 1000 intervals: %d tile records, most tiles empty) + 10^6 position-sorted "
+                             "queries of 100-40 000 bp, rule NEST (quirk #1 at scale)", None, 0, 1, 30, "sparse_q1000000_v0"),
+                            ("stress: the same sparse database and queries under `-v 1` (rule FLAT: later tiles count behind an empty "
+                             "first tile; %d tile records)", None, 1, 1, 30, "sparse_q1000000_v1")])):
+        try:
+            op = os.path.join(args.dir, tag + ".igd")
+            if not os.path.exists(op + ".done"):
+                synth.make_db(op, **kw)
+                open(op + ".done", "w").write("ok")
+            odb = Database(op, device=dev.index or 0)
+            others.append(odb)
+            for (nm, qq, v_, gf, st_, gk) in rows:
+                if qq is None:
+                    qq = synth.make_queries(Q, seed=7, genome=synth.HG38, min_len=100, max_len=40000, sorted_=True)
+                cases.append((nm % odb.nrecords, qq, v_, gf, st_, gk))
+                dbs.append(odb)
+        except Exception as e:
+            out.append({"workload": "stress: database " + tag, "error": str(e)})
     for (name, (ichr, qs, qe), v, gflags, steps, gkey), db in zip(cases, dbs):
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags, args.query_layout)
@@ -576,13 +590,15 @@ def extra_configs(db, dev, stream, args, box):
                 ent["matches_oracle"] = (ent["hits_per_step"], ent["hits_checksum"]) == g
                 if not ent["matches_oracle"]:
                     ent["error"] = "per-file counts differ from the oracle's (tests/golden/bench_checksums.json[%s])" % gkey
+            elif gkey:
+                ent["matches_oracle"] = None                # (another database size than the fixture's: nothing to compare with)
             out.append(ent)
             del job
         except Exception as e:                              # a side measurement must not lose the line
             out.append({"workload": name, "error": str(e)})
     db = dbs[0]
-    if cl is not None:
-        cl.close()
+    for odb in others:
+        odb.close()
     # config 5: -f through the C API (count + scan + chunked fill + pinned D2H, result in host memory)
     try:
         ichr, qs, qe = base

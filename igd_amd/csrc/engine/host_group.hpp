@@ -83,7 +83,13 @@ extern "C" int igd_hip_group_create(igd_hip_db *const *dbs, int n, igd_hip_group
             snprintf(g->why, sizeof g->why, "ncclCommInitAll: %s", A->GetErrorString ? A->GetErrorString(e) : "failed");
             for (int r = 0; r < n; r++) g->comm[r] = nullptr;
         }
-    } else snprintf(g->why, sizeof g->why, "librccl could not be loaded: %s", dlerror() ? dlerror() : "?");
+    } else {
+        const char *de = dlerror();                          // (once: the call clears the error it returns)
+        snprintf(g->why, sizeof g->why, "librccl could not be loaded: %s", de ? de : "?");
+    }
+    // a multi-device job whose one exchange is NOT the RCCL all-reduce says so once, whether or not IGD_TIMING is set
+    if (!g->rccl && distinct && !(how && !strcmp(how, "host")))
+        fprintf(stderr, "igd: %d devices, but hits[] is summed on the host (%s)\n", n, g->why);
     if (!g->rccl && how && !strcmp(how, "rccl")) {           // the caller insists: no silent host add
         snprintf(g_err, sizeof g_err, "igd_hip_group_create: IGD_MULTI_REDUCE=rccl but %s", g->why);
         delete g;
@@ -122,11 +128,16 @@ extern "C" int igd_hip_group_search(igd_hip_group *g, const int32_t *ichr, const
         errs[r][0] = 0;
         if (rcs[r] != IGD_HIP_OK) snprintf(errs[r], sizeof errs[r], "%s", g_err);      // thread-local text
     };
-    for (int r = 1; r < n; r++) th[r] = std::thread(work, r);
+    bool threaded[IGD_GROUP_MAX] = {false};
+    for (int r = 1; r < n; r++) {
+        try { th[r] = std::thread(work, r); threaded[r] = true; }
+        catch (...) { threaded[r] = false; }                 // (no thread to be had: the slab runs on this one -- nothing is thrown across the C boundary)
+    }
     work(0);
+    for (int r = 1; r < n; r++) if (!threaded[r]) work(r);
     int rc = IGD_HIP_OK;
     for (int r = 0; r < n; r++) {
-        if (r > 0) th[r].join();
+        if (r > 0 && threaded[r]) th[r].join();
         if (rcs[r] != IGD_HIP_OK && rc == IGD_HIP_OK) { rc = rcs[r]; snprintf(g_err, sizeof g_err, "%s", errs[r]); }
     }
     if (rc != IGD_HIP_OK) return rc;
@@ -152,6 +163,9 @@ extern "C" int igd_hip_group_search(igd_hip_group *g, const int32_t *ichr, const
         for (int r = 0; r < n; r++) {
             int64_t t1 = 0;
             HIPCHK(hipSetDevice(g->db[r]->device));
+            // (the engine streams do not wait for the null stream's copies: an EMPTY slab has only enqueued the clearing of
+            // its d_hits -- without this the previous search's counts could be read and added again)
+            HIPCHK(hipStreamSynchronize(g->db[r]->stream));
             HIPCHK(hipMemcpy(h.data(), g->db[r]->d_hits, (size_t)nf * 8, hipMemcpyDeviceToHost));
             HIPCHK(hipMemcpy(&t1, g->db[r]->d_total, 8, hipMemcpyDeviceToHost));
             for (int32_t f = 0; f < nf; f++) hits[f] += h[f];

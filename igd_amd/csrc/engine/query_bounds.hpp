@@ -238,6 +238,20 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     __shared__ int32_t sCovW[NW * QB_COVW];               // per wave: coverage differences of its long queries (see step 3; cleared by the wave that uses it)
     __shared__ int32_t sRun[RUNS ? 2 * QB_CTG : 1];       // runStart[0..nCtg], padded with INT_MAX to a power of two
     __shared__ int sK[2];                                 // RUNS: contig of the batch's first and last query
+    // What every batch owes the NEXT one and its caller -- hits[] cleared (IGD_HIP_FLAG_ZERO_FIRST), the other parity's list
+    // counters at zero -- is done before any way out of the kernel (a malformed run table below leaves at once: the batch
+    // after it would have appended to the stale fix list of two batches ago).
+    const int t = blockIdx.x * WGT + threadIdx.x;
+    if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * WGT) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
+    if (zeroTotal && t == 0) *zeroTotal = 0;
+    if (t == 0) {                                           // next batch's list counters
+        ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
+        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
+    }
     int runLevels = 0;
     if (RUNS) {
         int badRuns = 0;
@@ -293,17 +307,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
 #define QB_BASE(c) (FAST ? sBase[c] : (ldsTab ? sBase[c] : db.ctgBase[c]))
 #define QB_NTILE(c) (FAST ? sNTile[c] : (ldsTab ? sNTile[c] : db.ctgNTile[c]))
 #define QB_TILE(x) (FAST ? tile_shift(x, db.shift) : tile_of(db, x))
-    const int t = blockIdx.x * WGT + threadIdx.x;
-    if (zeroHits) for (int f = t; f < db.nFiles; f += gridDim.x * WGT) zeroHits[f] = 0;   // IGD_HIP_FLAG_ZERO_FIRST
-    if (zeroTotal && t == 0) *zeroTotal = 0;
-    if (t == 0) {                                           // next batch's list counters
-        ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
-    }
     const int lane = threadIdx.x & 63;
     // Once any wave has found the batch unordered nothing this kernel produces is going to be read
     // (the merge join is off, the bucket path keeps its own lists): later workgroups stop here (an unordered batch

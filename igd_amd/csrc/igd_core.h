@@ -99,7 +99,7 @@ int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32
 /* SMALL query files on the host (igd_hostpath.c; product code).  The reference starts cheaply -- header only, then the
  * tiles a query touches (src/igd_base.c:269-323, src/igd_search.c:469-476) -- while the engine costs a fixed ~0.18 s of HIP
  * start-up and upload: files of at most igdc_host_limit() queries (IGD_HOST_MAX_QUERIES; 0 = every file goes to the GPU) are
- * counted from a read-only mapping of the .igd by a few host threads, the reference's per-query algorithm.  NOT a
+ * counted with pread() on the .igd (per-thread tile buffers) by a few host threads, the reference's per-query algorithm.  NOT a
  * fallback: the choice depends on the number of queries only, never on whether a device is usable; larger files have
  * no CPU path.  The engine's own entry points (igd_hip.h) never come here. */
 typedef struct igdc_map igdc_map;

@@ -8,15 +8,17 @@
  * files of at most igdc_host_limit() queries here, like the single-interval entry points already do
  * (igdc_walk_one, igd_core.c), and take the engine for everything larger.
  *
- * What this is NOT: a fallback.  The choice depends on the number of queries alone, never on whether a GPU is
- * present; a file above the limit has no CPU path and fails loudly without a usable device (tests/test_host.py),
+ * What this is NOT: a fallback.  The choice depends on the number of queries and the host's thread count
+ * (igdc_host_limit: the same file can take different paths on different hosts, with identical output), never on whether
+ * a GPU is present; a file above the limit has no CPU path and fails loudly without a usable device (tests/test_host.py),
  * IGD_HOST_MAX_QUERIES=0 sends every file to the engine (all `-m gpu` parity tests run that way), and the engine's
  * own entry points (include/igd_hip.h, igd_amd.Database, bench.py) never come here.
  *
  * Algorithm = the reference's per query (src/igd_search.c:454-534 rule NEST, :623-694 rule FLAT): in every visited
  * tile bisect the start-sorted records for the last one with start < qe (:479-487 / bSearch src/igd_base.c:74-94),
  * walk back from there testing end > qs [&& value >= v] (:489-493), in later tiles stop at the first record that
- * starts before the tile (:510-511).  Tiles are read from a read-only mapping of the .igd (page cache; no copy), the
+ * starts before the tile (:510-511).  Tiles are read with pread() into per-thread buffers (igdc_map holds the file
+ * descriptor only; the page cache serves repeats), the
  * queries are split into contiguous ranges over a few threads with private hits[] that are added up at the end
  * (hits[] is a sum over queries).
  */

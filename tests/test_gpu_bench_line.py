@@ -38,9 +38,11 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 13 and not any("error" in e for e in x), x
+        assert len(x) == 15 and not any("error" in e for e in x), x
         assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
-        assert sum(e["workload"].startswith("stress:") for e in x) == 4
+        assert sum(e["workload"].startswith("stress:") for e in x) == 6
+        # every row but `-f` carries the comparison with the oracle's fixture (None here: not the fixture's database size)
+        assert all("matches_oracle" in e for e in x[:-1]), [e["workload"] for e in x[:-1] if "matches_oracle" not in e]
         assert r["cold"]["kernel_ms"] > 0 and 0 < r["cold"]["frac"] <= 1.0
         # what the fraction is a fraction of, and the like-for-like anchors of the weak-scaling curve
         assert r["frac_of"] and r["step_frac"] > 0 and r["step_frac"] <= r["frac"] and "frac_pmc" in r
@@ -190,5 +192,56 @@ def test_bench_fails_fast_when_a_rank_dies():
         assert p.returncode != 0 and time.time() - t < 120
         assert b"rank 1 failed" in p.stderr, p.stderr.decode()[-800:]
         assert not [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def _expected_whole(d, files, per_file, n_total):
+    """hits of the whole position-sorted set of n_total queries through Database.search on one GPU"""
+    import numpy as np
+    from igd_amd import Database, synth
+    db = Database(os.path.join(d, "rm%dx%d.igd" % (files, per_file)))
+    ichr, qs, qe = synth.make_queries(n_total, seed=7, genome=synth.HG38, sorted_=True)
+    hits, total = db.search(ichr, qs, qe)
+    db.close()
+    w = (hits.astype(np.uint64) * (np.arange(len(hits), dtype=np.uint64) + np.uint64(1))).sum() & np.uint64((1 << 63) - 1)
+    return int(total), int(w)
+
+
+def test_bench_eight_ranks_control_flow_on_one_gpu():
+    """Ready for the 8-GPU node: `bench.py --gpus 8` exactly as the driver starts it (torch.distributed.run,
+    8 ranks) -- slab bounds of ONE sorted set, barriers, the all-reduce, the MAX of the elapsed times, rank 0's anchor run --
+    with the 8 ranks sharing GPU 0 and the collective over gloo (the box has one GPU; with 8 GPUs the same code takes
+    LOCAL_RANK and RCCL).  The all-reduced hits[] equals the unsharded search, the line names 8 ranks, carries the
+    like-for-like anchor, its efficiency and the predicted per-rank step, and the whole job ends in minutes."""
+    import time
+    d = short_tmpdir("igb")
+    try:
+        files, per_file, q = 40, 3000, 6000
+        env = dict(os.environ, IGD_BENCH_ONE_GPU="1", IGD_DIST_BACKEND="gloo")
+        env.pop("WORLD_SIZE", None)
+        env.pop("RANK", None)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+               "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 250),
+               os.path.join(ROOT, "bench.py"), "--gpus", "8", "--files", str(files), "--per-file", str(per_file),
+               "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d]
+        t = time.time()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
+        wall = time.time() - t
+        assert p.returncode == 0, p.stderr.decode()[-1500:]
+        lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, p.stdout.decode()[-800:]
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 8 and j["n_ranks_seen"] == 8 and len(j["devices"]) == 8 and j["scaling"] == "weak"
+        assert all(("rank %d:" % r) in j["devices"][r] for r in range(8))
+        assert j["config"]["queries_per_gpu"] == q and j["config"]["queries_per_step_all_gpus"] == 8 * q
+        assert "config 4" in j["config"]["workload"] and "all-reduce" in j["config"]["collective"]
+        assert abs(j["value"] - 8 * q * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6
+        assert j["scale_anchor"]["value"] > 0 and j["efficiency_vs_anchor"] > 0
+        pr = j["scale_prediction"]                              # what a future SCALE file can be checked against
+        assert set(pr["step_ms"]) == {"1", "2", "4", "8"} and pr["source"]
+        total, chk = _expected_whole(d, files, per_file, 8 * q)
+        assert j["hits_per_step_total"] == total and j["hits_checksum"] == chk
+        assert wall < 600, wall
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -161,3 +161,38 @@ def test_a_run_table_that_is_not_one_is_a_broken_promise(workdir):
         np.testing.assert_array_equal(again, want)
     finally:
         db.close(); orc.close()
+
+
+def test_the_batch_right_after_a_bad_run_table_counts_exactly(workdir):
+    """a malformed run table made every workgroup of k_query_bounds leave before the next batch's list counters
+    were reset, so the batch after it appended to the stale exact-walk list of two batches ago.  Good batch WITH long
+    queries (a non-empty list), ONE bad table, then at once a smaller good batch with long queries -- against the oracle."""
+    import torch
+    from igd_amd import Database, synth
+    from igd_amd.database import IgdError
+    path = os.path.join(workdir, "b2.igd")
+    synth.make_db(path, files=10, per_file=8000, seed=6, nbp_log=12, genome=synth.HG38)
+    db, orc = Database(path), Oracle(path)
+    try:
+        nctg = db.nctg
+        big = _queries(synth, 200000, 21, synth.HG38, min_len=1, max_len=60000)       # up to 15 tiles long: walks + coverage
+        small = _queries(synth, 70000, 22, synth.HG38, min_len=1, max_len=60000)
+        for rounds in range(2):                                                        # both batch parities meet the bad table
+            for first, second in ((big, small), (small, big)):
+                runs1 = Database.contig_runs(first[0], nctg)
+                got, gtot = _run(db, torch, runs1, first[1], first[2])
+                want, wtot = orc.search(*first, 0)
+                assert gtot == wtot
+                np.testing.assert_array_equal(got, want)
+                bad = runs1.copy(); bad[3], bad[4] = bad[4] + 7, bad[3]
+                with pytest.raises(IgdError):
+                    _run(db, torch, bad, first[1], first[2])
+                runs2 = Database.contig_runs(second[0], nctg)
+                got, gtot = _run(db, torch, runs2, second[1], second[2])
+                want, wtot = orc.search(*second, 0)
+                assert gtot == wtot, "the batch after a bad run table"
+                np.testing.assert_array_equal(got, want)
+            # an odd number of batches in between flips the parity the bad table meets
+            _run(db, torch, Database.contig_runs(small[0], nctg), small[1], small[2])
+    finally:
+        db.close(); orc.close()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/pmc_cmd.sh <out tag> <kernel name substring> <python script> [args] -- GPU box: counters of one kernel of any python command,
-# one rocprofv3 --pmc pass per group (never combined with other trace domains)
+# one rocprofv3 --pmc pass per group (with --kernel-trace only -- the kernel names; never with the sys / runtime / hip / hsa / memory-copy trace domains)
 tag0=$1; pat=$2; shift 2
 root=$PWD; out=$root/gpurun_out/$tag0; rm -rf $out; mkdir -p $out
 python tools/prep.py > /dev/null 2>&1
