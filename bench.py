@@ -71,6 +71,7 @@ def parse_args(argv=None):
                     help="N=1 only: this GPU's step is slab 0 of a G-GPU config-4 job (G x --queries position-sorted queries) -- "
                          "what one of G GPUs would run, measured without the other G-1")
     ap.add_argument("--exact-arrays", action="store_true", help="read the 12-byte exact arrays, not the compact image")
+    ap.add_argument("--long-queries", action="store_true", help="do not pass IGD_HIP_FLAG_SHORT (A/B: dense sorted batches then take the ordinary step, with k_query_bounds)")
     ap.add_argument("--query-layout", choices=["runs", "ichr"], default="ichr",
                     help="how a position-sorted batch under the order promise is resident: one contig number per query (12 B/query, the "
                          "default) or contig runs + starts + ends (8 B/query, igd_hip_search_runs_dev: measured no faster -- the grouping "
@@ -517,19 +518,22 @@ def extra_configs(db, dev, stream, args, box):
     from igd_amd import synth
     out = []
     Q = 1000000
+    # config 4's batches go in under BOTH verified promises -- position-sorted (1) and no query longer than a tile (16: the
+    # generator's queries are 100 .. 1999 bp) -- and, being dense, take the engine's DIRECT step (no per-query pre-pass)
+    SHORT = 1 | 16
     base = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=True)
     shuf = synth.make_queries(Q, seed=7, genome=synth.HG38, sorted_=False)
     dense = synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     slab8 = synth.make_queries_slab(8 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100, "config2_sorted_q1000000_v500"),
              ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100, "config2_sorted_q1000000_v0"),
-             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, 1, 30, "config4_share_q12500000_v0"),
-             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, 1, 30,
+             ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, SHORT, 30, "config4_share_q12500000_v0"),
+             ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, SHORT, 30,
               "config4_slab0_of_8_v0"),
              ("config 4 as one of 4 GPUs sees it: slab 0 (1.25e7 queries) of 5e7 position-sorted queries",
-              synth.make_queries_slab(4 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, "config4_slab0_of_4_v0"),
+              synth.make_queries_slab(4 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, SHORT, 30, "config4_slab0_of_4_v0"),
              ("config 4 as one of 2 GPUs sees it: slab 0 (1.25e7 queries) of 2.5e7 position-sorted queries",
-              synth.make_queries_slab(2 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, 1, 30, "config4_slab0_of_2_v0"),
+              synth.make_queries_slab(2 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38), 0, SHORT, 30, "config4_slab0_of_2_v0"),
              ("small batch: 10^3 position-sorted queries per step (latency of one pass)",
               synth.make_queries(1000, seed=7, genome=synth.HG38, sorted_=True), 0, 1, 200, "small_sorted_q1000_v0"),
              ("small batch: 10^5 position-sorted queries per step", synth.make_queries(100000, seed=7, genome=synth.HG38, sorted_=True),
@@ -581,7 +585,7 @@ def extra_configs(db, dev, stream, args, box):
             hj = job.d_hits.cpu().numpy()
             assert (hj % steps == 0).all(), "hits[] is not K times one batch"
             ent = {"workload": name, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
-                   "ms_per_step": 1e3 * el / steps, "kernel_ms": prof["scan_ms"], "pipeline_ms": prof["pipeline_ms"],
+                   "ms_per_step": 1e3 * el / steps, "kernel": rl["kernel"], "kernel_ms": prof["scan_ms"], "pipeline_ms": prof["pipeline_ms"],
                    "roofline_frac": rl["frac"],
                    "bytes_per_launch": rl["bytes_per_launch"], "algorithmic_frac": rl["algorithmic_frac"],
                    "hits_per_step": int(hj.sum()) // steps, "hits_checksum": hits_checksum(hj // steps)}
@@ -711,6 +715,8 @@ def main():
     if args.grouping == "default":
         args.grouping = "auto" if args.shuffled else "sorted"
     gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
+    if args.grouping == "sorted" and not args.long_queries:
+        gflags |= 16                                # IGD_HIP_FLAG_SHORT: the generator's queries are 100 .. 1999 bp (verified on the device like the order)
 
     # A job = K batches (steps) whose per-file counts ACCUMULATE in hits[] -- the reference's hits[] is
     # one accumulator over the whole query file (src/igd_search.c:925,1032-1039) and the engine adds --
@@ -841,6 +847,15 @@ def main():
             # step), another workload, so a ratio of the two lines' `value` says nothing about scaling
             line["scale_anchor"] = anchor
             line["efficiency_vs_anchor"] = value / (world * anchor["value"]) if anchor.get("value") else None
+            # what one GPU measured for a rank's step of an N-GPU job (slab 0 of N, committed with its source): the curve a
+            # measured SCALE file can be checked against -- a rank's step gets SHORTER as N grows (fewer tiles per slab)
+            try:
+                line["scale_prediction"] = json.load(open(os.path.join(ROOT, "profiles", "scale_prediction.json")))
+                pm = line["scale_prediction"]["step_ms"].get(str(world))
+                if pm and Q == CONFIG4_PER_GPU:
+                    line["scale_prediction"]["this_run_vs_predicted_step"] = (1e3 * elapsed / args.steps) / pm
+            except Exception as e:
+                line["scale_prediction"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     del job
     db.close()

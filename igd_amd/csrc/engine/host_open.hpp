@@ -73,7 +73,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     (void)hipSetDevice(db->device);
     if (db->d_rEmpty) (void)hipFree(db->d_rEmpty);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
-                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far, db->d_tileD,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
@@ -142,6 +142,7 @@ extern "C" const char *igd_hip_last_scan_kernel(igd_hip_db *db)
     if (db && db->inner) return igd_hip_last_scan_kernel(db->inner);
     if (!db || db->epoch == 0) return "";
     if (db->lastMode == 2) return "igd_scan_tiles";
+    if (db->lastDirect) return "igd_scan_direct";
     int32_t uns = 0;
     if (hipSetDevice(db->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(&uns, db->d_ctl + CTL_UNSORTED, 4, hipMemcpyDeviceToHost) != hipSuccess) return "";
@@ -267,6 +268,8 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         const char *fb = getenv("IGD_HIP_BIG");
         db->bigImage = fb && *fb == '1';                 // (|| the record count, once it is known)
         db->qbVec1 = getenv("IGD_HIP_QB_VEC1") != nullptr;
+        const char *fd = getenv("IGD_HIP_DIRECT");
+        db->forceDirect = fd && *fd ? atoi(fd) : -1;
         db->timing = tim;
     }
     db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
@@ -371,6 +374,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                 for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
             }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
+            db->ldsDirect = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
@@ -383,7 +387,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->grid = cus * perCU;
         const size_t slabB = db->ldsHits ? (size_t)db->grid * (size_t)(db->winN > 0 ? db->winN : 1) * 8 : 0;
         const bool willPack = d->nbp <= 32768 && d->nFiles <= 65536 && n > 0;
-        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 112 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
+        size_t total = 16 * n + (willPack ? 10 * (n + IGD_CHUNK) : 0) + 128 * ((size_t)nT + 2) + (sizeof(Unit) + 4) * (units.size() + 1) + 4 * (IGD_HEAVY_MAX + IGD_HEAVYS_MAX) +
                        slabB + 8 * ((size_t)d->nFiles + 8) + 64 * 1024;
         db->arena = nullptr;
         if (hipMalloc((void **)&db->arena, total) == hipSuccess) { db->arenaSize = total; db->arenaUsed = 0; }
@@ -404,6 +408,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_heavy, IGD_HEAVY_MAX + IGD_HEAVYS_MAX, acct));   // bucket path's list, merge join's list
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_far, units.size() + 1, acct));
+    TRY(dalloc(&db->d_tileD, (size_t)nT + 1, acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -557,6 +562,10 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             for (const void *fn : wfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsSorted));
         }
     }
+    if (db->ldsDirect > 64 * 1024) {
+        const void *dfn[] = {(const void *)igd_scan_direct<false>, (const void *)igd_scan_direct<true>};
+        for (const void *fn : dfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsDirect));
+    }
     {   // the batch's last launch: its workgroups of 16 waves carry 16 rank-method areas (the skew valves) and the 64-bit counters
         // of the long queries' work (up to 48 KiB): beyond the 64 KiB a kernel gets without asking
         const void *tfn[] = {(const void *)k_reduce_slabs<false>, (const void *)k_reduce_slabs<true>};
@@ -608,6 +617,15 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->packedV = db->gType == 1 && !(fl & 1);
         if (fl & 2) db->packed = false;          // a record outside its tile: exact arrays only
         v.pse = db->d_pse; v.px = db->d_px; v.pxv = db->d_pxv;
+        // the DIRECT step's per-tile table (scan_direct.hpp): power-of-two tiles of at most 2^14 bp (two tile widths fit 16 bits),
+        // record numbers that fit 32 bits, contig tables that fit its LDS arrays
+        v.tileD = nullptr;
+        bool everyCtgHasTiles = true;                    // (a contig without tiles would lend its queries to a neighbour's range)
+        for (int c = 0; c < d->nCtg; c++) everyCtgHasTiles = everyCtgHasTiles && d->nTile[c] > 0;
+        if (db->packed && v.shift >= 0 && v.shift <= 14 && db->nCtg <= QB_CTG && !db->bigImage && (int64_t)n + IGD_CHUNK < (1ll << 30) && db->nT > 0 && everyCtgHasTiles) {
+            k_tile_desc<<<(db->nT + 255) / 256, 256, 0, db->stream>>>(v, db->d_tileD);
+            if (hipStreamSynchronize(db->stream) == hipSuccess && hipGetLastError() == hipSuccess) v.tileD = db->d_tileD;
+        }
     }
     OPEN_PHASE("compact image");
     t_arenaOwner = nullptr;

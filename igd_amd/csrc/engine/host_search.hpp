@@ -127,11 +127,11 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
 // pair to the launch itself: hipExtLaunchKernel stamps them with the dispatch's own start and end -- the figures a profiler
 // reads (rocprofv3 --kernel-trace) -- where two hipEventRecord packets around the kernel also time the two packet gaps
 // (3-6 % of a 70 us kernel) and put two more packets between the step's kernels.
-template <typename F>
-static void launch_sorted(igd_hip_db *db, F kernel, int grid, int block, size_t lds, hipStream_t st, const SortK &K)
+template <typename F, typename KA>
+static void launch_sorted(igd_hip_db *db, F kernel, int grid, int block, size_t lds, hipStream_t st, const KA &K)
 {
     if (db->evStart) {
-        SortK k = K;
+        KA k = K;
         void *args[] = {&k};
         (void)hipExtLaunchKernel((const void *)kernel, dim3(grid), dim3(block), args, lds, st, db->evStart, db->evStop, 0);
         db->evStart = db->evStop = nullptr;              // (one kernel per pair)
@@ -284,6 +284,11 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     // IGD_HIP_FLAG_ZERO_FIRST: the first kernel of the batch clears hits[] (and total)
     u64 *zh = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_hits : nullptr;
     u64 *zt = (flags & IGD_HIP_FLAG_ZERO_FIRST) ? (u64 *)d_total : nullptr;
+    // The DIRECT step (scan_direct.hpp): a batch promised sorted AND short that is dense on average -- no per-query pre-pass,
+    // the scan kernel reads q_qs / q_qe itself.  (IGD_HIP_DIRECT=1 at open: every promised-sorted batch that can -- tests.)
+    const bool direct = mode == 1 && packed && db->ldsHits && db->nWin == 1 && db->v.tileD != nullptr && db->v.vshift < 0 && db->v.shift >= 0 && db->nCtg <= QB_CTG &&
+                        (db->forceDirect > 0 || (db->forceDirect < 0 && (flags & IGD_HIP_FLAG_SHORT) && nq >= 28ll * db->nT));
+    db->lastDirect = direct ? 1 : 0;
     if (mode != 2) {
         bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
         if (db->qbVec1) vec = false;                  // A/B (IGD_HIP_QB_VEC1, read at open)
@@ -312,7 +317,15 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
         const bool wide = vec && nq >= ((int64_t)1 << 22);
 #define QB_GRID(PER_) ((int)((nq + (PER_) - 1) / (PER_)) > fillBlocks ? (int)((nq + (PER_) - 1) / (PER_)) : fillBlocks)
 #define QB_LAUNCH(VEC_, FAST_, WGT_)                                                                                                  \
-    if (runsK && VEC_ == 4 && FAST_)                                                                                                  \
+    if (direct && FAST_ && runsK && VEC_ == 4)          /* the DIRECT step: the bounds alone (BONLY) */                               \
+        k_query_bounds<4, true, WGT_, true, true><<<QB_GRID(WGT_ * 4), WGT_, 0, st>>>(db->v, d_runs, d_qs, d_qe, (int)nq, krule,      \
+        1, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,                      \
+        (int2 *)db->d_laterHdr, 1);                                                                                                  \
+    else if (direct && FAST_)                                                                                                        \
+        k_query_bounds<VEC_, true, WGT_, false, true><<<QB_GRID(WGT_ * VEC_), WGT_, 0, st>>>(db->v, d_ichr, d_qs, d_qe, (int)nq, krule, \
+        1, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,                      \
+        (int2 *)db->d_laterHdr, 1);                                                                                                  \
+    else if (runsK && VEC_ == 4 && FAST_)                                                                                             \
         k_query_bounds<4, true, WGT_, true><<<QB_GRID(WGT_ * 4), WGT_, 0, st>>>(db->v, d_runs, d_qs, d_qe, (int)nq, krule,            \
         packed ? 1 : 0, db->d_firstQ, db->d_lpos, db->d_fix, db->d_ctl, db->epoch, zh, zt, db->d_qw, db->d_later, db->d_spill,         \
         (int2 *)db->d_laterHdr, mode == 1 ? 1 : 0);                                                                                  \
@@ -350,10 +363,11 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     a.packedWalk = packed ? (useV ? 2 : 1) : 0;
     // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
-    const int valves = (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
+    const int valves = direct ? 8 : (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
                        (db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
     // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
-    size_t tailLds = (valves & 2) ? (size_t)(db->ldsHits ? IGD_TAIL_WG / IGD_WAVE : 4) * (size_t)IGD_WLDS_BYTES : 0;   // (k_exact_walk: workgroups of 4 waves)
+    const size_t tailWave = direct ? (size_t)IGD_D_WLDS : (size_t)IGD_WLDS_BYTES;                    // a wave's rank-method area in the last launch
+    size_t tailLds = (valves & (2 | 8)) ? (size_t)(db->ldsHits ? IGD_TAIL_WG / IGD_WAVE : 4) * tailWave : 0;   // (k_exact_walk: workgroups of 4 waves)
     int tailHistOff = -1;                                // u64 counters for the exact walks and the coverage, when the files fit
     if ((size_t)db->nFiles * 8 <= (size_t)48 * 1024) { tailHistOff = (int)tailLds; tailLds += (size_t)db->nFiles * 8; }
     if (db->ldsHits) {
@@ -364,6 +378,16 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
             const bool last = win == db->nWin - 1;
             const int fileLo = win * db->winN, fileN = db->nWin == 1 ? db->nFiles : (db->nFiles - fileLo < db->winN ? db->nFiles - fileLo : db->winN);
             if (extEv) { db->evStart = db->ev[4 * slot + 1]; db->evStop = db->ev[4 * slot + 2]; }
+            if (direct) {
+                DirK D;
+                D.db = db->v;
+                D.a.firstQ = db->d_firstQ; D.a.tileD = db->v.tileD; D.a.q_qs = d_qs; D.a.q_qe = d_qe; D.a.ctl = db->d_ctl; D.a.fix = db->d_fix;
+                D.a.heavyS = db->d_heavy + IGD_HEAVY_MAX; D.a.farList = db->d_far; D.a.nq = (int)nq; D.a.v = v; D.a.epoch = db->epoch;
+                D.a.rule = rule; D.a.promised = 1; D.a.sbCap = db->sbCap; D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap;
+                D.a.out = db->d_slab; D.a.hitsOut = (u64 *)d_hits; D.a.totalOut = (u64 *)d_total;
+                if (useV) launch_sorted(db, igd_scan_direct<true>, db->grid, IGD_WG_RANK, (size_t)db->ldsDirect, st, D);
+                else launch_sorted(db, igd_scan_direct<false>, db->grid, IGD_WG_RANK, (size_t)db->ldsDirect, st, D);
+            } else
             launch_scan_any<true>(db, a, useV, packed, st, db->nWin > 1 ? win : -1);
             if (extEv && db->evStart) {                  // (no merge-join launch took the pair: cannot happen for this kind of batch)
                 db->evStart = db->evStop = nullptr;
@@ -374,7 +398,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
             ScanArgs w = a;
             w.out = (u64 *)d_hits;
             SortK Kt = K;
-            Kt.a.sbCap = 0; Kt.a.wldsBytes = IGD_WLDS_BYTES; Kt.a.tailHistOff = tailHistOff;
+            Kt.a.sbCap = 0; Kt.a.wldsBytes = (int)tailWave; Kt.a.tailHistOff = tailHistOff;
             // IGD_REDUCE_GROUPS row groups sum the slab; the launch is filled up to IGD_TAIL_WGS workgroups (8 waves per SIMD),
             // which find out from the batch's control words that the tail has nothing for them -- or share a long
             // exact-walk list and the coverage of long queries, whose loops are chains of dependent loads

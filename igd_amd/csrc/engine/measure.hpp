@@ -40,6 +40,30 @@ __global__ void k_unit_traffic(DbView db, const int32_t *__restrict__ firstQ, co
     }
 }
 
+// ... of igd_scan_direct: a visited unit's records, the records of the next tile that ride with a tile's first unit, and the
+// tile's queries once per unit of the tile (8 bytes each: q_qs, q_qe)
+__global__ void k_unit_traffic_direct(DbView db, const int32_t *__restrict__ firstQ, int rule, u64 *__restrict__ acc /* units, records, -, queries read */)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    u64 nu = 0, nr = 0, nd = 0;
+    if (u < db.nUnits) {
+        const Unit un = db.units[u];
+        const int c0 = firstQ[un.tile + 1] - firstQ[un.tile];
+        const bool first = UNIT_FLAGS(un) & 1;
+        if (c0 > 0 && c0 <= IGD_HEAVY_FIRST && (un.n > 0 || first)) {
+            nd = (u64)c0;                                 // (a placeholder still reads -- checks -- its queries)
+            const bool dead = rule == IGD_HIP_RULE_NEST && un.n == 0;
+            if (un.n > 0 || !dead) { nu = 1; nr = (u64)un.n + (first && !dead ? (u64)(db.tileD[un.tile].y & 127) : 0); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { nu += __shfl_down(nu, o); nr += __shfl_down(nr, o); nd += __shfl_down(nd, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (nu) atomicAdd(&acc[0], nu);
+        if (nr) atomicAdd(&acc[1], nr);
+        if (nd) atomicAdd(&acc[3], nd);
+    }
+}
+
 extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_qs, const int32_t *d_qe,
                                      int64_t nq, int32_t v, int rule, int flags, igd_hip_traffic *out)
 {
@@ -75,6 +99,9 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         const bool useV = (v != IGD_HIP_NO_VALUE_FILTER && db->gType == 1);
         const bool packed = db->packed && !(flags & IGD_HIP_FLAG_EXACT) && (!useV || db->packedV);
         const int path = !sortedPath ? 0 : packed ? 2 : 1;
+        const bool direct = db->lastDirect != 0 && sortedPath;
+        if (direct) k_unit_traffic_direct<<<(db->nUnits + 255) / 256, 256, 0, st>>>(db->v, db->d_firstQ, rule, d_acc);
+        else
         k_unit_traffic<<<(db->nUnits + 255) / 256, 256, 0, st>>>(db->v, db->d_firstQ, db->d_pairN, db->d_spill, db->epoch, path,
                                                                ctl[CTL_NOTSTART] != db->epoch ? 1 : 0, d_acc);
         u64 acc[4] = {0, 0, 0, 0};
@@ -85,17 +112,18 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         out->records = (int64_t)acc[1];
         out->record_bytes = (int64_t)acc[1] * recB;
         out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (path == 2 ? 8ll * (db->nT + 1) : sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
+        if (direct) out->unit_bytes = (int64_t)(sizeof(Unit) + 8 + 16) * db->nUnits;      // per unit: its descriptor, two entries of firstQ[], its tile's int4 of tileD[]
         // merge join, compact image: one 4-byte word per query (qw0), the compacted later-tile words (later[]: every entry is
         // read at least once), the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe;
         // bucket path: 8 B per pair
         int64_t nLaterWords = 0;
-        if (path == 2) {
+        if (path == 2 && !direct) {
             const int64_t nb = (nq + ((int64_t)1 << db->lbShift) - 1) >> db->lbShift;
             std::vector<int32_t> hdr((size_t)nb * 2);
             e = hipMemcpy(hdr.data(), db->d_laterHdr, (size_t)nb * 8, hipMemcpyDeviceToHost);
             for (int64_t b = 0; b < nb; b++) nLaterWords += hdr[(size_t)b * 2];
         }
-        out->query_bytes = path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
+        out->query_bytes = direct ? 8ll * (int64_t)acc[3] : path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
                          : path == 1 ? 12ll * nq : 8ll * (int64_t)acc[2];
         out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * (path == 2 ? 4 : 8) : 8ll * db->nFiles;   // (merge join: 32-bit rows)
         out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;

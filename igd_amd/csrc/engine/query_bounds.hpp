@@ -182,7 +182,11 @@ __device__ __forceinline__ void cover_tiles(const DbView &db, int32_t *__restric
 // 12 bytes per query are not read (igd_hip_search_runs_dev).  The table is staged in LDS and checked (a table that is not
 // monotone or does not cover [0, nq) is a broken order promise); a wave finds its contig with one bisection and is on the
 // short path unless it straddles a run boundary.
-template <int VEC, bool FAST, int WGT, bool RUNS = false>
+// BONLY: the bounds alone -- firstQ[] and the order check -- for the DIRECT step (scan_direct.hpp), whose scan kernel reads the
+// queries itself: no ends are read, no word is computed or stored, nothing is listed.  Its keys keep the queries of contig
+// numbers outside the database OUT of every tile's range (-1: before tile 0, nT: behind the last tile), where the ordinary
+// step clamps them into the first / last tile and masks their words.
+template <int VEC, bool FAST, int WGT, bool RUNS = false, bool BONLY = false>
 __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_bounds(DbView db, const int32_t *__restrict__ ichr,
                                                       const int32_t *__restrict__ qs,
                                                       const int32_t *__restrict__ qe, int nq, int rule,
@@ -204,16 +208,17 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         int4 c4 = make_int4(0, 0, 0, 0), s4 = c4, e4 = c4;
         if (i0 + 3 < nq) {
             if (!RUNS) c4 = *(const int4 *)(ichr + i0);
-            s4 = *(const int4 *)(qs + i0); e4 = *(const int4 *)(qe + i0);
+            s4 = *(const int4 *)(qs + i0);
+            if (!BONLY) e4 = *(const int4 *)(qe + i0);
         } else {
-            if (i0 < nq) { if (!RUNS) c4.x = ichr[i0]; s4.x = qs[i0]; e4.x = qe[i0]; }
-            if (i0 + 1 < nq) { if (!RUNS) c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; e4.y = qe[i0 + 1]; }
-            if (i0 + 2 < nq) { if (!RUNS) c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; e4.z = qe[i0 + 2]; }
+            if (i0 < nq) { if (!RUNS) c4.x = ichr[i0]; s4.x = qs[i0]; if (!BONLY) e4.x = qe[i0]; }
+            if (i0 + 1 < nq) { if (!RUNS) c4.y = ichr[i0 + 1]; s4.y = qs[i0 + 1]; if (!BONLY) e4.y = qe[i0 + 1]; }
+            if (i0 + 2 < nq) { if (!RUNS) c4.z = ichr[i0 + 2]; s4.z = qs[i0 + 2]; if (!BONLY) e4.z = qe[i0 + 2]; }
         }
         qc[0] = c4.x; qc[1 % VEC] = c4.y; qc[2 % VEC] = c4.z; qc[3 % VEC] = c4.w;
         qs_[0] = s4.x; qs_[1 % VEC] = s4.y; qs_[2 % VEC] = s4.z; qs_[3 % VEC] = s4.w;
         qe_[0] = e4.x; qe_[1 % VEC] = e4.y; qe_[2 % VEC] = e4.z; qe_[3 % VEC] = e4.w;
-    } else if (i0 < nq) { qc[0] = RUNS ? 0 : ichr[i0]; qs_[0] = qs[i0]; qe_[0] = qe[i0]; }
+    } else if (i0 < nq) { qc[0] = RUNS ? 0 : ichr[i0]; qs_[0] = qs[i0]; qe_[0] = BONLY ? 0 : qe[i0]; }
     int pc = -1, ps = INT_MIN;
     if (i0 > 0 && i0 < nq) { if (!RUNS) pc = ichr[i0 - 1]; ps = qs[i0 - 1]; }
     // the batch's first and last query (head and tail of firstQ[], at the end of the kernel): asked for HERE -- four scalar
@@ -330,6 +335,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         for (int v = 0; v < VEC; v++) {
             a_[v] = qs_[v] & (W - 1);
             d_[v] = qe_[v] - (qs_[v] - a_[v]);              // qe - T0
+            if (BONLY) ok &= (qc[v] == cu) & (qs_[v] >= prev);
+            else
             ok &= (qc[v] == cu) & (qs_[v] >= prev) & ((unsigned)(d_[v] - 1) < (unsigned)(4 * W));   // 0 < qe - T0 <= 4W
             prev = qs_[v];
         }
@@ -345,9 +352,10 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                     key[v] = cb + n1;
                     lo[v] = pk + 1;
                     pk = key[v];
+                    w1v[v] = 0;
+                    if (BONLY) continue;
                     // ~query_word(): low half qe' - 1 = min(qe - T0, W), high half 65535 - qs' = 65534 - (qs - T0)
                     w0v[v] = (d_[v] < W ? d_[v] : W) | ((65534 - a_[v]) << 16);
-                    w1v[v] = 0;
                     if (d_[v] > W) {                        // reaches beyond its first tile -- unless that is the contig's last
                         int n2 = (qe_[v] - 1) >> sh;
                         if (n2 > cm) n2 = cm;
@@ -367,13 +375,13 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     int prevKey = -1;
     if (i0 > 0 && i0 < nq) {
         if (FAST) {                                         // tile_key from the staged tables
-            if (pc < 0) prevKey = 0;
-            else if (pc >= db.nCtg) prevKey = db.nT - 1;
+            if (pc < 0) prevKey = BONLY ? -1 : 0;
+            else if (pc >= db.nCtg) prevKey = BONLY ? db.nT : db.nT - 1;
             else {
                 const int n1 = tile_shift(ps, db.shift), mT = sNTile[pc] - 1;     // (negative: clamped to tile 0 either way)
                 prevKey = sBase[pc] + (n1 < 0 ? 0 : (n1 > mT ? mT : n1));
             }
-        } else prevKey = tile_key(db, pc, ps);
+        } else { prevKey = tile_key(db, pc, ps); if (BONLY) prevKey = pc < 0 ? -1 : (pc >= db.nCtg ? db.nT : prevKey); }
     }
     // 1. keys and order of the thread's queries (query i0 + v fills firstQ[lo[v]..key[v]] = i0 + v)
     int cBase[VEC], cMT[VEC];
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const int n1r = QB_TILE((db.vshift >= 0 && s0 < 0) ? 0 : s0);
             // key(i): global number of the first tile, clamped into the contig (tile_key)
             const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
-            const int k = c < 0 ? 0 : (c >= db.nCtg ? db.nT - 1 : cb + n1c);
+            const int k = c < 0 ? (BONLY ? -1 : 0) : (c >= db.nCtg ? (BONLY ? db.nT : db.nT - 1) : cb + n1c);
             unordered |= k < prevKey;
             notStart |= k == prevKey && s0 < ps;
             lo[v] = i == 0 ? k + 1 : prevKey + 1;           // the tiles up to the first query's key: filled by the whole grid (below)
@@ -417,6 +425,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     int covA[VEC], covB[VEC];                               // what it leaves to the coverage arrays (covA < 0: nothing)
 #pragma unroll
     for (int v = 0; v < VEC; v++) { covA[v] = -1; covB[v] = -1; }
+    if (!BONLY)
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // for by the barrier -- and nothing of an unordered batch's block is read.)
     int pos[VEC];
     int total = 0;
-    const bool blockLive = packed && (long long)blockIdx.x * (WGT * VEC) < nq;   // (workgroups past the queries only help filling firstQ[])
+    const bool blockLive = !BONLY && packed && (long long)blockIdx.x * (WGT * VEC) < nq;   // (workgroups past the queries only help filling firstQ[])
 #pragma unroll
     for (int v = 0; v < VEC; v++) pos[v] = 0;
     int c = 0;
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const bool some = h1 >= l1;
             if (quick && __ballot(some) == 0) continue;     // (a dense batch: most queries share their tile with the one before)
             const bool big = h1 - l1 >= 8;
-            if (!big) for (int tt = l1; tt <= h1; tt++) { firstQ[tt] = i; if (!(IGD_EXP & 0x800000)) lpos[tt] = p1; }
+            if (!big) for (int tt = l1; tt <= h1; tt++) { firstQ[tt] = i; if (!BONLY && !(IGD_EXP & 0x800000)) lpos[tt] = p1; }
             unsigned long long m = __ballot(big);
             if (m == 0) continue;
             // the budget is charged once for all long gaps of the wave's 64 queries (a returning atomic each made a small
@@ -606,11 +615,12 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                 const int l2 = __builtin_amdgcn_readlane(l1, src), h2 = __builtin_amdgcn_readlane(h1, src);
                 const int v2 = __builtin_amdgcn_readlane(i, src), p2 = __builtin_amdgcn_readlane(p1, src);
                 if (over && h2 - l2 >= 256) continue;
-                for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) { firstQ[tt] = v2; lpos[tt] = p2; }
+                for (int tt = l2 + lane; tt <= h2; tt += IGD_WAVE) { firstQ[tt] = v2; if (!BONLY) lpos[tt] = p2; }
             }
         }
     }
-    if (VEC == 4) {
+    if (BONLY) { }
+    else if (VEC == 4) {
         if (i0 + 3 < nq) *(int4 *)(qw0 + i0) = make_int4(w0v[0], w0v[1 % VEC], w0v[2 % VEC], w0v[3 % VEC]);
         else {
 #pragma unroll
@@ -627,6 +637,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     if (nq > 0 && !(IGD_EXP & 0x80000)) {
         // (tile_key over the staged tables when there are any: no look-up in global memory on the way out)
         auto edge_key = [&](int c, int q) -> int {
+            if (BONLY && c < 0) return -1;
+            if (BONLY && c >= db.nCtg) return db.nT;
             if (!ldsTab) return tile_key(db, c, q);
             if (c < 0) return 0;
             if (c >= db.nCtg) return db.nT - 1;
@@ -637,9 +649,9 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         };
         const int k0 = edge_key(RUNS ? sK[0] : edgeC0, edgeS0), kl = edge_key(RUNS ? sK[1] : edgeC1, edgeS1);
         const int nth = gridDim.x * WGT;
-        for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; lpos[tt] = 0; }
+        for (int tt = t; tt <= k0; tt += nth) { firstQ[tt] = 0; if (!BONLY) lpos[tt] = 0; }
         for (int tt = kl + 1 + t; tt <= db.nT; tt += nth) firstQ[tt] = nq;
-        if ((int)blockIdx.x == (nq - 1) / (WGT * VEC) && (int)threadIdx.x < IGD_SHORT_TILES - 1 && kl + 1 + (int)threadIdx.x <= db.nT)
+        if (!BONLY && (int)blockIdx.x == (nq - 1) / (WGT * VEC) && (int)threadIdx.x < IGD_SHORT_TILES - 1 && kl + 1 + (int)threadIdx.x <= db.nT)
             lpos[kl + 1 + threadIdx.x] = (nq % (WGT * VEC)) != 0 ? total : 0;
     }
 #if IGD_EXP & 0x1000000

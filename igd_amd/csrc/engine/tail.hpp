@@ -55,7 +55,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             vj1 = n2 > vn1 ? n2 : vn1;
             if (a.rule == IGD_HIP_RULE_NEST && db.tileCnt[vbase + vn1] == 0) vj1 = -1;   // :468 -- nothing to walk
             if (vj1 >= 0) {                              // ... and the first tile of the walk (the only one of WALK_LAST and WALK_FIRST)
-                const int jf = vkind == WALK_LAST ? vj1 : vn1;
+                const int jf = vkind == WALK_LAST ? vj1 : vkind == WALK_REST ? vn1 + 1 : vn1;
                 if (jf <= vj1 && cimg && vkind == WALK_LAST) {
                     vu0 = db.tileUnit0[vbase + jf]; vnu = db.tileUnit0[vbase + jf + 1] - vu0;
                     vcnt = vnu;                          // (0: an empty tile)
@@ -159,6 +159,7 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
             int j0 = n1;
             if (kind == WALK_LAST) j0 = j1;              // (n2 >= n1 + IGD_SHORT_TILES: the tiles between are counted by coverage_body)
             if (kind == WALK_FIRST) j1 = n1;
+            if (kind == WALK_REST) { j0 = n1 + 1; j1 = j1 < n1 + IGD_SHORT_TILES - 1 ? j1 : n1 + IGD_SHORT_TILES - 1; }   // (igd_scan_direct: the later tiles the scan leaves out; a long query's tiles from n1+4 on: coverage + WALK_LAST)
             for (int j = j0; j <= j1; j = (kind == WALK_ALL && j < j1) ? j1 : j + 1) {   // (WALK_ALL: first and last tile, coverage_body has the rest)
                 const int t = base + j;
                 const int tcnt = j == j0 ? __builtin_amdgcn_readlane(vcnt, e) : db.tileCnt[t];
@@ -405,6 +406,13 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     if (lane == 0 && gwave < 16384) { u64 *o = d_tailSt + (size_t)gwave * 5; o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = __builtin_amdgcn_s_memtime(); }
 #endif
     if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane, ctlv);
+    if (valves & 8) {                                    // the batch took the DIRECT step (scan_direct.hpp): its dense tiles and deferred units
+        DirArgs d;
+        d.firstQ = K.a.firstQ; d.tileD = K.db.tileD; d.q_qs = wa.q_qs; d.q_qe = wa.q_qe; d.ctl = K.a.ctlw; d.fix = nullptr;
+        d.heavyS = K.a.heavyS; d.farList = K.a.farList; d.nq = wa.nq; d.v = wa.v; d.epoch = wa.epoch; d.rule = wa.rule;
+        d.promised = 1; d.sbCap = 0; d.wldsBytes = K.a.wldsBytes; d.out = nullptr; d.hitsOut = d_hits; d.totalOut = d_total;
+        direct_tail_body<USE_V>(K.db, d, smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes, gwave, nwaves, lane, ctlv);
+    } else
     if (valves & 2) {
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
         if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);

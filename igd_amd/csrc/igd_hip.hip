@@ -229,6 +229,7 @@ struct DbView {
     const int32_t *ctgNTile;                    // [nCtg]
     const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
     int32_t *cov;                               // workspace: 4 sets of coverage difference arrays (IGD_COV_*)
+    const int4 *tileD;                          // [nT] per tile: the records that start in the NEXT tile, the contig, the tiles left in it (k_tile_desc; null: no DIRECT step)
     // A database whose file is bucketed with another tile width than the image likes (-b 11..13, 16..19) is searched over a
     // RE-TILED copy: the same records in tiles of 2^14 bp (igd_hip_db::inner).  Which records a query counts does not depend on
     // the tile width -- every record that overlaps it, once -- with two exceptions that are properties of the FILE's tiles: a
@@ -278,6 +279,10 @@ struct igd_hip_db {
     int lbShift;                  // log2(queries per later block) of the batch in flight
     int lastMode, lastPacked;     // of the last batch (igd_hip_last_scan_kernel)
     int forceRank;                // IGD_HIP_RANK at open (tests): 0 lean build, 1 full build, -1 the engine decides
+    int forceDirect;              // IGD_HIP_DIRECT at open (tests): 1 every batch under IGD_HIP_FLAG_SORTED that can takes the DIRECT step, 0 none, -1 the engine decides
+    int4 *d_tileD;                // DbView::tileD
+    int ldsDirect;                // dynamic LDS of igd_scan_direct
+    int lastDirect;               // the last batch took the DIRECT step (igd_hip_last_scan_kernel)
     bool bigImage;                // the compact image is addressed with per-unit 64-bit bases (>= 2^30 tile records; IGD_HIP_BIG=1 at open: tests)
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
     uint32_t *d_spTable;          // split path: [nWG][nCoarse] offset | count << 16
@@ -331,6 +336,7 @@ struct igd_hip_db {
 #include "engine/compact_image.hpp"   // k_pack_units: the 6-byte tile-relative image and its unit descriptors
 #include "engine/scan_tiles.hpp"      // igd_scan_tiles (bucket path) and its skew valve
 #include "engine/scan_sorted.hpp"     // igd_scan_sorted: the merge join (pairwise and rank builds) -- the dominant kernel
+#include "engine/scan_direct.hpp"     // dense sorted batches without a per-query pre-pass: k_tile_bounds, igd_scan_direct
 #include "engine/tail.hpp"            // exact walks, coverage, k_reduce_slabs (last launch of a batch), k_sum_hits
 #include "engine/enumerate_dev.hpp"   // `-f` enumeration kernels
 #include "engine/hitmap_dev.hpp"      // `-m` hit map kernel

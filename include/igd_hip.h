@@ -103,6 +103,12 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
 /* igd_hip_search_dev only: d_hits[] (and d_total) are cleared by the batch's first kernel before the
  * counts are added -- saves the caller a separate memset when it does not accumulate. */
 #define IGD_HIP_FLAG_ZERO_FIRST 8
+/* With IGD_HIP_FLAG_SORTED: the caller also states that no query is longer than one tile (qe - qs < nbp) -- what a
+ * query file of peaks / regions is, and what the command line tool finds out while it parses.  A dense batch (>= 28 queries
+ * per tile on average) then takes the DIRECT step: no per-query pre-pass, the scan kernel reads q_qs / q_qe itself
+ * (engine/scan_direct.hpp).  VERIFIED like the order: a longer query is found where it is read and its later tiles are
+ * walked exactly -- it costs time, never a count. */
+#define IGD_HIP_FLAG_SHORT 16
 
 /* Host-buffer search.  ichr[i] = contig index (as get_id returns; <0 or >=nCtg: skipped).
  * hits[0..nFiles) is caller-allocated and is ADDED to (reference semantics :491).

@@ -29,7 +29,7 @@ def _run(args, devices=None):
 def test_two_engine_handles_give_the_single_device_table(family, extra):
     db, q = os.path.join(GOLDEN, family, "db.igd"), os.path.join(GOLDEN, family, "q.bed")
     one = _run(["search", db, "-q", q] + extra)
-    for devs in ("0,0", "0,0,0", "0"):
+    for devs in ("0,0", "0,0,0", "0", "0,0,0,0,0,0,0,0"):     # (eight handles: the shape of the 8-GPU node's one-process job)
         assert _run(["search", db, "-q", q] + extra, devs) == one, devs
     o = Oracle(db)
     ichr, qs, qe = o.read_queries(q)
