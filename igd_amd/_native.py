@@ -95,7 +95,7 @@ class CoreDb(C.Structure):
 
 class CoreQueries(C.Structure):
     _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("ichr", i32p), ("qs", i32p), ("qe", i32p),
-                ("unsorted", C.c_int32)]
+                ("unsorted", C.c_int32), ("max_len", C.c_int32)]
 
 
 IGD_HIP_RULE_NEST = 0

@@ -374,7 +374,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
                 for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
             }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
-            db->ldsDirect = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
+            db->ldsDirect = hitB + (IGD_WG_DIR / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));

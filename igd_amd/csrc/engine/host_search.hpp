@@ -336,7 +336,8 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
 #ifndef IGD_QB_WIDE
 #define IGD_QB_WIDE 1024
 #endif
-        if (wide) { if (fast) QB_LAUNCH(4, true, IGD_QB_WIDE); else QB_LAUNCH(4, false, IGD_QB_WIDE); }
+        // (the bounds alone need no later blocks: workgroups of 256 -- more of them in flight, no barrier across 16 waves)
+        if (wide && !(direct && !getenv("IGD_HIP_BONLY_WIDE"))) { if (fast) QB_LAUNCH(4, true, IGD_QB_WIDE); else QB_LAUNCH(4, false, IGD_QB_WIDE); }
         else if (vec) { if (fast) QB_LAUNCH(4, true, 256); else QB_LAUNCH(4, false, 256); }
         else { if (fast) QB_LAUNCH(1, true, 256); else QB_LAUNCH(1, false, 256); }
 #undef QB_LAUNCH
@@ -385,8 +386,8 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
                 D.a.heavyS = db->d_heavy + IGD_HEAVY_MAX; D.a.farList = db->d_far; D.a.nq = (int)nq; D.a.v = v; D.a.epoch = db->epoch;
                 D.a.rule = rule; D.a.promised = 1; D.a.sbCap = db->sbCap; D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap;
                 D.a.out = db->d_slab; D.a.hitsOut = (u64 *)d_hits; D.a.totalOut = (u64 *)d_total;
-                if (useV) launch_sorted(db, igd_scan_direct<true>, db->grid, IGD_WG_RANK, (size_t)db->ldsDirect, st, D);
-                else launch_sorted(db, igd_scan_direct<false>, db->grid, IGD_WG_RANK, (size_t)db->ldsDirect, st, D);
+                if (useV) launch_sorted(db, igd_scan_direct<true>, db->grid, IGD_WG_DIR, (size_t)db->ldsDirect, st, D);
+                else launch_sorted(db, igd_scan_direct<false>, db->grid, IGD_WG_DIR, (size_t)db->ldsDirect, st, D);
             } else
             launch_scan_any<true>(db, a, useV, packed, st, db->nWin > 1 ? win : -1);
             if (extEv && db->evStart) {                  // (no merge-join launch took the pair: cannot happen for this kind of batch)
@@ -528,7 +529,7 @@ static int search_slab_resident(igd_hip_db *db, const int32_t *ichr, const int32
         if (rc == IGD_HIP_ERR_UNSORTED) {
             // the caller's order promise did not hold for this slice (it added nothing): redo it
             // with the device choosing the grouping
-            flags &= ~IGD_HIP_FLAG_SORTED;
+            flags &= ~(IGD_HIP_FLAG_SORTED | IGD_HIP_FLAG_SHORT);
             rc = igd_hip_search_dev(db, db->d_qc, db->d_qs, db->d_qe, m, v, rule, flags, db->d_hits, db->d_total, st);
             if (rc == IGD_HIP_OK) rc = igd_hip_sync(db, st);
         }

@@ -1,35 +1,41 @@
 // engine/scan_direct.hpp -- part of igd_hip.hip (included there once; not a stand-alone header).
-// The DIRECT step of a dense, position-sorted batch: no per-query pre-pass at all.
+// The DIRECT step of a dense, position-sorted batch: the queries' words are never written -- the scan reads the queries.
 // ------------------------------------------------------------------------------------------
 // What it replaces.  The ordinary sorted step is k_query_bounds (every query read once: 12 bytes in, 4.3 out) ->
-// igd_scan_sorted (reads the 4.3) -> k_reduce_slabs.  For one GPU's share of BASELINE config 4 -- 1.25e7 queries,
-// 66 .. 530 per tile -- the pre-pass costs 48 .. 55 us beside a scan of 56 .. 144 us.  Here the
-// queries are read ONCE, 8 bytes each, by the wave that counts them:
-//   k_tile_bounds     firstQ[t] = the first query of every tile, by bisection over the sorted (contig, start) keys:
-//                     O(T log Q) probes instead of a pass over Q queries; [ichr form] streams ichr[] once to verify the
-//                     contig order the bisection relies on.
+// igd_scan_sorted (reads the 4.3) -> k_reduce_slabs.  For one GPU's slab of BASELINE config 4 -- 1.25e7 queries, 130 .. 530
+// per visited tile -- the pre-pass costs 47 us beside a scan of 56 .. 94 us.  Here:
+//   k_query_bounds<.., BONLY>  the BOUNDS alone: firstQ[t] = the first query of every tile, and the check that the keys
+//                     (contig, clamped first tile) never decrease -- starts and contig numbers read, nothing else read,
+//                     computed or stored: 21 .. 24 us.  (Tried first: no pass at all -- firstQ[] by bisection per tile,
+//                     then by 64-ary searches per 64 / 256 tiles with the last steps in LDS: O(T log Q) probes, but every
+//                     probe in a page of its own -- 59 / 46 / 38 us for the benchmark's 188 505 tiles.  LABNOTES.md.)
 //   igd_scan_direct   the rank method of igd_scan_sorted (scan_sorted.hpp) with the queries' words derived in registers
-//                     from q_qs / q_qe, the order promise verified where the queries are read (each query belongs to
-//                     exactly one tile's range and is checked by that tile's first unit), and the LATER tiles PUSHED
-//                     instead of pulled: the first unit of tile t appends the first 64 records that START in tile t+1
-//                     to its own sorted start array (s' + W), so that ONE bisection per query with the unclamped key
-//                     min(qe - T0, 2W) + 1 places it among both, and the prefix sum over one more slot yields the
-//                     later-tile counts (src/igd_search.c:495-531: a later tile counts the records with
-//                     tile start <= start < qe; end > qs holds by construction).  Queries that reach further than the
-//                     appended records cover -- or beyond tile t+1 -- are listed for an exact walk of their later tiles
-//                     (WALK_REST; long ones also WALK_LAST + the coverage arrays, as k_query_bounds lists them).
+//                     from q_qs / q_qe (8 bytes per query, read once by the wave that counts them), the order of the
+//                     starts inside a tile verified where they are read (each query belongs to exactly one tile's range
+//                     and is checked by that tile's first unit), and the LATER tiles PUSHED instead of pulled: the first
+//                     unit of tile t appends the first 64 records that START in tile t+1 to its own sorted start array
+//                     (s' + W), so that ONE bisection per query with the unclamped key min(qe - T0, 2W) + 1 places it
+//                     among both, and the prefix sum over one more slot yields the later-tile counts
+//                     (src/igd_search.c:495-531: a later tile counts the records with tile start <= start < qe; end > qs
+//                     holds by construction).  Queries that reach further than the appended records cover -- or beyond
+//                     tile t+1 -- are listed for an exact walk of their later tiles (WALK_REST; long ones also WALK_LAST +
+//                     the coverage arrays, as k_query_bounds lists them).
 // Semantics kept: tile range and clamps src/igd_search.c:459-464, rule NEST :468 (an empty first tile ends the query:
 // its first unit is a placeholder with n == 0 and pushes nothing), later tiles :495-531, rule FLAT :635-691.
 // Chosen by the host for batches under IGD_HIP_FLAG_SORTED | IGD_HIP_FLAG_SHORT that are dense (>= 28 queries per tile
 // on average) over a compact image with power-of-two tiles of <= 2^14 bp; everything else takes the ordinary step.
-// Both promises are VERIFIED here: disorder marks the batch broken (it adds nothing, igd_hip_sync reports it), a query
+// Both promises are VERIFIED: disorder marks the batch broken (it adds nothing, igd_hip_sync reports it), a query
 // longer than promised only costs time (its later tiles are walked exactly).
+// Measured (one MI355X, step = all three launches): slab 0 of 8 / 4 / 2 of config 4's sorted set 112 -> 89, 127 -> 107,
+// 156 -> 145 us; the unsharded 1.25e7-query batch (66 per tile) 215 -> 214 us -- its scan is 181 against 149 us there: two
+// batches per unit, the second nearly empty, and a sixth slot per unit cost what the pre-pass saves.
 
-#ifndef IGD_D_ORDER_LOAD
-#define IGD_D_ORDER_LOAD 0      // 1: the order check reads q_qs[i - 1] again instead of a cross-lane shift
+#ifndef IGD_D_EXP
+#define IGD_D_EXP 0             // measurement only (WRONG counts): 1 no term B, 2 no search in term A, 4 no prefix sums, 8 no flush, 16 no order check
 #endif
-#ifndef IGD_D_PRE2
-#define IGD_D_PRE2 0            // 1: the second batch of queries also comes with the unit's records
+#ifndef IGD_WG_DIR
+#define IGD_WG_DIR IGD_WG_RANK  // threads per workgroup / waves per SIMD of igd_scan_direct (2 workgroups per CU)
+#define IGD_WPE_DIR IGD_WPE_RANK
 #endif
 #define IGD_D_SL 512                                    // u16 entries per wave: 320 own starts, 64 appended, 128 x 65535
 #define IGD_D_H 392                                     // u32 entries per wave: histogram over positions 0 .. 384
@@ -63,205 +69,8 @@ __global__ void k_tile_desc(DbView db, int4 *__restrict__ out)
     out[t] = d;
 }
 
-// key of query i for the bisection: the global number of its first tile, clamped into its contig; -1 / nT for contig
-// numbers outside the database (they belong to no tile's range and are never read again)
-__device__ __forceinline__ int direct_key(const DbView &db, const int32_t *sBase, const int32_t *sNTile, int c, int qs)
-{
-    if (c < 0) return -1;
-    if (c >= db.nCtg) return db.nT;
-    const int n1 = tile_shift(qs, db.shift), mT = sNTile[c] - 1;
-    return sBase[c] + (n1 < 0 ? 0 : (n1 > mT ? mT : n1));
-}
-
-// firstQ[t] = first query whose key is >= t, t = 0 .. nT.  RUNS: `ichr` is run_start[nCtg + 1] (igd_hip_search_runs_dev).
-// Also what every batch owes its caller and the next batch (hits[] cleared on request, the other parity's lists emptied).
-// One WORKGROUP of four waves per 256 consecutive tiles (a bisection per tile over 1.25e7 queries is 24 dependent probes:
-// 59 us for the benchmark's 188 505 tiles; a search per 64 tiles -- 5892 of them, every probe in a page of its own -- 46 us):
-//   1. [ichr form] the workgroup's share of ichr[] is streamed and checked to be non-decreasing -- what makes every tile's
-//      range lie inside its contig's run of queries, whatever the starts are;
-//   2. wave 0 finds the range [lo, hi) of queries the 256 tiles share by TWO 64-ary searches that advance together (64
-//      probes per search and round, 4-5 rounds); a probe compares (contig, clamped tile) with the target pair;
-//   3. IGD_TB_KEYS evenly spaced keys of that range (all of them when it is that short) are loaded into LDS, every thread
-//      bisects them for its own tile, and the few steps that are left probe memory -- neighbours, in the same cache lines.
-#ifndef IGD_TB_EXP
-#define IGD_TB_EXP 0            // measurement only (WRONG bounds): 1 no ichr stream, 2 no per-tile step, 4 no 64-ary searches
-#endif
-#define IGD_TB_KEYS 3072                                // sampled keys of a workgroup's range kept in LDS
-#define IGD_TB_WG 256                                   // threads = tiles per workgroup
-#define IGD_TB_CTG 256                                  // contig tables kept in LDS up to this many contigs
-template <bool RUNS>
-__global__ __launch_bounds__(IGD_TB_WG) void k_tile_bounds(DbView db, const int32_t *__restrict__ ichr, const int32_t *__restrict__ qs, int nq,
-                                                           int32_t *__restrict__ firstQ, int32_t *__restrict__ ctl, int epoch, int promised,
-                                                           u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal)
-{
-    __shared__ int32_t sB[IGD_TB_CTG], sN[IGD_TB_CTG];
-    __shared__ int32_t sRun[RUNS ? QB_CTG + 1 : 1];
-    __shared__ int32_t sKey[IGD_TB_KEYS];
-    __shared__ int sLoHi[2];
-    const bool ldsTab = db.nCtg <= IGD_TB_CTG;
-    const int32_t *sBase = ldsTab ? sB : db.ctgBase, *sNTile = ldsTab ? sN : db.ctgNTile;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int t = blockIdx.x * IGD_TB_WG + tid;
-    const int nth = gridDim.x * IGD_TB_WG;
-    if (zeroHits) for (int f = t; f < db.nFiles; f += nth) zeroHits[f] = 0;       // IGD_HIP_FLAG_ZERO_FIRST
-    if (zeroTotal && t == 0) *zeroTotal = 0;
-    if (t == 0) {
-        ctl[CTL_NLONG + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NFIX + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_BUDGET + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NHEAVY + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NHEAVYS + ((epoch + 1) & 1)] = 0;
-        ctl[CTL_NFAR + ((epoch + 1) & 1)] = 0;
-    }
-    if (ldsTab) for (int c = tid; c < db.nCtg; c += IGD_TB_WG) { sB[c] = db.ctgBase[c]; sN[c] = db.ctgNTile[c]; }
-    int bad = 0;
-    if (RUNS) {
-        for (int c = tid; c <= db.nCtg; c += IGD_TB_WG) {
-            const int r0 = ichr[c];
-            sRun[c] = r0;
-            if (c < db.nCtg) bad |= r0 > ichr[c + 1] ? 1 : 0;
-            if (c == 0) bad |= (r0 != 0 || ichr[db.nCtg] != nq) ? 1 : 0;
-        }
-    } else if (!(IGD_TB_EXP & 1)) {
-        // 1. this workgroup's share of the contig numbers (whole int4s; 8 loads in flight per lane)
-        const long long per = ((((long long)nq + gridDim.x - 1) / gridDim.x) + 1023) & ~1023ll;
-        const long long s0 = (long long)blockIdx.x * per, s1 = s0 + per < nq ? s0 + per : nq;
-        if ((((uintptr_t)ichr) & 15) == 0) {
-            for (long long i0 = s0; i0 < s1; i0 += IGD_TB_WG * 4 * 8) {
-                int4 c4[8];
-                int pv[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const long long i = i0 + ((long long)u * IGD_TB_WG + tid) * 4;
-                    c4[u] = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX); pv[u] = INT_MIN;
-                    if (i + 4 <= s1) { c4[u] = *(const int4 *)(ichr + i); if (i > 0) pv[u] = ichr[i - 1]; }
-                    else if (i < s1) {
-                        if (i > 0) pv[u] = ichr[i - 1];
-                        c4[u].x = ichr[i];
-                        if (i + 1 < s1) c4[u].y = ichr[i + 1];
-                        if (i + 2 < s1) c4[u].z = ichr[i + 2];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) bad |= (c4[u].x < pv[u]) | (c4[u].y < c4[u].x) | (c4[u].z < c4[u].y) | (c4[u].w < c4[u].z);
-            }
-        } else
-            for (long long i = s0 + tid; i < s1; i += IGD_TB_WG) bad |= (i > 0 && ichr[i] < ichr[i - 1]) ? 1 : 0;
-    }
-    if (__syncthreads_or(bad)) {                          // (also: the tables are staged)
-        if (tid == 0) { ctl[CTL_UNSORTED] = epoch; if (promised) ctl[CTL_BROKEN] = epoch; }
-        if (RUNS) return;                                 // not a run table of this batch (firstQ[] is not read: the scan kernel sees the mark first)
-    }
-    // contig of query i, RUNS: the number of run starts 1 .. nCtg that are <= i
-    auto ctg_of = [&](int i) -> int {
-        if (!RUNS) return ichr[i];
-        int a = 0, b = db.nCtg;                           // largest a with sRun[a] <= i  (sRun[0] = 0)
-        while (a < b) { const int mid = (a + b + 1) >> 1; if (sRun[mid] <= i) a = mid; else b = mid - 1; }
-        return a;
-    };
-    // the (contig, tile in it, last tile of it) of a global tile number; nT: (nCtg, 0, 0)
-    auto where = [&](int tile, int &c, int &j, int &mT) {
-        if (tile >= db.nT) { c = db.nCtg; j = 0; mT = 0; return; }
-        int a = 0, b = db.nCtg - 1;
-        while (a < b) { const int mid = (a + b + 1) >> 1; if (sBase[mid] <= tile) a = mid; else b = mid - 1; }
-        c = a; j = tile - sBase[a]; mT = sNTile[a] - 1;
-    };
-    // key(i) >= the tile (c, j): by contig first, then by the clamped tile of the start (both loads are issued before
-    // either is looked at: a probe is ONE round trip)
-    auto reaches = [&](int i, int c, int j, int mT) -> bool {
-        const int ci = ctg_of(i), si = qs[i];
-        int n1 = tile_shift(si, db.shift);
-        n1 = n1 < 0 ? 0 : (n1 > mT ? mT : n1);
-        return ci != c ? ci > c : n1 >= j;
-    };
-    const int t0 = blockIdx.x * IGD_TB_WG;
-    const int t1 = t0 + IGD_TB_WG < db.nT ? t0 + IGD_TB_WG : db.nT;    // the workgroup's tiles are t0 .. t1 - 1 (the last one also writes firstQ[nT])
-    if (wv == 0) {
-        int cA, jA, mA, cB, jB, mB;
-        where(t0, cA, jA, mA);
-        where(t1, cB, jB, mB);
-        // ---- 2. two 64-ary searches side by side: lo = first i with key >= t0, hi = first i with key >= t1 ----
-        // [lo, hi): the candidates; the answer is the first of them that reaches the target, or `hi` (known to, or the batch's
-        // end).  A round cuts the candidates into 64 pieces and probes each piece's last query: the first piece whose probe
-        // reaches the target holds the answer.
-        int loA = 0, hiA = nq, loB = 0, hiB = nq;
-        if (IGD_TB_EXP & 4) { loA = hiA = (int)((long long)nq * t0 / db.nT); loB = hiB = (int)((long long)nq * t1 / db.nT); }
-        while (hiA - loA > 0 || hiB - loB > 0) {
-            const int nA = hiA - loA, nB = hiB - loB;
-            const int stA = (nA + 63) >> 6, stB = (nB + 63) >> 6;
-            const int pA = loA + (lane + 1) * stA - 1, pB = loB + (lane + 1) * stB - 1;     // last query of the lane's piece
-            const bool vA = nA > 0 && pA - stA + 1 < hiA, vB = nB > 0 && pB - stB + 1 < hiB;
-            const int qA = pA < hiA ? pA : hiA - 1, qB = pB < hiB ? pB : hiB - 1;
-            // (all four loads of the round in flight together: lanes without a probe read query 0)
-            const int iA = vA ? qA : 0, iB = vB ? qB : 0;
-            const int ciA = ctg_of(iA), siA = qs[iA], ciB = ctg_of(iB), siB = qs[iB];
-            int nA1 = tile_shift(siA, db.shift), nB1 = tile_shift(siB, db.shift);
-            nA1 = nA1 < 0 ? 0 : (nA1 > mA ? mA : nA1);
-            nB1 = nB1 < 0 ? 0 : (nB1 > mB ? mB : nB1);
-            const bool rA = vA && (ciA != cA ? ciA > cA : nA1 >= jA), rB = vB && (ciB != cB ? ciB > cB : nB1 >= jB);
-            if (nA > 0) {
-                const unsigned long long m = __ballot(rA);
-                if (m == 0) loA = hiA;                    // no probe reaches t0: the answer is the candidates' end
-                else {
-                    const int f = __builtin_ctzll(m);
-                    hiA = __builtin_amdgcn_readlane(qA, f);
-                    loA = loA + f * stA;
-                }
-            }
-            if (nB > 0) {
-                const unsigned long long m = __ballot(rB);
-                if (m == 0) loB = hiB;
-                else {
-                    const int f = __builtin_ctzll(m);
-                    hiB = __builtin_amdgcn_readlane(qB, f);
-                    loB = loB + f * stB;
-                }
-            }
-        }
-        if (lane == 0) { sLoHi[0] = loA; sLoHi[1] = loB; }
-    }
-    __syncthreads();
-    const int lo = sLoHi[0], hi = sLoHi[1];               // the queries of tiles t0 .. t1-1 are [lo, hi)
-    const int tt = t0 + tid;
-    int ans = lo;
-    if (hi > lo && !(IGD_TB_EXP & 2)) {                   // (the same for the whole workgroup)
-        const int R = hi - lo;
-        int cT, jT, mT_;
-        where(tt < db.nT ? tt : db.nT - 1, cT, jT, mT_);
-        // 3. evenly spaced keys of [lo, hi) in LDS (every key when stp = 1), each thread's bisection over them, then the steps
-        // that are left in memory
-        const long long stp = ((long long)R + IGD_TB_KEYS - 1) / IGD_TB_KEYS;
-        const int ns = (int)(((long long)R + stp - 1) / stp);             // samples: the last query of every piece of stp
-        {
-            int sv[IGD_TB_KEYS / IGD_TB_WG];
-#pragma unroll
-            for (int u = 0; u < IGD_TB_KEYS / IGD_TB_WG; u++) {
-                const int k = u * IGD_TB_WG + tid;
-                long long at = (long long)lo + (long long)(k + 1) * stp - 1;
-                if (at >= hi) at = hi - 1;
-                sv[u] = INT_MAX;
-                if (k < ns) { const int ci = ctg_of((int)at), si = qs[at]; sv[u] = direct_key(db, sBase, sNTile, ci, si); }
-            }
-#pragma unroll
-            for (int u = 0; u < IGD_TB_KEYS / IGD_TB_WG; u++) sKey[u * IGD_TB_WG + tid] = sv[u];
-        }
-        __syncthreads();
-        int a = 0, b = ns;                                // first sample whose key is >= tt
-        while (a < b) { const int mid = (a + b) >> 1; if (sKey[mid] >= tt) b = mid; else a = mid + 1; }
-        // the answer lies in the piece of sample a: [lo + a stp, its last query] -- that one is known to reach tt -- or is `hi`
-        long long l2 = (long long)lo + (long long)a * stp, h2 = l2 + stp - 1;
-        if (h2 >= hi) h2 = a < ns ? hi - 1 : hi;
-        if (a >= ns) { l2 = hi; h2 = hi; }
-        int x = (int)l2, y = (int)h2;
-        while (x < y) { const int mid = (int)(((unsigned)x + (unsigned)y) >> 1); if (reaches(mid, cT, jT, mT_)) y = mid; else x = mid + 1; }
-        ans = x;
-    }
-    if (tt < t1) firstQ[tt] = ans;
-    if (t1 == db.nT && tid == 0) firstQ[db.nT] = hi;
-}
-
 struct DirArgs {
-    const int32_t *firstQ;       // [nT + 1] (k_tile_bounds)
+    const int32_t *firstQ;       // [nT + 1] (k_query_bounds<.., BONLY>)
     const int4 *tileD;           // [nT] (k_tile_desc)
     const int32_t *q_qs, *q_qe;
     int32_t *ctl;
@@ -287,11 +96,29 @@ struct DRaw {
     uint32_t a[IGD_SLOTS + 1];   // record words; [IGD_SLOTS]: the appended records of the next tile
     int32_t x[IGD_SLOTS + 1];    // dataset numbers (| value << 16)
     int32_t qs, qe;              // the first 64 queries of the unit's range
-#if IGD_D_PRE2
-    int32_t qs2, qe2;            // the next 64
-#endif
     int32_t c0, f0, n;           // wave-uniform (the rest of the descriptor is read from the lane that holds it when the unit's turn comes)
 };
+
+// the dataset numbers (| value << 16 with the filter) of a unit's records and of the appended ones
+template <bool USE_V>
+__device__ __forceinline__ void d_load_x(const DbView &db, int32_t (&x)[IGD_SLOTS + 1], unsigned offLo, int n, unsigned appOff, int appN, int lane)
+{
+    const int vo4 = lane * 4, vo2 = lane * 2;
+    const int end = (int)offLo + n, endA = (int)appOff + appN;
+    if (USE_V) {
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, (int)((unsigned)end * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, appN ? (int)((unsigned)endA * 4u) : 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), 0);
+        x[IGD_SLOTS] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsY, vo4, (int)(appOff * 4u), 0);
+    } else {
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, (int)((unsigned)end * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, appN ? (int)((unsigned)endA * 2u) : 0, 0x00020000);
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, (int)(offLo * 2u), 0);
+        x[IGD_SLOTS] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsY, vo2, (int)(appOff * 2u), 0);
+    }
+}
 
 template <bool USE_V>
 __device__ __forceinline__ void d_issue(const DbView &db, const DirArgs &a, const DRegs &L, int kk, bool valid, int lane, DRaw &R)
@@ -307,31 +134,14 @@ __device__ __forceinline__ void d_issue(const DbView &db, const DirArgs &a, cons
     R.c0 = c0; R.f0 = f0; R.n = n;
     const unsigned offLo = (unsigned)__builtin_amdgcn_readlane(L.offLo, kq);
     const unsigned appOff = (unsigned)__builtin_amdgcn_readlane(L.appOff, kq);
-    const int vo4 = lane * 4, vo2 = lane * 2;
+    const int vo4 = lane * 4;
     const int end = (int)offLo + n, endA = (int)appOff + appN;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, (int)((unsigned)end * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, appN ? (int)((unsigned)endA * 4u) : 0, 0x00020000);
-    if (USE_V) {
-        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, (int)((unsigned)end * 4u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)db.pxv, 0, appN ? (int)((unsigned)endA * 4u) : 0, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < IGD_SLOTS; r++) {
-            R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
-            R.x[r] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsX, vo4 + r * 256, (int)(offLo * 4u), 0);
-        }
-        R.a[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
-        R.x[IGD_SLOTS] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsY, vo4, (int)(appOff * 4u), 0);
-    } else {
-        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, (int)((unsigned)end * 2u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void *)db.px, 0, appN ? (int)((unsigned)endA * 2u) : 0, 0x00020000);
-#pragma unroll
-        for (int r = 0; r < IGD_SLOTS; r++) {
-            R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
-            R.x[r] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, vo2 + r * 128, (int)(offLo * 2u), 0);
-        }
-        R.a[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
-        R.x[IGD_SLOTS] = (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsY, vo2, (int)(appOff * 2u), 0);
-    }
+    for (int r = 0; r < IGD_SLOTS; r++) R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
+    R.a[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
+    d_load_x<USE_V>(db, R.x, offLo, n, appOff, appN, lane);
     // the first 64 queries of the tile.  ONE descriptor per array for the whole kernel (its end = the batch's end): lanes past
     // the tile's last query read the queries that follow -- every use is masked by the tile's count -- and an unvisited unit
     // (c0 = 0) is pushed out of range: no memory access.
@@ -340,11 +150,6 @@ __device__ __forceinline__ void d_issue(const DbView &db, const DirArgs &a, cons
     const int so = c0 ? f0 * 4 : 0x7FFFFF00;
     R.qs = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, so, 0);
     R.qe = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, so, 0);
-#if IGD_D_PRE2
-    const int so2 = c0 > IGD_WAVE ? (f0 + IGD_WAVE) * 4 : 0x7FFFFF00;
-    R.qs2 = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, so2, 0);
-    R.qe2 = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, so2, 0);
-#endif
 }
 
 // The batch was found out of order: nothing it has counted or is still going to count is added (k_reduce_slabs and the
@@ -400,7 +205,6 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     const int j = jf >> 4;
     const bool first = jf & 1;                           // the tile's first unit: it checks, lists and pushes
     const int T0 = (int)((unsigned)j * (unsigned)W);
-    const int appN = first ? (meta & 127) : 0;
     const bool appMore = (meta & 128) != 0, nextTile = (meta & 256) != 0;
     const int ctg = (meta >> 13) & 1023;
     int rem = (meta >> 9) & 15;                          // tiles left in the contig behind this one, capped at 15 ...
@@ -411,12 +215,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     int cnt[IGD_SLOTS + 1];
 #pragma unroll
     for (int r = 0; r <= IGD_SLOTS; r++) cnt[r] = 0;
-    bool keep[IGD_SLOTS + 1];
-#pragma unroll
-    for (int r = 0; r <= IGD_SLOTS; r++) {
-        keep[r] = true;
-        if (USE_V) { keep[r] = (R.x[r] >> 16) >= a.v; R.x[r] &= 0xFFFF; }
-    }
+    int32_t (&X)[IGD_SLOTS + 1] = R.x;
     // ---- the unit's starts, and behind them (first unit) the starts of the next tile's first records, + W ----
     // Lanes past the unit's last record hold W + 1 there: above every own start (<= W), not above any appended one (>= W + 1),
     // so the array stays sorted and a query that ends inside the tile is placed at the unit's end as before.
@@ -439,7 +238,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     __builtin_amdgcn_wave_barrier();
     // a query is served by the appended records iff every record of tile t+1 that it can count is among them
     int covKey = 0;                                      // keys up to this one are
-    if (push) covKey = appMore ? (int)sl[IGD_SLOTS * IGD_WAVE + appN - 1] : 2 * W + 1;
+    if (push) covKey = appMore ? W + (int)(65535u - ((unsigned)__builtin_amdgcn_readlane((int)R.a[IGD_SLOTS], IGD_D_APP - 1) & 0xFFFFu)) : 2 * W + 1;   // (more than ride along: all IGD_D_APP lanes hold one)
     // ... in terms of d = qe - T0: a query of the first unit with W < d <= dlim is served (when the appended records are all
     // there are and tile t+1 is the contig's last, whatever its end: n2 is clamped, :463)
     const int dlim = !first ? INT_MAX : (rem == 0 || dead) ? INT_MAX : appMore ? covKey - 1 : rem == 1 ? INT_MAX : 2 * W;
@@ -458,24 +257,18 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     auto batch = [&](const int p, const int qs_, const int qe_) {
         const int idx = p + lane;
         const int a_ = qs_ - T0, d_ = qe_ - T0;
-        if (first) {                                     // the order of the starts, where they are read
-#if IGD_D_ORDER_LOAD
-            int pq = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + p) * 4 - 4, 0);     // (the same cache lines again)
-            if (idx == 0) pq = carryQ;
-            disorder = disorder || (idx < c0 && qs_ < pq);
-#else
-            int pq = __shfl_up(qs_, 1);
-            if (lane == 0) pq = carryQ;
+        if (first && !(IGD_D_EXP & 16)) {                // the order of the starts, where they are read
+            // lane i gets lane i-1's start, lane 0 keeps the last start of the batch before (DPP wave_shr:1 -- one instruction)
+            const int pq = __builtin_amdgcn_update_dpp(carryQ, qs_, 0x138, 0xf, 0xf, false);
             disorder = disorder || (idx < c0 && qs_ < pq);
             carryQ = __builtin_amdgcn_readlane(qs_, IGD_WAVE - 1);
-#endif
         }
         // ---- the usual batch: queries of this tile, none inverted, that end inside it or are served by the records that ride
         // along -- nothing to mask or list ----
         const bool there = idx < c0;
         if (__ballot(there && !((unsigned)a_ < (unsigned)W && d_ >= (a_ > 1 ? a_ : 1) && d_ <= dlim)) == 0ull) {
             if (rankAny) {
-                const int pos = lds_lower_bound(sl, (d_ < capF ? d_ : capF) + 1);
+                const int pos = (IGD_D_EXP & 2) ? (d_ & 255) : lds_lower_bound(sl, (d_ < capF ? d_ : capF) + 1);
                 if (there) atomicAdd(&hist[pos], 1u);
             }
             nFirst += __popcll(__ballot(there));
@@ -578,22 +371,10 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     };
     {
         // the next 64 queries are on their way while these are searched (past the batch's last query: no access)
-#if IGD_D_PRE2
-        int qsN = R.qs2, qeN = R.qe2;
-        batch(0, R.qs, R.qe);
-        if (c0 > IGD_WAVE) {
-            const int qs_ = qsN, qe_ = qeN;
-            qsN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + 2 * IGD_WAVE) * 4, 0);
-            qeN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, (f0 + 2 * IGD_WAVE) * 4, 0);
-            batch(IGD_WAVE, qs_, qe_);
-        }
-        for (int p = 2 * IGD_WAVE; p < c0; p += IGD_WAVE) {
-#else
         int qsN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + IGD_WAVE) * 4, 0);
         int qeN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, (f0 + IGD_WAVE) * 4, 0);
         batch(0, R.qs, R.qe);
         for (int p = IGD_WAVE; p < c0; p += IGD_WAVE) {
-#endif
             const int qs_ = qsN, qe_ = qeN;
             qsN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + p + IGD_WAVE) * 4, 0);
             qeN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, (f0 + p + IGD_WAVE) * 4, 0);
@@ -605,7 +386,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // term B: #{q of this tile: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
-    if (un != 0) {
+    if (un != 0 && !(IGD_D_EXP & 1)) {
         const int levels = 32 - __builtin_clz((unsigned)c0), top = 1 << levels;
         if (inLds) {
             for (int k = c0 + lane; k < top - 1; k += IGD_WAVE) sb[k] = 65535;
@@ -657,11 +438,14 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
         if (r == IGD_SLOTS && !push) { cnt[r] = 0; break; }              // (no query is placed beyond the unit's own positions then)
         const int h = (int)hist[r * IGD_WAVE + lane];
         hist[r * IGD_WAVE + lane] = 0u;
-        const int inc = wave_inclusive_sum(h);
+        const int inc = (IGD_D_EXP & 4) ? h : wave_inclusive_sum(h);
         cnt[r] += nFirst - (carry + inc) + (r < IGD_SLOTS ? nBack : 0);
         carry += __builtin_amdgcn_readlane(inc, 63);
-        if (R.a[r] == 0u || !keep[r]) cnt[r] = 0;
+        bool keep = true;
+        if (USE_V) { keep = (X[r] >> 16) >= a.v; X[r] &= 0xFFFF; }
+        if (R.a[r] == 0u || !keep) cnt[r] = 0;
     }
+    if (USE_V && !push) X[IGD_SLOTS] = 0;
     if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;      // (position 320 of a unit without appended records / 384)
     if (push && lane == 0) hist[(IGD_SLOTS + 1) * IGD_WAVE] = 0u;
     if (GLOBAL) {
@@ -670,7 +454,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
         for (int r = 0; r <= IGD_SLOTS; r++) {
             const int c = cnt[r];
             t += c;
-            if (c) atomicAdd((u64 *)((char *)a.hitsOut + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
+            if (c) atomicAdd((u64 *)((char *)a.hitsOut + ((size_t)X[r] << 3)), (u64)(unsigned)c);
         }
         if (a.totalOut) {
             for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
@@ -678,18 +462,20 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
         }
     } else {
 #pragma unroll
-        for (int r = 0; r <= IGD_SLOTS; r++)
-            if (cnt[r]) atomicAdd(hits32 + R.x[r], (unsigned)cnt[r]);
+        for (int r = 0; r <= IGD_SLOTS; r++) {
+            if (IGD_D_EXP & 8) { asm volatile("" ::"v"(cnt[r]), "v"(X[r])); continue; }
+            if (cnt[r]) atomicAdd(hits32 + X[r], (unsigned)cnt[r]);
+        }
     }
 }
 
 // The DIRECT scan kernel: 2 workgroups of 12 waves per CU (6 waves per SIMD, like the full build of igd_scan_sorted).
 template <bool USE_V>
-__global__ __launch_bounds__(IGD_WG_RANK) __attribute__((amdgpu_waves_per_eu(IGD_WPE_RANK, IGD_WPE_RANK))) void igd_scan_direct(DirK K)
+__global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_WPE_DIR, IGD_WPE_DIR))) void igd_scan_direct(DirK K)
 {
     const DbView &db = K.db;
     const DirArgs &a = K.a;
-    if (__builtin_amdgcn_readfirstlane(KARGD(a.ctl)[CTL_UNSORTED]) == a.epoch) return;    // k_tile_bounds found the contigs out of order
+    if (__builtin_amdgcn_readfirstlane(KARGD(a.ctl)[CTL_UNSORTED]) == a.epoch) return;    // the bounds kernel found the keys out of order
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -699,11 +485,11 @@ __global__ __launch_bounds__(IGD_WG_RANK) __attribute__((amdgpu_waves_per_eu(IGD
     unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)KARGD(a.wldsBytes));
     unsigned int *hist = (unsigned int *)(sl + IGD_D_SL);
     unsigned short *sb = (unsigned short *)(hist + IGD_D_H);
-    for (int f = threadIdx.x; f < nFiles; f += IGD_WG_RANK) hits[f] = 0u;
+    for (int f = threadIdx.x; f < nFiles; f += IGD_WG_DIR) hits[f] = 0u;
     for (int k = lane; k < IGD_D_SL; k += IGD_WAVE) sl[k] = 65535;
     for (int k = lane; k < IGD_D_H; k += IGD_WAVE) hist[k] = 0u;
     __syncthreads();
-    constexpr int wavesPerWG = IGD_WG_RANK / IGD_WAVE;
+    constexpr int wavesPerWG = IGD_WG_DIR / IGD_WAVE;
     const int gwave = (int)blockIdx.x * wavesPerWG + wid;
     const int nwaves = gridDim.x * wavesPerWG;
     unsigned spent = 0u;
@@ -770,7 +556,7 @@ __global__ __launch_bounds__(IGD_WG_RANK) __attribute__((amdgpu_waves_per_eu(IGD
     {
         const int nf = KARGD(db.nFiles);
         unsigned int *row32 = (unsigned int *)KARGD(a.out) + (size_t)blockIdx.x * nf;
-        for (int f = threadIdx.x; f < nf; f += IGD_WG_RANK) row32[f] = hits[f];
+        for (int f = threadIdx.x; f < nf; f += IGD_WG_DIR) row32[f] = hits[f];
     }
 }
 
@@ -829,3 +615,5 @@ __device__ __forceinline__ void direct_tail_body(const DbView &db, const DirArgs
         run(u, f0, b.firstQ[tl + 1] - f0, INT_MIN);
     }
 }
+#undef DA
+#undef DD

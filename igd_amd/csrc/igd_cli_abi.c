@@ -299,8 +299,8 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
         t0 = now_s();
         /* position-sorted BED (the common case): tell the engine, it verifies on the device */
         int rc = !dev ? IGD_HIP_OK
-               : g_core->grp ? igdc_search_multi(g_core, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total)
-               : igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, &total);
+               : g_core->grp ? igdc_search_multi(g_core, q.ichr, q.qs, q.qe, q.n, v, rule, igdc_queries_flags(&q, g_core->nbp), hits, &total)
+               : igd_hip_search_ex(dev, q.ichr, q.qs, q.qe, q.n, v, rule, igdc_queries_flags(&q, g_core->nbp), hits, &total);
         if (rc != IGD_HIP_OK) { engine_failed("search", rc); total = 0; }
         phase("search (H2D + kernels + D2H)", &t0);
     }

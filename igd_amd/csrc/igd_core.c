@@ -441,7 +441,17 @@ int igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe)
     if (q->n > 0 && (ichr < q->ichr[q->n - 1] || (ichr == q->ichr[q->n - 1] && qs < q->qs[q->n - 1]))) q->unsorted = 1;
     q->ichr[q->n] = ichr; q->qs[q->n] = qs; q->qe[q->n] = qe;
     q->n++;
+    {
+        const int64_t len = (int64_t)qe - (int64_t)qs;
+        if (len > q->max_len) q->max_len = len > INT32_MAX ? INT32_MAX : (int32_t)len;
+    }
     return 0;
+}
+
+int igdc_queries_flags(const igdc_queries *q, int32_t nbp)
+{
+    if (!q || q->unsorted) return 0;
+    return IGD_HIP_FLAG_SORTED | (q->max_len < nbp ? IGD_HIP_FLAG_SHORT : 0);
 }
 
 /* A position-sorted BED whose chromosomes come in another order than the database numbers its contigs (`sort -k1,1
@@ -637,6 +647,7 @@ static int read_queries_text_parallel(const igdc_db *db, const char *map, size_t
             out->n += q->n;
         }
         out->unsorted |= q->unsorted;
+        if (q->max_len > out->max_len) out->max_len = q->max_len;
         igdc_queries_free(q);
     }
     return 0;

@@ -135,7 +135,12 @@ typedef struct {
     int64_t n, cap;
     int32_t *ichr, *qs, *qe;
     int32_t unsorted;        /* 0 while every pushed query was >= the previous by (contig, start) */
+    int32_t max_len;         /* largest qe - qs pushed (0 for an empty set): queries shorter than a tile let a dense sorted
+                              * file take the engine's DIRECT step (IGD_HIP_FLAG_SHORT, verified on the device) */
 } igdc_queries;
+/* the engine flags a parsed query set earns: IGD_HIP_FLAG_SORTED when it is ordered, + IGD_HIP_FLAG_SHORT when no query is
+ * as long as a tile of `nbp` bp */
+int  igdc_queries_flags(const igdc_queries *q, int32_t nbp);
 /* returns 0, or -1 when the file cannot be opened.  Lines whose contig is not in the
  * database are dropped here (the reference drops them in get_overlaps, :456-457). */
 int  igdc_read_queries(const igdc_db *db, const char *qfile, int require_chr, igdc_queries *out);

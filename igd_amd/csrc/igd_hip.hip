@@ -191,7 +191,7 @@ extern "C" int64_t igd_hip_max_batch(void) { return max_batch(); }
 // work in such a build unless IGD_HIP_ALLOW_EXP_BUILD=1 says the caller knows (tools/valu_ab.sh does).
 #define IGD_EXP_WRONG_BITS (1 | 2 | 4 | 8 | 64 | 128 | 256 | 512 | 8192 | 0x10000 | 0x20000 | 0x40000 | 0x80000 | 0x100000 | 0x200000 | 0x800000)
 extern "C" unsigned igd_hip_build_flags(void) { return ((unsigned)IGD_EXP & 0xffffffu) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
-extern "C" unsigned igd_hip_build_wrong_counts(void) { return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u); }
+extern "C" unsigned igd_hip_build_wrong_counts(void);     // (defined behind the engine's parts: igd_scan_direct's measurement bits count too)
 
 // ------------------------------------------------------------------------------------------
 // device view of one database (passed to kernels by value)
@@ -348,3 +348,7 @@ struct igd_hip_db {
 #include "engine/seqpare.hpp"         // Seqpare `-s`: kernels and host
 #include "engine/host_misc.hpp"       // igd_hip_hitmap, igd_hip_batch_stats
 #include "engine/measure.hpp"         // instrumentation: compulsory traffic, streaming rates of the box, launch profile
+extern "C" unsigned igd_hip_build_wrong_counts(void)
+{
+    return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u) | ((IGD_D_EXP & 15) ? 1u << 25 : 0u);
+}

@@ -124,7 +124,7 @@ int64_t getOverlaps(iGD_t *iGD, char *qFile, int64_t *hits)
     (void)igdc_queries_group_contigs(&q, iGD->core->nCtg);    /* a sorted BED with another chromosome order than the database's */
     if (q.n > 0) {
         int rc = igdc_search_auto(iGD->core, iGD->path, device_from_env(), q.ichr, q.qs, q.qe, q.n, IGD_HIP_NO_VALUE_FILTER,
-                                  IGD_HIP_RULE_NEST, q.unsorted ? 0 : IGD_HIP_FLAG_SORTED, hits, NULL);
+                                  IGD_HIP_RULE_NEST, igdc_queries_flags(&q, iGD->core->nbp), hits, NULL);
         if (rc != IGD_HIP_OK) { engine_failed("getOverlaps", rc); igdc_queries_free(&q); return 0; }
     }
     igdc_queries_free(&q);
