@@ -189,7 +189,7 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
     exe = os.path.join(ROOT, "bin", "igd")
     out = {"command": "bin/igd search <db> -q <the headline's 10^6-query BED> [..]", "repeats": repeats}
     for name, extra in (("q", []), ("q_v500", ["-v", "500"]), ("q_f", ["-f"])):
-        best, ok = None, None
+        best, worst, ok = None, None, None
         for _ in range(repeats if name != "q_f" else 3):
             t = time.perf_counter()
             p = subprocess.run([exe, "search", igd_path, "-q", bed_path] + extra,
@@ -199,12 +199,41 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
                 best = None
                 break
             best = dt if best is None else min(best, dt)
+            worst = dt if worst is None else max(worst, dt)
             if name == "q":
                 tot = [int(l.split(":")[1]) for l in p.stdout.decode().splitlines()[-2:] if l.startswith("Total:")]
                 ok = bool(tot) and tot[0] == expect_total
         out[name + "_seconds"] = best
+        out[name + "_seconds_slowest"] = worst
         if ok is not None:
             out["q_total_matches_gpu"] = ok
+    out["q_route"] = ("the host's threads (igd_hostpath.c: the file is below igdc_host_limit() = 250 000 queries per usable thread, <= 4e6 -- where "
+                      "the host route takes as long as the engine route's best run); q_engine_only_* = the same command with IGD_HOST_MAX_QUERIES=0")
+    # the same file sent to the GPU whatever its size, with the tool's own phase table (IGD_TIMING) of the fastest and the
+    # slowest of the repeats: what a search costs before its first kernel varies from run to run on one box
+    try:
+        runs = []
+        for _ in range(repeats):
+            t = time.perf_counter()
+            p = subprocess.run([exe, "search", igd_path, "-q", bed_path], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               env=dict(os.environ, IGD_HOST_MAX_QUERIES="0", IGD_TIMING="1"))
+            dt = time.perf_counter() - t
+            if p.returncode == 0:
+                runs.append((dt, [l for l in p.stderr.decode().splitlines() if l.startswith("[igd timing]")]))
+        if runs:
+            runs.sort(key=lambda r: r[0])
+            out["q_engine_only_seconds"] = runs[0][0]
+            out["q_engine_only_seconds_slowest"] = runs[-1][0]
+            out["q_engine_only_phases_fastest"] = runs[0][1]
+            out["q_engine_only_phases_slowest"] = runs[-1][1]
+        try:
+            pc = open("/proc/meminfo").read()
+            out["page_cache_note"] = "the .igd (%d MB) was written and read by this process before: served from the page cache; %s" % (
+                os.path.getsize(igd_path) >> 20, [l for l in pc.splitlines() if l.startswith("Cached:")][0])
+        except Exception:
+            pass
+    except Exception as e:
+        out["q_engine_only_error"] = str(e)
     # Small query files: the reference starts cheaply (header only, then the tiles the queries touch); files of at most
     # IGD_HOST_MAX_QUERIES lines are counted on the host by product code (igd_hostpath.c), larger ones go to the engine.
     # Wall time of `search -q` at every size, the reference binary's beside it, stdout compared byte for byte.
@@ -212,7 +241,7 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
         ref = os.path.join(ROOT, "oracle", "_ref", "igd")
         synth_exe = os.path.join(ROOT, "bin", "igd_synth")
         rows = []
-        for n in (1000, 10000, 100000, 300000):
+        for n in (1000, 10000, 100000, 300000, 1000000, 3000000):
             q = os.path.join(os.path.dirname(bed_path), "q%d.bed" % n)
             if not os.path.exists(q):
                 subprocess.check_call([synth_exe, "queries", q, "--n", str(n)], stdout=subprocess.DEVNULL)
@@ -223,7 +252,7 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
                 if who == "reference" and not os.path.exists(ref):
                     continue
                 best = None
-                for _ in range(5):
+                for _ in range(5 if n <= 1000000 else 3):
                     t = time.perf_counter()
                     p = subprocess.run(cmd + ["search", igd_path, "-q", q], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
                     dt = time.perf_counter() - t
@@ -236,8 +265,9 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
             row["stdout_identical"] = len(set(outs.values())) == 1 and len(outs) >= 2
             rows.append(row)
         out["small_files"] = rows
-        out["small_files_note"] = ("files of at most IGD_HOST_MAX_QUERIES queries (default 25 000 per usable host thread, 50 000 .. 400 000) "
-                                   "are counted on the host (igd_hostpath.c, product code); product_engine_only = the same file sent to the GPU")
+        out["small_files_note"] = ("files of at most IGD_HOST_MAX_QUERIES queries (default: 250 000 per usable host thread, at most 4e6 -- the size at which "
+                                   "the host route takes as long as the engine route's best run) are counted on the host (igd_hostpath.c, product code); "
+                                   "product_engine_only = the same file sent to the GPU")
     except Exception as e:
         out["small_files"] = {"error": str(e)}
     return out

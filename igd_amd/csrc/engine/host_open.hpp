@@ -249,17 +249,17 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         }
         fprintf(stderr, "igd_hip: WARNING: measurement build IGD_EXP=0x%x -- counts are WRONG on purpose\n", igd_hip_build_flags());
     }
-    int ndev = igd_hip_device_count();
-    if (ndev <= 0) {
-        if (!g_err[0]) snprintf(g_err, sizeof g_err, "igd_hip_open: no HIP device");
-        return IGD_HIP_ERR_DEVICE;
-    }
-    if (device < 0 || device >= ndev) {
-        snprintf(g_err, sizeof g_err, "igd_hip_open: device %d out of range (%d visible)", device, ndev);
-        return IGD_HIP_ERR_ARG;
-    }
-    HIPCHK(hipSetDevice(device));
-    OPEN_PHASE("HIP runtime init");
+    // Bringing up the HIP runtime is the largest single item of a command line search (50 .. 120 ms on the pool's hosts, more on
+    // some): it runs on a thread of its own while this one builds the host-side tables (24 ms for the roadmap-scale header).
+    // (Error texts are thread-local: a failure is looked at again from this thread below.)
+    std::thread warm;
+    try {
+        warm = std::thread([device]() {
+            int n = 0;
+            if (hipGetDeviceCount(&n) == hipSuccess && device >= 0 && device < n && hipSetDevice(device) == hipSuccess) (void)hipFree(nullptr);
+        });
+    } catch (...) { }
+    struct JoinWarm { std::thread &t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{warm};
     igd_hip_db *db = new igd_hip_db();   // value-initialised: every field zero
     db->device = device;
     {   // the environment is read here, once: the per-batch entry points look at nothing but the handle
@@ -335,13 +335,31 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         return IGD_HIP_ERR_ARG;
     }
     db->nUnits = (int32_t)units.size();
+    OPEN_PHASE("host tables");
+    if (warm.joinable()) warm.join();
+    {
+        const int ndev = igd_hip_device_count();
+        if (ndev <= 0) {
+            if (!g_err[0]) snprintf(g_err, sizeof g_err, "igd_hip_open: no HIP device");
+            delete db;
+            return IGD_HIP_ERR_DEVICE;
+        }
+        if (device < 0 || device >= ndev) {
+            snprintf(g_err, sizeof g_err, "igd_hip_open: device %d out of range (%d visible)", device, ndev);
+            delete db;
+            return IGD_HIP_ERR_ARG;
+        }
+        const hipError_t e_ = hipSetDevice(device);
+        if (e_ != hipSuccess) { set_err("hipSetDevice", e_, __FILE__, __LINE__); delete db; return IGD_HIP_ERR_DEVICE; }
+    }
+    OPEN_PHASE("HIP runtime init (beside the tables)");
 
     int rc;
     int64_t *acct = &db->resident;
 #define TRY(x) do { rc = (x); if (rc != IGD_HIP_OK) { igd_hip_close(db); return rc; } } while (0)
 #define TRYHIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_err(#x, e_, __FILE__, __LINE__); igd_hip_close(db); return IGD_HIP_ERR_DEVICE; } } while (0)
     TRYHIP(hipStreamCreateWithFlags(&db->stream, hipStreamNonBlocking));
-    OPEN_PHASE("host tables, stream");
+    OPEN_PHASE("stream");
     size_t n = (size_t)d->nRecords;
     {   // launch geometry first: the slab is part of the arena
         int cus = 0;                                     // one attribute, not hipGetDeviceProperties (~30 ms)

@@ -256,9 +256,9 @@ static void *parse_run(void *arg)
 }
 
 /* a file of at most igdc_host_limit() queries, while no engine is resident: counted on the host (igd_hostpath.c) */
-static igdc_map *host_map(int64_t nq)
+static igdc_map *host_map_lim(int64_t nq, int64_t lim)
 {
-    if (!g_core || g_core->dev || nq > igdc_host_limit()) return NULL;
+    if (!g_core || g_core->dev || nq > lim) return NULL;
     const int fd = g_core_path ? open(g_core_path, O_RDONLY) : (fP ? dup(fileno(fP)) : -1);
     if (fd < 0) return NULL;
     g_core->nFiles = cur_igd()->nFiles;          /* hits[] is sized from the TSV (:923-925) */
@@ -286,7 +286,7 @@ static int64_t file_query(const char *qFile, int32_t v, int rule, int64_t *hits)
         phase("contig runs put into the database's order", &t0);
     else if (q.unsorted && timing_on())                                   /* one out-of-place line is enough */
         fprintf(stderr, "[igd timing] the query file is not position-sorted: the engine groups it (bucket path)\n");
-    igdc_map *hm = q.n > 0 ? host_map(q.n) : NULL;
+    igdc_map *hm = q.n > 0 ? host_map_lim(q.n, igdc_host_limit()) : NULL;
     int onHost = 0;
     if (hm) {
         onHost = igdc_search_host(g_core, hm, q.ichr, q.qs, q.qe, q.n, v, rule, hits, &total) == 0;   // (fails only on a read error: hits[] untouched)
@@ -564,7 +564,7 @@ static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, c
 static int64_t enumerate_and_print(const igdc_queries *q, char **names)
 {
     if (q->n == 0) return 0;
-    igdc_map *hm = host_map(q->n);
+    igdc_map *hm = host_map_lim(q->n, igdc_host_limit_enum());
     igd_hip_db *dev = hm ? NULL : engine();
     if (!hm && !dev) return 0;
     iGD_t *G = cur_igd();

@@ -103,7 +103,8 @@ int64_t igdc_walk_one(const igdc_db *db, int fd, int32_t ichr, int32_t qs, int32
  * fallback: the choice depends on the number of queries only, never on whether a device is usable; larger files have
  * no CPU path.  The engine's own entry points (igd_hip.h) never come here. */
 typedef struct igdc_map igdc_map;
-int64_t   igdc_host_limit(void);
+int64_t   igdc_host_limit(void);                            /* counting searches: 250 000 queries per usable thread, <= 4e6 */
+int64_t   igdc_host_limit_enum(void);                       /* `-f`: 25 000 per usable thread */
 int       igdc_host_probably_small(const char *qfile);       /* by file size: parse it before starting the engine */
 igdc_map *igdc_map_open(const igdc_db *db, int fd);           /* fd stays the caller's */
 void      igdc_map_close(igdc_map *m);

@@ -33,24 +33,47 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-/* Where the engine starts to pay.  Measured on the pool's host (2 x EPYC 9575F, 16 counting threads) with the roadmap-scale
- * database, wall time of `igd search -q` (tools/cli_small_probe.py --gpu, profiles/r04/cli_small.txt): the engine costs a fixed
- * 0.15-0.2 s (HIP start-up + 851 MB upload) whatever the file holds; the host counts ~2 x 10^5 queries per 40 ms with 16
- * threads (10^5: 19 ms vs 195 ms on the engine and 120 ms for the reference; 1.5 x 10^5: 32 ms), i.e. the two meet near 10^6
- * queries there -- and near 1.3 x 10^5 on a host whose threads do not scale (the 8-vCPU build sandbox: 1.4 us per query
- * whatever the thread count).  The limit follows the threads that are there: 25 000 queries per usable thread, between
- * 50 000 and 400 000. */
-int64_t igdc_host_limit(void)
+/* Where the engine starts to pay: a model of two measured rates, not a constant.
+ *   engine route  t_e(n) = F + n * p        F = what a command line search costs before its first kernel -- HIP runtime,
+ *                                           851 MB through PCIe, transposes: 0.18 s at best on the pool's hosts (2 x EPYC 9575F
+ *                                           + MI355X), 0.40-0.48 s in every third run of the same command on the same box
+ *                                           (runtime start-up and first allocations vary that much; profiles/r05/cli_walls.txt);
+ *                                           p = 7 ns per query (the threaded parser; the kernels are below 0.1 ns)
+ *   host route    t_h(n) = 0.03 s + n * h / T   h = 0.55 us per query and counting thread (the reference's per-query algorithm
+ *                                           over pread, this file), T = min(threads, 16): measured 0.068 / 0.087 / 0.166 s for
+ *                                           1 / 2 / 4 x 10^6 queries at T = 16, 0.086 / 0.118 / 0.170 s at T = 8
+ * t_h(n) = t_e(n) with F = 0.18 s gives n = 0.15 s * T / 0.53 us = 280 000 * T: the limit is 250 000 queries per usable thread,
+ * at most 4 x 10^6 -- where the host route takes as long as the engine route's BEST run (reference: 1.13 s).  A host whose
+ * threads do not scale (the 8-vCPU build sandbox: 1.4 us per query whatever T) would want a lower limit; there is no way to know
+ * without timing, so IGD_HOST_MAX_QUERIES overrides it (0: every file goes to the GPU).
+ * `-f` prints ~35 bytes per overlap and its host route formats on fewer threads: it keeps the round-4 limit (25 000 per thread). */
+static int64_t host_threads_usable(void)
+{
+    long t = sysconf(_SC_NPROCESSORS_ONLN);
+    if (t > 16) t = 16;
+    if (t < 2) t = 2;
+    return t;
+}
+static int64_t host_limit_env(void)
 {
     const char *e = getenv("IGD_HOST_MAX_QUERIES");
     if (e && *e) {
         const long long x = atoll(e);
         return x < 0 ? 0 : (int64_t)x;
     }
-    long t = sysconf(_SC_NPROCESSORS_ONLN);
-    if (t > 16) t = 16;
-    if (t < 2) t = 2;
-    return 25000 * (int64_t)t;
+    return -1;
+}
+int64_t igdc_host_limit(void)
+{
+    const int64_t e = host_limit_env();
+    if (e >= 0) return e;
+    const int64_t lim = 250000 * host_threads_usable();
+    return lim > 4000000 ? 4000000 : lim;
+}
+int64_t igdc_host_limit_enum(void)
+{
+    const int64_t e = host_limit_env();
+    return e >= 0 ? e : 25000 * host_threads_usable();
 }
 
 /* a query file of `bytes` bytes can be expected to hold at most the limit's number of lines (a BED3 line of a human

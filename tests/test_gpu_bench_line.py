@@ -51,9 +51,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert "query_layout" in j["config"]
         e2e = j["cli_end_to_end"]
         small = e2e["small_files"]
-        assert [row["queries"] for row in small] == [1000, 10000, 100000, 300000] and all(row["product_seconds"] > 0 for row in small)
+        assert [row["queries"] for row in small] == [1000, 10000, 100000, 300000, 1000000, 3000000] and all(row["product_seconds"] > 0 for row in small)
         assert all(row["stdout_identical"] for row in small if "reference_seconds" in row)
         assert e2e["q_seconds"] > 0 and e2e["q_v500_seconds"] > 0 and e2e["q_f_seconds"] > 0 and e2e["q_total_matches_gpu"] is True
+        # the engine route's own seconds with the tool's phase table of the fastest and the slowest repeat
+        assert e2e["q_engine_only_seconds"] > 0 and e2e["q_engine_only_seconds_slowest"] >= e2e["q_engine_only_seconds"]
+        assert any("HIP runtime init" in l for l in e2e["q_engine_only_phases_fastest"]) and e2e["q_engine_only_phases_slowest"]
         assert c["host"]["cpu_model"] and c["host"]["logical_cpus"] >= 1
         c = j["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == j["unit"] and c["sample"]

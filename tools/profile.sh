@@ -37,7 +37,7 @@ try:
     best = -1
     for k in f:
         # the variant of the timed steps: most launches (set-up code may run another variant once; the gated twin reads ~nothing)
-        if ("igd_scan_sorted" in k or "igd_scan_tiles" in k) and f[k] > 1000 and nf[k] > best:
+        if ("igd_scan_sorted" in k or "igd_scan_tiles" in k or "igd_scan_direct" in k) and f[k] > 1000 and nf[k] > best:
             best = nf[k]
             res = {"kernel": k, "launches_sampled": nf[k], "FETCH_SIZE_KB": f[k], "WRITE_SIZE_KB": w.get(k, 0.0),
                    "hbm_bytes_per_launch": int((2 * f[k] + w.get(k, 0.0)) * 1024),
