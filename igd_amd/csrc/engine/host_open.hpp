@@ -384,11 +384,12 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         {   // igd_scan_sorted: counters + per wave (sorted starts, histogram, the tile's query starts).  The last array takes
             // what two workgroups per CU leave of the 160 KiB: tiles with more queries bisect the caller's array instead
             const int hitB = db->ldsHits ? (int)((((size_t)db->winN * 4) + 15) & ~(size_t)15) : 0;   // (32-bit counters: CNT32)
-            int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;   // the full build: 2 workgroups per CU
+            constexpr int waveLds = IGD_D_WLDS > IGD_WLDS_BYTES ? IGD_D_WLDS : IGD_WLDS_BYTES;        // (igd_scan_direct's areas are the larger ones)
+            int spare = (160 * 1024 / 2 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - waveLds;   // the full build: 2 workgroups per CU
             db->sbCap = 0;                               // a power of two (s_compute pads the array to one)
             for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
             if (db->sbCap == 0) {                        // counters that leave two workgroups per CU nothing: one workgroup, with the arrays
-                spare = (160 * 1024 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - IGD_WLDS_BYTES;
+                spare = (160 * 1024 - 512 - hitB) / (IGD_WG_RANK / IGD_WAVE) - waveLds;
                 for (int c = 64; c <= 2048 && c <= spare / 2; c <<= 1) db->sbCap = c;
             }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);

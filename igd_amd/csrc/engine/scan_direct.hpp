@@ -31,7 +31,7 @@
 // batches per unit, the second nearly empty, and a sixth slot per unit cost what the pre-pass saves.
 
 #ifndef IGD_D_EXP
-#define IGD_D_EXP 0             // measurement only (WRONG counts): 1 no term B, 2 no search in term A, 4 no prefix sums, 8 no flush, 16 no order check
+#define IGD_D_EXP 0             // measurement only (WRONG counts): 1 no term B, 2 no search in term A, 4 no prefix sums, 8 no flush, 16 no order check, 32 no records of the next tile
 #endif
 #ifndef IGD_WG_DIR
 #define IGD_WG_DIR IGD_WG_RANK  // threads per workgroup / waves per SIMD of igd_scan_direct (2 workgroups per CU)
@@ -219,7 +219,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     // ---- the unit's starts, and behind them (first unit) the starts of the next tile's first records, + W ----
     // Lanes past the unit's last record hold W + 1 there: above every own start (<= W), not above any appended one (>= W + 1),
     // so the array stays sorted and a query that ends inside the tile is placed at the unit's end as before.
-    const bool push = first && !dead && nextTile;
+    const bool push = first && !dead && nextTile && !(IGD_D_EXP & 32);
     const unsigned padv = push ? (unsigned)W + 1u : 65535u;
     // (s' = the inverted low half of the record word; a lane without a record holds 0 there, i.e. 65535 inverted: one `not`
     // and one 16-bit `min` with the padding value per slot)

@@ -350,5 +350,5 @@ struct igd_hip_db {
 #include "engine/measure.hpp"         // instrumentation: compulsory traffic, streaming rates of the box, launch profile
 extern "C" unsigned igd_hip_build_wrong_counts(void)
 {
-    return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u) | ((IGD_D_EXP & 15) ? 1u << 25 : 0u);
+    return (((unsigned)IGD_EXP) & (unsigned)IGD_EXP_WRONG_BITS) | (IGD_EXP_NOMATCH ? 1u << 24 : 0u) | ((IGD_D_EXP & 47) ? 1u << 25 : 0u);
 }

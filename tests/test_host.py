@@ -478,7 +478,8 @@ def test_contig_runs_of_a_sorted_bed_are_put_into_the_databases_order(N):
     L = N.cli()
 
     class Q(C.Structure):
-        _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("ichr", N.i32p), ("qs", N.i32p), ("qe", N.i32p), ("unsorted", C.c_int32)]   # igd_core.h
+        _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("ichr", N.i32p), ("qs", N.i32p), ("qe", N.i32p), ("unsorted", C.c_int32),
+                    ("max_len", C.c_int32)]   # igd_core.h
     L.igdc_queries_push.argtypes = [C.POINTER(Q), C.c_int32, C.c_int32, C.c_int32]
     L.igdc_queries_group_contigs.argtypes = [C.POINTER(Q), C.c_int32]
     L.igdc_queries_group_contigs.restype = C.c_int
@@ -509,3 +510,50 @@ def test_contig_runs_of_a_sorted_bed_are_put_into_the_databases_order(N):
         before, flag = rows_of(q), q.unsorted
         assert L.igdc_queries_group_contigs(C.byref(q), 6) == 0 and rows_of(q) == before and q.unsorted == flag
         L.igdc_queries_free(C.byref(q))
+
+
+def test_a_parsed_query_set_earns_its_engine_flags(N):
+    """igdc_queries_flags: IGD_HIP_FLAG_SORTED (1) when every pushed query was >= the one before by (contig, start), and
+    IGD_HIP_FLAG_SHORT (16) on top when no query is as long as a tile -- what lets a dense file take the engine's DIRECT step.
+    Both are statements the device verifies; here: that the reader makes them exactly when they hold, also across the
+    seams of the threaded parser."""
+    L = N.cli()
+    Q = N.CoreQueries
+    L.igdc_queries_push.argtypes = [C.POINTER(Q), C.c_int32, C.c_int32, C.c_int32]
+    L.igdc_queries_flags.argtypes = [C.POINTER(Q), C.c_int32]
+    L.igdc_queries_flags.restype = C.c_int
+    L.igdc_queries_free.argtypes = [C.POINTER(Q)]
+    nbp = 16384
+    for rows, want in (([(0, 10, 500), (0, 10, 16393), (1, 5, 6)], 1 | 16),          # longest = 16383 < nbp
+                       ([(0, 10, 500), (0, 10, 16394), (1, 5, 6)], 1),               # one query a tile long
+                       ([(0, 10, 500), (0, 9, 20)], 0),                              # out of order: no promise at all
+                       ([(0, 100, 90), (0, 100, 100)], 1 | 16),                      # inverted / zero-length: "short"
+                       ([], 1 | 16)):
+        q = Q()
+        for c, s, e in rows:
+            assert L.igdc_queries_push(C.byref(q), c, s, e) == 0
+        assert L.igdc_queries_flags(C.byref(q), nbp) == want, rows
+        L.igdc_queries_free(C.byref(q))
+    # through the reader (threaded for files above 1 MiB): the longest query sits in the middle of a large file
+    d = short_tmpdir("igf")
+    try:
+        from igd_amd import synth
+        p = os.path.join(d, "s.igd")
+        synth.make_db(p, files=3, per_file=50, seed=2, genome=synth.SMALL)
+        ichr, qs, qe = synth.make_queries(80000, seed=3, genome=synth.SMALL, min_len=10, max_len=900, sorted_=True)
+        db = L.igdc_open(p.encode())
+        assert db
+        for longest, want in ((None, 1 | 16), (16384, 1), (16383, 1 | 16)):
+            a, b, c2 = ichr.copy(), qs.copy(), qe.copy()
+            if longest is not None:
+                c2[40000] = b[40000] + longest
+            bed = os.path.join(d, "q.bed")
+            synth.write_bed(bed, synth.SMALL, a, b, c2)
+            assert os.path.getsize(bed) > (1 << 20)
+            q = Q()
+            assert L.igdc_read_queries(db, bed.encode(), 1, C.byref(q)) == 0 and q.n == 80000
+            assert L.igdc_queries_flags(C.byref(q), nbp) == want, longest
+            L.igdc_queries_free(C.byref(q))
+        L.igdc_close(db)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -9,7 +9,10 @@ dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 keys = {"sorted": "hits/sorted/q1000000", "shuffled": "hits/shuffled/q1000000", "v500": "v/sorted/q1000000",
         "dense": "hits/sorted/q12500000", "slab8": "hits/sorted/q12500000/slab0of8", "exact": "hits/sorted/q1000000/exact", "auto": None}
-traffic = {}
+try:
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic.json")))      # entries of earlier rounds stay until re-measured
+except Exception:
+    traffic = {}
 for tag, key in keys.items():
     src = os.path.join(root, "gpurun_out", "profile_" + tag)
     if not os.path.isdir(src):
@@ -27,7 +30,7 @@ for tag, key in keys.items():
     except Exception:
         pass
 for tag in ("sorted", "dense", "slab8"):                  # instruction mix of the scan kernel / of k_query_bounds (tools/pmc_any.sh)
-    for kern in ("scan", "qb"):
+    for kern in ("scan", "qb", "direct"):
         src = os.path.join(root, "gpurun_out", "pmc_%s_%s" % (kern, tag), "summary.txt")
         if os.path.exists(src):
             os.makedirs(os.path.join(dst, "pmc"), exist_ok=True)

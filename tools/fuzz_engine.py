@@ -60,14 +60,18 @@ def main():
             srt = (ichr[o], qs[o], qe[o])
             msg = []
             orc = Oracle(path)
-            for build in ("", "0", "1"):
-                if build: os.environ["IGD_HIP_RANK"] = build
-                else: os.environ.pop("IGD_HIP_RANK", None)
+            for build in ("", "0", "1", "D"):
+                # "D" (round 5): every promised-sorted batch takes the DIRECT step (engine/scan_direct.hpp) over the file's own tiles
+                for k in ("IGD_HIP_RANK", "IGD_HIP_DIRECT", "IGD_HIP_NO_RETILE"): os.environ.pop(k, None)
+                if build == "D": os.environ["IGD_HIP_DIRECT"] = "1"; os.environ["IGD_HIP_NO_RETILE"] = "1"
+                elif build: os.environ["IGD_HIP_RANK"] = build
                 db = Database(path)
                 for v in (0, int(rng.choice([1, 300, 900]))):
                     want, wtot = orc.search(ichr, qs, qe, v)
-                    for q, flags in ((srt, 1), (srt, 0), ((ichr, qs, qe), 0), ((ichr, qs, qe), 2)):
+                    for q, flags in ((srt, 1), (srt, 17), (srt, 0), ((ichr, qs, qe), 0), ((ichr, qs, qe), 2)):
                         if build and flags == 2: continue
+                        if build == "D" and (q is not srt or flags == 0): continue
+                        if build != "D" and flags == 17 and build: continue
                         got, gtot = db.search(*q, v, flags=flags)
                         if gtot != wtot or not np.array_equal(got, want):
                             msg.append("build=%r v=%d flags=%d sorted=%s: total %d vs %d" % (build, v, flags, q is srt, gtot, wtot))
