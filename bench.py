@@ -588,11 +588,18 @@ def extra_configs(db, dev, stream, args, box):
     for tag, kw, rows in (("cl300x40000", dict(files=300, per_file=40000, seed=77, genome=synth.HG38, clustered=True),
                            [("stress: clustered database (300 files x 40 000 intervals, half around 2000 hot spots: %d tile records) "
                              "+ 10^6 position-sorted queries", base, 0, 1, 30, "clustered_q1000000_v0")]),
+                          ("clrm1900x26316", dict(files=1900, per_file=26316, seed=1000, genome=synth.HG38, clustered=True),
+                           [("stress: the roadmap-scale database with real-data clustering (1900 files x 26 316 intervals, half of them around 2000 "
+                             "hot spots: %d tile records, tiles of 10^2 .. 10^4 records) + the headline's 10^6 position-sorted queries", base, 0, 1, 30,
+                             "clustered_roadmap_q1000000_v0"),
+                            ("stress: the same clustered roadmap-scale database, -v 500 (%d tile records)", base, 500, 1, 30, "clustered_roadmap_q1000000_v500")]),
                           ("sparse100x1000", dict(files=100, per_file=1000, seed=31, genome=synth.HG38),
                            [("stress: sparse database (100 files x 1000 intervals: %d tile records, most tiles empty) + 10^6 position-sorted "
                              "queries of 100-40 000 bp, rule NEST (quirk #1 at scale)", None, 0, 1, 30, "sparse_q1000000_v0"),
                             ("stress: the same sparse database and queries under `-v 1` (rule FLAT: later tiles count behind an empty "
                              "first tile; %d tile records)", None, 1, 1, 30, "sparse_q1000000_v1")])):
+        if tag == "clrm1900x26316" and not (args.files == 1900 and args.per_file == 26316):
+            continue                                        # (a row of the full-size run only)
         try:
             op = os.path.join(args.dir, tag + ".igd")
             if not os.path.exists(op + ".done"):

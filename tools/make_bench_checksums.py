@@ -37,6 +37,8 @@ def stress_piled(span, Q=1000000):
 OTHER_DBS = {
     "cl300x40000": dict(files=300, per_file=40000, seed=77, genome=synth.HG38, clustered=True),
     "sparse100x1000": dict(files=100, per_file=1000, seed=31, genome=synth.HG38),
+    # the roadmap-scale database with real-data clustering: half of its 5e7 intervals around 2000 hot spots
+    "clrm1900x26316": dict(files=1900, per_file=26316, seed=1000, genome=synth.HG38, clustered=True),
 }
 
 
@@ -69,6 +71,7 @@ def main():
         "piled_10tiles_q1000000": (stress_piled(10), (0,)),
         # ... and the stress databases (`@name`: OTHER_DBS), each with the headline's 10^6 position-sorted queries
         "clustered_q1000000@cl300x40000": (base, (0,)),
+        "clustered_roadmap_q1000000@clrm1900x26316": (base, (0, 500)),
         # (sparse: 59 % of the tiles are empty and the queries reach up to three tiles on -- rule NEST drops a third of what rule
         #  FLAT, `-v 1`, counts: quirk #1 of SURVEY.md at scale)
         "sparse_q1000000@sparse100x1000": (synth.make_queries(1000000, seed=7, genome=synth.HG38, min_len=100, max_len=40000, sorted_=True), (0, 1)),
