@@ -112,6 +112,7 @@ IGD_HIP_FLAG_SORTED = 1
 IGD_HIP_FLAG_BUCKET = 2
 IGD_HIP_FLAG_EXACT = 4
 IGD_HIP_FLAG_ZERO_FIRST = 8
+IGD_HIP_FLAG_SHORT = 16        # with SORTED: no query is as long as a tile (verified on the device; dense batches take the DIRECT step)
 IGD_HIP_ERR_UNSORTED = -4
 
 _hip = None

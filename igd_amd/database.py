@@ -126,7 +126,8 @@ class Database:
     def search_dev(self, d_ichr, d_qs, d_qe, nq, d_hits, d_total=None, v=0, rule=None,
                    value_filter=None, stream=None, flags=0):
         """Resident batch: arguments are device pointers (ints).  Asynchronous.
-        flags: 0, IGD_HIP_FLAG_SORTED (verified promise; sync() raises if broken) or IGD_HIP_FLAG_BUCKET."""
+        flags: 0, IGD_HIP_FLAG_SORTED (verified promise; sync() raises if broken) [| IGD_HIP_FLAG_SHORT: no query as long as a tile,
+        verified too -- a dense batch then takes the DIRECT step] or IGD_HIP_FLAG_BUCKET."""
         if rule is None:
             rule, vf = self.cli_dispatch(self.gtype, v)
         else:
