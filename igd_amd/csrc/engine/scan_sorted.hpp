@@ -91,14 +91,19 @@ struct Raw2 {
 // whole kernel (loop-invariant SGPRs) and a unit only moves soffset (= its first byte) and num_records (= its end):
 // two scalar instructions per array instead of a 64-bit address computation.  BIG = the image is beyond the 4 GiB a
 // 32-bit soffset reaches (> 2^30 records): per-unit base addresses, as igd_scan_tiles does.
-template <bool USE_V, bool BIG>
+// PLAIN (the lean build's own loop): kk < 64 names a lane that holds a unit of the round or zeros (a round is IGD_ROUND =
+// 62 units: the two lanes past it stay empty, so the loop's look-ahead needs neither a `valid` flag nor a wrap), and no
+// far unit gets here (they are listed for far_units_body) -- a dozen scalar instructions per unit that a kernel bound by
+// instruction issue does not have to spare.
+template <bool USE_V, bool BIG, bool PLAIN = false>
 __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, const SRegs &L, int kk, bool valid, int lane, Raw2 &R)
 {
-    const int kq = kk & 63;
+    const int kq = PLAIN ? kk : kk & 63;
     int c0 = __builtin_amdgcn_readlane(L.c0, kq), ln = __builtin_amdgcn_readlane(L.ln, kq);
-    if (!valid) { c0 = 0; ln = 0; }
+    if (!PLAIN && !valid) { c0 = 0; ln = 0; }
     const int f0 = __builtin_amdgcn_readlane(L.f0, kq);
-    const int n = (c0 | ln) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
+    // (SRegs::n is 0 already for a unit nobody asks about: set where the round's descriptors are read)
+    const int n = (PLAIN || (c0 | ln)) ? __builtin_amdgcn_readlane(L.n, kq) : 0;
     R.c0 = c0; R.ln = ln; R.f0 = f0; R.n = n;
     const unsigned offLo = (unsigned)__builtin_amdgcn_readlane(L.offLo, kq);
     const int vo4 = lane * 4, vo2 = lane * 2;
@@ -148,10 +153,18 @@ __device__ __forceinline__ void s_issue(const DbView &db, const SortArgs &a, con
     // of later[] words, or two when the candidate range crosses a block boundary; none for the 71 % of the units no query
     // reaches as a later tile -- and behind them the first-tile words.  Lanes outside either run are out of the buffers'
     // range: they read 0 (no memory access at all when a run is empty).
-    const int nA = IGD_LN_FAR(ln) ? 0 : IGD_LN_A(ln), nB = IGD_LN_FAR(ln) ? 0 : IGD_LN_B(ln);
+    const bool isFar = !PLAIN && IGD_LN_FAR(ln);
+    const int nA = isFar ? 0 : IGD_LN_A(ln), nB = isFar ? 0 : IGD_LN_B(ln);
     const int nl = nA + nB;
     const int b0 = c0 < IGD_WAVE - nl ? c0 : IGD_WAVE - nl;
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, (f0 + b0) * 4, 0x00020000);
+    // (PLAIN, image below 4 GiB: the end of the first batch's words was worked out with the round's descriptors -- SRegs::offHi)
+    const int qEnd = (PLAIN && !BIG) ? __builtin_amdgcn_readlane(L.offHi, kq) : (f0 + b0) * 4;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void *)a.qw0, 0, qEnd, 0x00020000);
+    if (PLAIN && nl == 0) {                                                            // 71 % of the units: no later[] words to ask for
+        R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, vo4, f0 * 4, 0);
+        R.lw = 0;
+        return;
+    }
     int voq = vo4;
     if (nl) voq = lane < nl ? 0x7FFFFF00 : vo4 - nl * 4;                               // (the later-tile lanes: far out of range)
     R.q = ~(int)__builtin_amdgcn_raw_buffer_load_b32(rs0, voq, f0 * 4, 0);             // before / past the tile's queries: ~0 = IGD_NEVER
@@ -301,12 +314,11 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                                           u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u)
 {
     const int c0 = R.c0, ln = R.ln;
-    if ((c0 | ln) == 0) return;                          // nobody asks about this unit
 #if IGD_EXP & 1024
     const u64 t_unit = __builtin_amdgcn_s_memtime();
 #endif
     const int un = R.n;
-    if (un == 0) return;                                 // placeholder of an empty tile
+    if (un == 0) return;                                 // placeholder of an empty tile, or nobody asks about this unit (s_issue: n = 0 then)
     const int f0 = R.f0;
     int cnt[IGD_SLOTS];
 #pragma unroll
@@ -324,7 +336,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     // later tiles: how many entries lead the candidate list (0: none, or a `far` unit, which walks them separately), the
     // low bits of the unit's global tile number and which of the 3 tiles before it are empty (rule NEST)
     const bool far = RANK && IGD_LN_FAR(ln) && !(IGD_EXP & 8);   // (the lean build lists its far units: far_units_body)
-    const int nl = (IGD_LN_FAR(ln) || (IGD_EXP & 8) != 0) ? 0 : IGD_LN_A(ln) + IGD_LN_B(ln);
+    const int nl = ((RANK && IGD_LN_FAR(ln)) || (IGD_EXP & 8) != 0) ? 0 : IGD_LN_A(ln) + IGD_LN_B(ln);
     int g2 = 0, deadk = 0;
     if (ln) {
         g2 = IGD_LN_G2(ln);
@@ -355,12 +367,17 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             nLater = __popcll(__ballot(covers));
             w = lane < nl ? lw : w;
         }
-        for (int p = 0; p < nE; p += IGD_WAVE) {
-            // the next 64 words are on their way while these are compared (a dense tile is a chain of such batches)
-            const int wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
+        // the first batch came with the records; most units have no other (one scalar test), a dense tile is a chain of
+        // them, each on its way while the one before it is compared
+        if (nE > IGD_WAVE) {
+            int wn = (IGD_WAVE + lane < nE) ? ~a.qw0[f0 + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
             match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, w);
-            w = wn;
-        }
+            for (int p = IGD_WAVE; p < nE; p += IGD_WAVE) {
+                w = wn;
+                wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
+                match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, w);
+            }
+        } else if (nE > 0) match_words<IGD_ASM_MATCH == 1 || !RANK>(R, cnt, W, w);
         if (far)
             far_later<RANK>(a, __builtin_amdgcn_readlane(L.la, kk), ln, f0, lane, [&](int e) {
                 bool covers;
@@ -627,6 +644,13 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             // lean build: every lane adds, 0 included (no compare / exec masking -- that build is bound by instruction issue);
             // full build: lanes without hits stay out -- the lanes past a unit's end all name counter 0, and the dozens
             // of them in a unit's last slot would queue up for ONE address in an LDS the rank method keeps busy
+            if (!RANK && !few && !USE_V) {
+                // (the dataset number is a zero-extended 16-bit load the compiler masks again before it scales it: one
+                // v_mad_u32_u16 does both)
+                unsigned off;
+                asm("v_mad_u32_u16 %0, %1, 4, 0" : "=v"(off) : "v"(R.x[r]));
+                atomicAdd((unsigned int *)((char *)hits + off), (unsigned)cnt[r]);
+            } else
             if ((!RANK && !few) || cnt[r]) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
         }
     } else {
@@ -662,6 +686,7 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #ifndef IGD_XCD_REMAP
 #define IGD_XCD_REMAP 0         // 1: an XCD (blockIdx & 7) takes a contiguous eighth of every round of units
 #endif
+#define IGD_ROUND 62            // units whose descriptors a wave of the lean build reads at once, one per lane; the last two lanes stay empty (s_issue, PLAIN)
 #ifndef IGD_WG_LEAN
 #define IGD_WG_LEAN IGD_WG      // ... and of the lean build
 #define IGD_WPE_LEAN IGD_WPE
@@ -732,14 +757,14 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
     __builtin_amdgcn_s_setprio(3);
 #endif
 
-    for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_WAVE) {
+    for (int ub = gwave; ub < db.nUnits; ub += nwaves * IGD_ROUND) {
         SRegs L;
         L.offLo = L.offHi = L.n = L.jf = L.f0 = L.c0 = L.la = L.ln = 0;
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++) L.w[r] = 0;
         {
             const long long mi = (long long)ub + (long long)lane * nwaves;
-            if (mi < db.nUnits) {
+            if (lane < IGD_ROUND && mi < db.nUnits) {
                 const Unit *units = KARG(db.units);
                 const int32_t *firstQ = KARG(a.firstQ), *spill = KARG(a.spill);
                 const UnitRegs u = load_unit_regs(units + mi);
@@ -771,11 +796,17 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
                         if (!a.noList) KARG(a.farList)[atomicAdd(&KARG(a.ctlw)[CTL_NFAR + (a.epoch & 1)], 1)] = (int)mi | (heavy ? (int)0x80000000 : 0);
                         L.c0 = 0; L.ln = 0;
                     }
+                    if ((L.c0 | L.ln) == 0) L.n = 0;     // nobody asks about this unit: no loads (s_issue), nothing to compare
+                    if (!BIG) {                          // (offHi is free: < 2^30 records)
+                        const int nlL = IGD_LN_FAR(L.ln) ? 0 : IGD_LN_A(L.ln) + IGD_LN_B(L.ln);
+                        const int b0L = L.c0 < IGD_WAVE - nlL ? L.c0 : IGD_WAVE - nlL;
+                        L.offHi = (L.f0 + b0L) * 4;
+                    }
                 }
             }
         }
         int cntU = (int)(((long long)db.nUnits - ub + nwaves - 1) / nwaves);
-        if (cntU > IGD_WAVE) cntU = IGD_WAVE;
+        if (cntU > IGD_ROUND) cntU = IGD_ROUND;
 #if IGD_EXP & 32
         if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.ln)); t_desc = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -817,14 +848,14 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
         }
         // (three units in flight per wave -- the next unit's loads issued before the current one is compared -- need 74 registers,
         // i.e. 6 waves per SIMD: measured twice, 68.3 against 64.9 us on the final build; the code is gone)
-        s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
+        s_issue<USE_V, BIG, !RANK>(db, a, L, 0, true, lane, A);
         for (int kk = 0; kk < cntU; kk += 2) {
-            s_issue<USE_V, BIG>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
+            s_issue<USE_V, BIG, !RANK>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
             s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
-            s_issue<USE_V, BIG>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
+            s_issue<USE_V, BIG, !RANK>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
             if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
 #if IGD_OPT_PRIO
             done += 2;
