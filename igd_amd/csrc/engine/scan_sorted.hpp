@@ -686,6 +686,9 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
 #ifndef IGD_XCD_REMAP
 #define IGD_XCD_REMAP 0         // 1: an XCD (blockIdx & 7) takes a contiguous eighth of every round of units
 #endif
+#ifndef IGD_LEAN_SKIP
+#define IGD_LEAN_SKIP 1         // the lean build steps through the visited units only when a round has many others
+#endif
 #define IGD_ROUND 62            // units whose descriptors a wave of the lean build reads at once, one per lane; the last two lanes stay empty (s_issue, PLAIN)
 #ifndef IGD_WG_LEAN
 #define IGD_WG_LEAN IGD_WG      // ... and of the lean build
@@ -810,11 +813,15 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
 #if IGD_EXP & 32
         if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.ln)); t_desc = __builtin_amdgcn_s_memtime(); }
 #endif
-        if (RANK) {
+        // (the lean build: when more than a quarter of the round's units hold no record or are asked about by nobody -- a database
+        // with empty tiles -- it steps through the others only, like the full build; its own loop below takes every unit in turn
+        // with nothing to find out per unit, which is what a round of visited units wants)
+        const unsigned long long mVis = __ballot((L.c0 | L.ln) != 0 && L.n > 0);
+        if (RANK || (IGD_LEAN_SKIP && __popcll(mVis) * 4 < cntU * 3)) {
             // The full build also serves batches that visit a fraction of the units (one GPU's slab of config 4: one unit
             // in eight): the wave steps through the units somebody asks about only -- an unvisited one still cost its
             // dozen zero-size loads, which queue up behind everybody's real ones.
-            unsigned long long m = __ballot((L.c0 | L.ln) != 0 && L.n > 0);
+            unsigned long long m = mVis;
             const int visited = __popcll(m);
             int qd = (visited + 3) >> 2, at = qd, level = 3, nd = 0;
 #if IGD_OPT_PRIO
