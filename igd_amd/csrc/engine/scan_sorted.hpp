@@ -25,6 +25,9 @@
 #ifndef IGD_DENSE_MIN
 #define IGD_DENSE_MIN 32
 #endif
+#ifndef IGD_LEAN_SMALL
+#define IGD_LEAN_SMALL 1        // the lean build's units of <= 64 / <= 192 records take the pairwise path over one / three slots
+#endif
 
 #define IGD_WLDS_S 512                                  // u16 entries per wave: the unit's sorted s' (+ sentinels)
 #define IGD_WLDS_H 328                                  // u32 entries per wave: histogram over record positions 0..320
@@ -674,6 +677,87 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
     }
 }
 
+// The lean build's unit of at most NS x 64 records (NS = 1 or 3 of the IGD_SLOTS slots): the pairwise path of s_compute over
+// the slots that can hold a record at all.  A unit costs the same instructions whether it is full or holds 30 records --
+// five summary words read out, five slots tested, five counter adds -- and on databases of small tiles (a clustered one: half of
+// the units of the roadmap-scale database hold 129 .. 192 records, a small one's units 32 on average) that fixed cost is the
+// kernel: both the vector and the ONE scalar unit of a CU are busy with it.  (LDS counters, 32-bit, more than 8 files: the
+// usual lean build; everything else takes s_compute.)
+template <bool USE_V, int NS>
+__device__ __forceinline__ void s_compute_small(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R, u64 *hits)
+{
+    const int c0 = R.c0, ln = R.ln, f0 = R.f0;
+    int cnt[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) cnt[r] = 0;
+    if (USE_V) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) {
+            if ((R.x[r] >> 16) < a.v) R.a[r] = 0u;       // fails the value filter: the word nothing matches
+            R.x[r] &= 0xFFFF;
+        }
+    }
+    const int nl = IGD_LN_A(ln) + IGD_LN_B(ln);          // (a far unit never gets here: the lean build lists it)
+    int g2 = 0, deadk = 0, nLater = 0;
+    if (ln) {
+        g2 = IGD_LN_G2(ln);
+        deadk = a.rule == IGD_HIP_RULE_NEST ? (__builtin_amdgcn_readlane(L.jf, kk) & 14) : 0;
+    }
+    const int nE = nl + c0;
+    uint32_t W[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) W[r] = (uint32_t)__builtin_amdgcn_readlane(L.w[r], kk);
+    int w = R.q;
+    if (nl) {
+        bool covers;
+        const int lw = later_word(db.nbp, R.lw, g2, deadk, lane < nl, covers);
+        nLater = __popcll(__ballot(covers));
+        w = lane < nl ? lw : w;
+    }
+    auto match = [&](int P0) {
+#pragma unroll
+        for (int r = 0; r < NS; r++) match_slot_asm<false>(cnt[r], W[r], P0, R.a[r], 0ull);
+    };
+    if (nE > IGD_WAVE) {
+        int wn = (IGD_WAVE + lane < nE) ? ~a.qw0[f0 + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
+        match(w);
+        for (int p = IGD_WAVE; p < nE; p += IGD_WAVE) {
+            w = wn;
+            wn = (p + IGD_WAVE + lane < nE) ? ~a.qw0[f0 + p + IGD_WAVE + lane - nl] : (int)IGD_NEVER;
+            match(w);
+        }
+    } else if (nE > 0) match(w);
+    if (nLater != 0) {                                   // (:510-511: a later-tile query does not count the records that start before the tile)
+#pragma unroll
+        for (int r = 0; r < NS; r++) cnt[r] -= (R.a[r] & 0xFFFFu) == 0xFFFFu ? nLater : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < NS; r++) {
+        if (!USE_V) {
+            unsigned off;
+            asm("v_mad_u32_u16 %0, %1, 4, 0" : "=v"(off) : "v"(R.x[r]));
+            atomicAdd((unsigned int *)((char *)hits + off), (unsigned)cnt[r]);
+        } else atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
+    }
+}
+
+// the lean build's unit, by how many of its slots can hold a record
+template <bool USE_V, bool CNT32, bool LDS_HITS, int FEW>
+__device__ __forceinline__ void s_compute_lean(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
+                                               u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
+                                               unsigned *spent, unsigned budget)
+{
+#if IGD_LEAN_SMALL && IGD_ASM_MATCH && IGD_EXP == 0 && !IGD_EXP_NOMATCH
+    if (CNT32 && LDS_HITS && FEW == 0) {
+        const int un = R.n;
+        if (un == 0) return;
+        if (un <= IGD_WAVE) { s_compute_small<USE_V, 1>(db, a, L, kk, lane, R, hits); return; }
+        if (un <= 3 * IGD_WAVE) { s_compute_small<USE_V, 3>(db, a, L, kk, lane, R, hits); return; }
+    }
+#endif
+    s_compute<USE_V, CNT32, false, LDS_HITS, FEW>(db, a, L, kk, lane, R, hits, sl, hist, sb, rankOK, nullptr, spent, budget);
+}
+
 // CNT32: the workgroup's private counters are 32-bit (LDS_HITS only; the host checks that no counter of the launch can
 // reach 2^32); BIG: more than 2^30 records (see s_issue).
 // The full (rank method) build wants ~82 VGPRs and ~100 SGPRs: cut to the 64 / 80 of 8 waves per SIMD it spilled 13 + 34 of
@@ -816,6 +900,8 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
         // (the lean build: when more than a quarter of the round's units hold no record or are asked about by nobody -- a database
         // with empty tiles -- it steps through the others only, like the full build; its own loop below takes every unit in turn
         // with nothing to find out per unit, which is what a round of visited units wants)
+#define IGD_UNIT(kk_, R_) do { if (RANK) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk_, lane, R_, hits, sl, hist, sb, rankOK, nullptr, &spent, budget); \
+                               else s_compute_lean<USE_V, CNT32, LDS_HITS, FEW>(db, a, L, kk_, lane, R_, hits, sl, hist, sb, rankOK, &spent, budget); } while (0)
         const unsigned long long mVis = __ballot((L.c0 | L.ln) != 0 && L.n > 0);
         if (RANK || (IGD_LEAN_SKIP && __popcll(mVis) * 4 < cntU * 3)) {
             // The full build also serves batches that visit a fraction of the units (one GPU's slab of config 4: one unit
@@ -861,9 +947,9 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
 #if IGD_EXP & 32
             if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
 #endif
-            s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk, lane, A, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+            IGD_UNIT(kk, A);
             s_issue<USE_V, BIG, !RANK>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
-            if (kk + 1 < cntU) s_compute<USE_V, CNT32, RANK, LDS_HITS, FEW>(db, a, L, kk + 1, lane, B, hits, sl, hist, sb, rankOK, nullptr, &spent, budget);
+            if (kk + 1 < cntU) IGD_UNIT(kk + 1, B);
 #if IGD_OPT_PRIO
             done += 2;
             if (done >= prioAt) {
