@@ -81,7 +81,8 @@ def parse_args(argv=None):
                          "merge-join or bucketing (no assumption, ~5 gated no-op launches extra); sorted: the caller "
                          "promises (contig,start) order -- what a position-sorted BED is -- and the device VERIFIES it "
                          "in the timed region (a broken promise is an error, never a wrong count); bucket: always "
-                         "counting-sort.  default = sorted for the position-sorted workload, auto with --shuffled")
+                         "counting-sort, no order check (what the CLI passes when its parser saw a line out of order).  default = sorted for "
+                         "the position-sorted workload, bucket with --shuffled")
     return ap.parse_args(argv)
 
 
@@ -556,7 +557,8 @@ def extra_configs(db, dev, stream, args, box):
     dense = synth.make_queries_slab(CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     slab8 = synth.make_queries_slab(8 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100, "config2_sorted_q1000000_v500"),
-             ("10^6 queries in generation order (device picks the bucket path)", shuf, 0, 0, 100, "config2_sorted_q1000000_v0"),
+             ("10^6 queries in generation order (flags = IGD_HIP_FLAG_BUCKET, what the command line tool's parser passes for a file it has seen out of order)",
+              shuf, 0, 2, 100, "config2_sorted_q1000000_v0"),
              ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, SHORT, 30, "config4_share_q12500000_v0"),
              ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, SHORT, 30,
               "config4_slab0_of_8_v0"),
@@ -750,7 +752,7 @@ def main():
     assert stream != 0
 
     if args.grouping == "default":
-        args.grouping = "auto" if args.shuffled else "sorted"
+        args.grouping = "bucket" if args.shuffled else "sorted"    # (igdc_queries_flags: what the CLI passes for an ordered / an unordered file)
     gflags = {"auto": 0, "sorted": 1, "bucket": 2}[args.grouping] | (4 if args.exact_arrays else 0)
     if args.grouping == "sorted" and not args.long_queries:
         gflags |= 16                                # IGD_HIP_FLAG_SHORT: the generator's queries are 100 .. 1999 bp (verified on the device like the order)

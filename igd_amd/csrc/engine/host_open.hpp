@@ -73,7 +73,7 @@ extern "C" void igd_hip_close(igd_hip_db *db)
     (void)hipSetDevice(db->device);
     if (db->d_rEmpty) (void)hipFree(db->d_rEmpty);
     void *ptrs[] = {db->d_start, db->d_end, db->d_idx, db->d_value, db->d_tileOff, db->d_tileCnt,
-                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far, db->d_tileD,
+                    db->d_tileBd, db->d_ctgBase, db->d_ctgNTile, db->d_tileUnit0, db->d_heavy, db->d_far, db->d_tileD, db->d_tileBits,
                     db->d_pairCnt, db->d_pairPos, db->d_blockSums, db->d_pairs, db->d_long, db->d_fix, db->d_ctl,
                     db->d_units, db->d_firstQ, db->d_pairN, db->d_pse, db->d_px, db->d_pxv,
                     db->d_slab, db->d_qc, db->d_qs, db->d_qe, db->d_hits, db->d_total, db->d_qw, db->d_later, db->d_spill, db->d_laterHdr, db->d_lpos, db->d_cov,
@@ -428,6 +428,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRY(dalloc(&db->d_units, units.size(), acct));
     TRY(dalloc(&db->d_far, units.size() + 1, acct));
     TRY(dalloc(&db->d_tileD, (size_t)nT + 1, acct));
+    TRY(dalloc(&db->d_tileBits, ((size_t)nT + 31) / 32 + 1, acct));
     TRY(dalloc(&db->d_firstQ, (size_t)nT + 2, acct));
     TRY(dalloc(&db->d_lpos, (size_t)nT + 2 + IGD_SHORT_TILES, acct));
     TRY(dalloc(&db->d_pairN, (size_t)nT + 1, acct));
@@ -442,6 +443,11 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     TRYHIP(hipMemcpy(db->d_tileOff, tileOff.data(), ((size_t)nT + 1) * 8, hipMemcpyHostToDevice));
     OPEN_PHASE("first H2D copy");
     TRYHIP(hipMemcpy(db->d_tileCnt, tileCnt.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> bits(((size_t)nT + 31) / 32 + 1, 0u);
+        for (int64_t t = 0; t < nT; t++) if (tileCnt[(size_t)t] > 0) bits[(size_t)(t >> 5)] |= 1u << (t & 31);
+        TRYHIP(hipMemcpy(db->d_tileBits, bits.data(), bits.size() * 4, hipMemcpyHostToDevice));
+    }
     TRYHIP(hipMemcpy(db->d_tileBd, tileBd.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgBase, ctgBase.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
     TRYHIP(hipMemcpy(db->d_ctgNTile, ctgNTile.data(), ((size_t)d->nCtg + 1) * 4, hipMemcpyHostToDevice));
@@ -601,7 +607,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     v.units = db->d_units; v.nUnits = db->nUnits;
 
     v.start = db->d_start; v.end = db->d_end; v.idx = db->d_idx; v.value = db->d_value;
-    v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd;
+    v.tileOff = db->d_tileOff; v.tileCnt = db->d_tileCnt; v.tileBd = db->d_tileBd; v.tileBits = db->d_tileBits;
     v.ctgBase = db->d_ctgBase; v.ctgNTile = db->d_ctgNTile; v.tileUnit0 = db->d_tileUnit0; v.cov = db->d_cov;
     OPEN_PHASE("idx check, slab");
     // compact image (see k_pack_units): needs tile-relative offsets and idx to fit 16 bits

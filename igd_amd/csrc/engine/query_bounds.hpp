@@ -30,10 +30,10 @@ __device__ __forceinline__ bool real_gate(const DbView &db, int c, int qs, bool 
 // Tile span of one query = the prologue of every reference kernel (src/igd_search.c:455-467):
 // n1=qs/nbp, n2=(qe-1)/nbp (C division), n1>mTile -> nothing, n2 clamped, and for rule NEST an
 // empty first tile ends the query (:468).  Returns false when the query visits nothing.
-__device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int qe, int rule,
-                                           int &gt0, int &ntl)
+// (the contig's two table entries -- its tiles, the number of its first one -- come from the caller: k_split_local keeps the tables in LDS)
+__device__ __forceinline__ bool query_span_at(const DbView &db, int c, int ctgTiles, int ctgFirst, int qs, int qe, int rule,
+                                              int &gt0, int &ntl)
 {
-    if (c < 0 || c >= db.nCtg) return false;
     if (db.vshift >= 0) {                     // a re-tiled copy: the file's tiles decide whether the query counts at all ...
         if (!real_gate(db, c, qs, (rule >> 8) & 1)) return false;
         if (qs < 0) qs = 0;                   // ... and a start before the contig (above -nbp of the file) lies in tile 0
@@ -41,13 +41,19 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
     }
     int n1 = tile_of(db, qs);
     int n2 = tile_of(db, (int)((unsigned)qe - 1u));
-    int mT = db.ctgNTile[c] - 1;
+    int mT = ctgTiles - 1;
     if (n1 < 0 || n1 > mT) return false;      // n1<0: out-of-bounds read in the reference
     if (n2 > mT) n2 = mT;
-    gt0 = db.ctgBase[c] + n1;
+    gt0 = ctgFirst + n1;
     if (rule == IGD_HIP_RULE_NEST && db.tileCnt[gt0] == 0) return false;
     ntl = n2 > n1 ? n2 - n1 + 1 : 1;
     return true;
+}
+__device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int qe, int rule,
+                                           int &gt0, int &ntl)
+{
+    if (c < 0 || c >= db.nCtg) return false;
+    return query_span_at(db, c, db.ctgNTile[c], db.ctgBase[c], qs, qe, rule, gt0, ntl);
 }
 
 // Control words shared by the kernels of one batch (int32 ctl[16]):

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
                                                        uint32_t *__restrict__ table, SpTuple *__restrict__ reg,
                                                        int2 *__restrict__ longList, int32_t *__restrict__ ctl, int gate,
                                                        int epoch, u64 *__restrict__ zeroHits, u64 *__restrict__ zeroTotal,
-                                                       int32_t *__restrict__ bucketLong)
+                                                       int32_t *__restrict__ bucketLong, int bitsWords, int ctgStaged, int stageCap)
 {
     {
         const int gi = blockIdx.x * SP_WG + threadIdx.x;
@@ -47,33 +47,60 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         }
     }
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
+    IGD_QSTAMP(0);                                        // (diagnostic build -DIGD_EXP=0x1000000: tools/sp_stamps.py)
     __shared__ uint32_t hist[SP_MAXC], cur[SP_MAXC], wsum[SP_WG / IGD_WAVE];
     for (int b = threadIdx.x; b < nCoarse; b += SP_WG) hist[b] = 0;
+    // "does tile t hold records" is asked once or twice per query, of tiles all over the genome: out of tileCnt[] that is a
+    // 4-byte gather that moves a cache line per query (10^6 queries: 128 MB through the L2s -- 3/4 of this kernel's time went
+    // into waiting for it); the same answers as one bit per tile are 24 KB for hg38 in 16 kbp tiles, staged in LDS
+    // ... and so are the two contig tables (ctgStaged = nCtg when they fit): with them no load is left between a query's
+    // arrival and its LDS atomics, and the queries themselves are all asked for up front -- behind the branches below the
+    // thread's four would arrive one after the other
+    extern __shared__ uint32_t sl_bits[];
+    int32_t *sCtgN = (int32_t *)(sl_bits + bitsWords), *sCtgB = sCtgN + ctgStaged;
+    int c_[SP_PER], qs_[SP_PER], qe_[SP_PER];
+#pragma unroll
+    for (int k = 0; k < SP_PER; k++) {                    // (asked for first: they come from memory, the tables below from an L2)
+        const int i = blockIdx.x * SP_Q + k * SP_WG + threadIdx.x;
+        const bool in = i < nq;
+        c_[k] = in ? ichr[i] : -1; qs_[k] = in ? qs[i] : 0; qe_[k] = in ? qe[i] : 0;
+    }
+    for (int w = threadIdx.x; w < bitsWords; w += SP_WG) sl_bits[w] = db.tileBits[w];
+    for (int c = threadIdx.x; c < ctgStaged; c += SP_WG) { sCtgN[c] = db.ctgNTile[c]; sCtgB[c] = db.ctgBase[c]; }
     __syncthreads();
-    int gt0[SP_PER], ntl[SP_PER], s_[SP_PER], e_[SP_PER];
+    IGD_QSTAMP(1);
+    auto has_records = [&](int t) -> bool { return bitsWords ? ((sl_bits[t >> 5] >> (t & 31)) & 1u) != 0u : db.tileCnt[t] > 0; };
+    // (query_span's last test -- rule NEST: an empty first tile ends the query, :468 -- is made here, from the bits)
+    const int spanRule = (rule & ~0xff) | IGD_HIP_RULE_FLAT;
+    const bool nestTest = (rule & 0xff) == IGD_HIP_RULE_NEST && db.vshift < 0;
+    int gt0[SP_PER], ntl[SP_PER];
 #pragma unroll
     for (int k = 0; k < SP_PER; k++) {
         const int i = blockIdx.x * SP_Q + k * SP_WG + threadIdx.x;
-        ntl[k] = 0; gt0[k] = 0; s_[k] = 0; e_[k] = 0;
-        if (i < nq) {
-            const int s = qs[i], e = qe[i];
+        ntl[k] = 0; gt0[k] = 0;
+        const int c = c_[k];
+        if (c >= 0 && c < db.nCtg) {                      // (i >= nq: c = -1)
+            const int s = qs_[k], e = qe_[k];
             int g, n;
-            if (query_span(db, ichr[i], s, e, rule, g, n)) {
+            if (query_span_at(db, c, ctgStaged ? sCtgN[c] : db.ctgNTile[c], ctgStaged ? sCtgB[c] : db.ctgBase[c], s, e, spanRule, g, n) &&
+                !(nestTest && !has_records(g))) {
                 const int kind = walk_kind(db, s, e, n, packed);
                 if (kind >= 0) {
                     longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, kind);
                     if (kind == WALK_ALL) cover_tiles(db, ctl, 1, epoch, g + 1, g + n - 1);   // first and last tile by the walk, the rest covered
                 } else {
                     int live = 0;                         // bit j: tile g+j is not empty
-                    for (int j = 0; j < n; j++) live |= (db.tileCnt[g + j] > 0) << j;
-                    gt0[k] = g; ntl[k] = live; s_[k] = s; e_[k] = e;
+                    for (int j = 0; j < n; j++) live |= (int)has_records(g + j) << j;
+                    gt0[k] = g; ntl[k] = live;
                     for (int j = 0; j < n; j++)
                         if ((live >> j) & 1) atomicAdd(&hist[(g + j) >> shift], 1u);
                 }
             }
         }
     }
+    IGD_QSTAMP(2);                                        // wave 0 has counted its pairs
     __syncthreads();
+    IGD_QSTAMP(3);                                        // ... and every wave
     {   // exclusive prefix over the buckets: thread t owns buckets 4t .. 4t+3 (SP_MAXC = 4 * SP_WG)
         const int b0 = threadIdx.x * (SP_MAXC / SP_WG);
         uint32_t c[SP_MAXC / SP_WG], sum = 0;
@@ -100,16 +127,36 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         }
     }
     __syncthreads();
+    IGD_QSTAMP(4);                                        // table row written, cursors set
     const size_t rb = (size_t)blockIdx.x * SP_CAP;
+    // The tuples go to their places in the workgroup's region -- grouped by bucket, i.e. 64 lanes to 64 places: a store
+    // instruction of 64 separate 12-byte pieces, 16 000 of them per 10^6 queries, was a third of this kernel.  The region is
+    // put together in LDS (in the area of the tile bits, which nobody reads any more) and written out as it lies, 16 bytes
+    // per lane; a workgroup with more pairs than the area holds (long queries: up to 4 pairs each) stores them one by one.
+    uint32_t nPairs = 0;
+    for (int k = 0; k < SP_WG / IGD_WAVE; k++) nPairs += wsum[k];
+    const bool staged = nPairs <= (uint32_t)stageCap;
+    SpTuple *stg = (SpTuple *)sl_bits;
 #pragma unroll
     for (int k = 0; k < SP_PER; k++)
         for (int live = ntl[k], j = 0; live; live >>= 1, j++)
             if (live & 1) {
                 const int t = gt0[k] + j;
                 const uint32_t pos = atomicAdd(&cur[t >> shift], 1u);
-                SpTuple tu; tu.t = t; tu.s = s_[k]; tu.e = e_[k];
-                reg[rb + pos] = tu;
+                SpTuple tu; tu.t = t; tu.s = qs_[k]; tu.e = qe_[k];
+                if (staged) stg[pos] = tu; else reg[rb + pos] = tu;
             }
+    if (staged) {
+        __syncthreads();
+        const uint4 *src = (const uint4 *)sl_bits;
+        uint4 *dst = (uint4 *)(reg + rb);                 // (a region starts at a multiple of SP_CAP tuples: 16-byte aligned; the last piece may carry up to 12 bytes beyond the pairs -- inside the area, inside the region, never read)
+        for (uint32_t k = threadIdx.x; k < (nPairs * 3 + 3) / 4; k += SP_WG) dst[k] = src[k];
+    }
+#if IGD_EXP & 0x1000000
+    IGD_QSTAMP(5);                                        // tuples issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IGD_QSTAMP(6);                                        // stores drained
+#endif
 }
 
 #define SP_ROWS 4     // table rows a thread keeps in flight
@@ -117,7 +164,7 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
                                                       const SpTuple *__restrict__ reg,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
                                                       int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
-                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy, int cap = 0)
 {
     extern __shared__ uint32_t sp_lds[];
     const int F = 1 << shift;
@@ -126,6 +173,53 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
     const int t0 = b << shift;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
+    // The usual bucket (round 5): all of its segments are short and its pairs fit the workgroup's staging area (cap tuples
+    // of LDS behind the counters).  One thread per segment walked its tuples one dependent load after the other, twice
+    // (count, then place): ~11 memory round trips in a row at 3 waves per SIMD.  Now the segments are laid out flat -- every
+    // thread expands its own into a list of tuple addresses in LDS -- and thread k fetches tuple k, k + 256, ... (four loads
+    // in flight), counts it and keeps it in LDS, from where the second pass places it: the tuples are read from memory once,
+    // in one or two round trips.
+    int nStaged = -1;
+    uint32_t *stT = start + F, *stS = stT + cap, *stE = stS + cap;   // staged tuples: tile - t0 (first: the tuple's address), qs, qe
+    if (cap > 0 && nWG <= SPF_WG * SP_ROWS) {
+        __shared__ uint32_t wsumN[SPF_WG / IGD_WAVE], wsumO[SPF_WG / IGD_WAVE];
+        uint32_t e[SP_ROWS], mine = 0, offs = 0;
+        int anyLong = 0;
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) { const int w = (int)threadIdx.x + r * SPF_WG; e[r] = w < nWG ? table[(size_t)w * nCoarse + b] : 0u; }
+#pragma unroll
+        for (int r = 0; r < SP_ROWS; r++) { mine += e[r] >> 16; offs += e[r] & 0xFFFFu; anyLong |= (e[r] >> 16) >= IGD_WAVE; }
+        const uint32_t incl = (uint32_t)wave_inclusive_sum((int)mine);
+        for (int o = 32; o > 0; o >>= 1) offs += (uint32_t)__shfl_xor((int)offs, o);
+        if (lane == 63) { wsumN[wv] = incl; wsumO[wv] = offs; }
+        anyLong = __syncthreads_or(anyLong);
+        uint32_t at0 = incl - mine, N = 0, O = 0;
+        for (int k = 0; k < SPF_WG / IGD_WAVE; k++) { if (k < wv) at0 += wsumN[k]; N += wsumN[k]; O += wsumO[k]; }
+        if (!anyLong && N <= (uint32_t)cap) {
+            nStaged = (int)N;
+            if (threadIdx.x == 0) baseSh = O;
+#pragma unroll
+            for (int r = 0; r < SP_ROWS; r++) {
+                const unsigned at = (unsigned)((int)threadIdx.x + r * SPF_WG) * (unsigned)SP_CAP + (e[r] & 0xFFFFu);
+                for (int j = 0, c = (int)(e[r] >> 16); j < c; j++) stT[at0++] = at + (unsigned)j;
+            }
+            __syncthreads();
+            for (int k0 = 0; k0 < nStaged; k0 += 4 * SPF_WG) {
+                SpTuple tu[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = k0 + u * SPF_WG + (int)threadIdx.x;
+                    if (k < nStaged) tu[u] = reg[stT[k]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = k0 + u * SPF_WG + (int)threadIdx.x;
+                    if (k < nStaged) { const uint32_t f = (uint32_t)(tu[u].t - t0); atomicAdd(&cnt[f], 1u); stT[k] = f; stS[k] = (uint32_t)tu[u].s; stE[k] = (uint32_t)tu[u].e; }
+                }
+            }
+        }
+    }
+    if (nStaged < 0)
     {   // first pair of this bucket = pairs of all earlier buckets = the sum over the table's rows of each row's own
         // exclusive prefix at this column (the low half of the entries this workgroup reads anyway): no kernel of column sums
         uint32_t x = 0;
@@ -134,7 +228,7 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         if (lane == 0) wsum[wv] = x;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < SPF_WG / IGD_WAVE; k++) t += wsum[k]; baseSh = t; }
+    if (nStaged < 0 && threadIdx.x == 0) { uint32_t t = 0; for (int k = 0; k < SPF_WG / IGD_WAVE; k++) t += wsum[k]; baseSh = t; }
     // Every (workgroup of k_split_local, this bucket) segment of pairs is walked: short ones by the thread that looked
     // them up, long ones (>= 64 pairs: queries that come in sorted runs put a workgroup's 4096 queries into one or two
     // buckets, and ONE thread walked them all -- 5 x the time of scattered queries) by the whole wave.
@@ -169,7 +263,7 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
             }
         }
     };
-    walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
+    if (nStaged < 0) walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
     __syncthreads();
     {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
         const int per0 = F >= SPF_WG ? F / SPF_WG : 1, f0 = threadIdx.x * per0;
@@ -202,6 +296,14 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         }
     }
     __syncthreads();
+    if (nStaged >= 0) {       // (placed straight from LDS; putting the bucket's pairs in order in LDS first and writing them out side by side
+                              // -- what pays in k_split_local -- cost 3 us here: the places of one bucket lie within a dozen KB)
+        for (int k = (int)threadIdx.x; k < nStaged; k += SPF_WG) {
+            const uint32_t pos = atomicAdd(&start[stT[k]], 1u);
+            pairs[pos] = make_int2((int)stS[k], (int)stE[k]);
+        }
+        return;
+    }
     walk([&](const SpTuple &tu) {
         const uint32_t pos = atomicAdd(&start[tu.t - t0], 1u);
         pairs[pos] = make_int2(tu.s, tu.e);
@@ -263,12 +365,12 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine_a(int nT, int shift, int 
                                                         uint32_t *__restrict__ bucketBase, const int32_t *__restrict__ bucketLong,
                                                         int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
                                                         int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
-                                                        int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+                                                        int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy, int cap)
 {
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
     const int b = blockIdx.x % nCoarse, share = blockIdx.x / nCoarse;   // (workgroups go round-robin to the 8 XCDs: share = blockIdx & 7 put every first share -- all the work of an ordinary batch -- on ONE of them: 121 instead of 25 us)
     if (__builtin_amdgcn_readfirstlane(bucketLong[b]) != epoch) {      // the usual bucket: one workgroup, one kernel
-        if (share == 0) split_fine_whole(b, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy);
+        if (share == 0) split_fine_whole(b, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy, cap);
         return;
     }
     extern __shared__ uint32_t sp_lds[];

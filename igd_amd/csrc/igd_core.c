@@ -450,7 +450,8 @@ int igdc_queries_push(igdc_queries *q, int32_t ichr, int32_t qs, int32_t qe)
 
 int igdc_queries_flags(const igdc_queries *q, int32_t nbp)
 {
-    if (!q || q->unsorted) return 0;
+    if (!q) return 0;
+    if (q->unsorted) return IGD_HIP_FLAG_BUCKET;         /* the parser has seen it: the device need not check again */
     return IGD_HIP_FLAG_SORTED | (q->max_len < nbp ? IGD_HIP_FLAG_SHORT : 0);
 }
 

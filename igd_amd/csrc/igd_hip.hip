@@ -229,6 +229,7 @@ struct DbView {
     const int32_t *ctgNTile;                    // [nCtg]
     const int32_t *tileUnit0;                   // [nT+1] number of each tile's first unit
     int32_t *cov;                               // workspace: 4 sets of coverage difference arrays (IGD_COV_*)
+    const uint32_t *tileBits;                   // [(nT + 31) / 32] bit t: tile t holds records (what the grouping of an unordered batch asks of tileCnt[], 32 tiles per word)
     const int4 *tileD;                          // [nT] per tile: the records that start in the NEXT tile, the contig, the tiles left in it (k_tile_desc; null: no DIRECT step)
     // A database whose file is bucketed with another tile width than the image likes (-b 11..13, 16..19) is searched over a
     // RE-TILED copy: the same records in tiles of 2^14 bp (igd_hip_db::inner).  Which records a query counts does not depend on
@@ -281,6 +282,7 @@ struct igd_hip_db {
     int forceRank;                // IGD_HIP_RANK at open (tests): 0 lean build, 1 full build, -1 the engine decides
     int forceDirect;              // IGD_HIP_DIRECT at open (tests): 1 every batch under IGD_HIP_FLAG_SORTED that can takes the DIRECT step, 0 none, -1 the engine decides
     int4 *d_tileD;                // DbView::tileD
+    uint32_t *d_tileBits;         // DbView::tileBits
     int ldsDirect;                // dynamic LDS of igd_scan_direct
     int lastDirect;               // the last batch took the DIRECT step (igd_hip_last_scan_kernel)
     bool bigImage;                // the compact image is addressed with per-unit 64-bit bases (>= 2^30 tile records; IGD_HIP_BIG=1 at open: tests)

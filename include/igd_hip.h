@@ -93,7 +93,10 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  *   IGD_HIP_FLAG_SORTED   the caller PROMISES that order, which skips enqueueing the bucket
  *                         kernels.  The promise is verified on the device: if it does not hold,
  *                         that batch adds nothing and igd_hip_sync returns IGD_HIP_ERR_UNSORTED.
- *   IGD_HIP_FLAG_BUCKET   always counting-sort (tests / measurements). */
+ *   IGD_HIP_FLAG_BUCKET   the caller KNOWS the batch is not in that order (the command line tool's
+ *                         parser saw a line out of order): no order check, no merge-join launch,
+ *                         always the counting sort.  Never wrong -- the counting sort takes any
+ *                         order -- only slower than the merge join on a batch that is sorted after all. */
 #define IGD_HIP_FLAG_SORTED 1
 #define IGD_HIP_FLAG_BUCKET 2
 /* Besides the exact start/end/idx/value arrays the engine keeps a compact tile-relative image

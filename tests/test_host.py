@@ -516,7 +516,7 @@ def test_a_parsed_query_set_earns_its_engine_flags(N):
     """igdc_queries_flags: IGD_HIP_FLAG_SORTED (1) when every pushed query was >= the one before by (contig, start), and
     IGD_HIP_FLAG_SHORT (16) on top when no query is as long as a tile -- what lets a dense file take the engine's DIRECT step.
     Both are statements the device verifies; here: that the reader makes them exactly when they hold, also across the
-    seams of the threaded parser."""
+    seams of the threaded parser.  A set the reader saw out of order earns IGD_HIP_FLAG_BUCKET (2): no order check on the device."""
     L = N.cli()
     Q = N.CoreQueries
     L.igdc_queries_push.argtypes = [C.POINTER(Q), C.c_int32, C.c_int32, C.c_int32]
@@ -526,7 +526,7 @@ def test_a_parsed_query_set_earns_its_engine_flags(N):
     nbp = 16384
     for rows, want in (([(0, 10, 500), (0, 10, 16393), (1, 5, 6)], 1 | 16),          # longest = 16383 < nbp
                        ([(0, 10, 500), (0, 10, 16394), (1, 5, 6)], 1),               # one query a tile long
-                       ([(0, 10, 500), (0, 9, 20)], 0),                              # out of order: no promise at all
+                       ([(0, 10, 500), (0, 9, 20)], 2),                              # out of order: IGD_HIP_FLAG_BUCKET (the device need not check again)
                        ([(0, 100, 90), (0, 100, 100)], 1 | 16),                      # inverted / zero-length: "short"
                        ([], 1 | 16)):
         q = Q()
