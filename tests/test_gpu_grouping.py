@@ -303,3 +303,72 @@ def test_blocking_api_repairs_a_wrong_order_promise(workdir):
     finally:
         db.close()
         orc.close()
+
+
+_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from igd_amd import Database
+d = np.load(sys.argv[3])
+db = Database(sys.argv[2])
+out = []
+for tag in ("few", "many", "lumpy"):
+    for v in (0, 300):
+        for rule_flags in (2, 2 | 4):
+            got, tot = db.search(d["c_" + tag], d["s_" + tag], d["e_" + tag], v, flags=rule_flags)
+            out.append(got); out.append(np.array([tot], np.int64))
+db.close()
+np.save(sys.argv[4], np.concatenate(out))
+"""
+
+
+@pytest.mark.parametrize("switch", ["", "IGD_HIP_SPLIT_NOSTAGE", "IGD_HIP_SPLIT_NOBITS", "IGD_HIP_SPLIT_NOREGION"])
+def test_unordered_batches_through_every_form_of_the_grouping_kernels(switch, workdir):
+    """Round 5's grouping kernels put their output together in LDS -- the tile-has-records bits and contig tables, a workgroup's
+    region of tuples (k_split_local), a coarse bucket's pairs (k_split_fine_a) -- and each has the older form behind it for what
+    does not fit: a workgroup with more pairs than its area holds (many queries of 2-4 tiles), a bucket with more pairs than its
+    area, a database of more tiles than the bits have room for.  Three unordered batches over an hg38-sized tile table -- one of
+    short queries (everything staged), one where 40 % of the queries span 2-4 tiles (regions overflow), one with half of its
+    queries on chr1 (buckets overflow) -- under
+    IGD_HIP_FLAG_BUCKET, compact image and exact arrays, with and without a value filter, must give the oracle's counts in the
+    shipped form and with each stage switched off (the switches are read once per process: child processes)."""
+    import os, subprocess, sys
+    from igd_amd import synth
+    from helpers import ROOT
+    p = os.path.join(workdir, "hgsmall.igd")
+    if not os.path.exists(p):
+        synth.make_db(p, files=12, per_file=6000, seed=5, genome=synth.HG38)
+    rng = np.random.default_rng(99)
+    sets = {}
+    for tag, frac in (("few", 0.02), ("many", 0.40)):
+        c, s, e = synth.make_queries(150000, seed=11 if tag == "few" else 12, genome=synth.HG38, sorted_=False)
+        long_ = rng.random(len(s)) < frac
+        e = np.where(long_, s + rng.integers(16384, 3 * 16384 + 8000, len(s)), e).astype(np.int32)
+        sets[tag] = (c, s, e)
+    # ... and one whose coarse buckets on chr1 hold 7 x the average: more pairs than the bucket's staging area, in short segments
+    c, s, e = synth.make_queries(600000, seed=13, genome=synth.HG38, sorted_=False)
+    hot = rng.random(len(s)) < 0.5
+    hs = rng.integers(0, 248000000 - 4000, len(s))
+    c = np.where(hot, 0, c).astype(np.int32)
+    e = np.where(hot, hs + (e - s), e).astype(np.int32)
+    s = np.where(hot, hs, s).astype(np.int32)
+    sets["lumpy"] = (c, s, e)
+    orc = Oracle(p)
+    want = []
+    try:
+        for tag in ("few", "many", "lumpy"):
+            for v in (0, 300):
+                h, t = orc.search(*sets[tag], v)
+                for _ in range(2):
+                    want.append(h); want.append(np.array([t], np.int64))
+    finally:
+        orc.close()
+    want = np.concatenate(want)
+    qf = os.path.join(workdir, "gq.npz")
+    np.savez(qf, **{"%s_%s" % (k, tag): a for tag, (c, s, e) in sets.items() for k, a in (("c", c), ("s", s), ("e", e))})
+    outf = os.path.join(workdir, "gout_%s.npy" % (switch or "shipped"))
+    env = dict(os.environ)
+    if switch:
+        env[switch] = "1"
+    subprocess.check_call([sys.executable, "-c", _CHILD, ROOT, p, qf, outf], env=env, timeout=600)
+    np.testing.assert_array_equal(np.load(outf), want, err_msg=switch or "shipped")
