@@ -34,7 +34,7 @@ static int ensure_workspace(igd_hip_db *db, int64_t nq, int pairBytes)
     if ((rc = dalloc((char **)&db->d_pairs, (size_t)cap * IGD_SHORT_TILES * (size_t)pb, nullptr)) != IGD_HIP_OK) return rc;
     if ((rc = dalloc(&db->d_long, (size_t)cap, nullptr)) != IGD_HIP_OK) return rc;
     {   // split path geometry: <= SP_MAXC coarse buckets of 2^shift tiles, 2^shift counters x 2 in LDS
-        int sh = 8;
+        int sh = SP_MINSHIFT;
         while (sh < 13 && ((db->nT + (1 << sh) - 1) >> sh) > SP_MAXC) sh++;
         db->spShift = (((db->nT + (1 << sh) - 1) >> sh) <= SP_MAXC && sh <= 12) ? sh : -1;   // 2 * 4 * 2^12 = 32 KiB of LDS
         db->spCoarse = db->spShift >= 0 ? (db->nT + (1 << sh) - 1) >> sh : 0;
@@ -85,7 +85,7 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
     int32_t *blong = shared ? (int32_t *)(bases + db->spCoarse) : nullptr;
     // (one bit per tile in LDS when they fit 40 KiB -- up to 327 680 tiles: hg38 in 16 kbp tiles has 188 505)
     static const bool noBits = getenv("IGD_HIP_SPLIT_NOBITS") != nullptr;            // A/B: tileCnt[] gathers (until round 5)
-    const int bitsWords = (!noBits && db->v.tileBits && db->nT <= 40 * 1024 * 8) ? (db->nT + 31) / 32 : 0;
+    const int bitsWords = (!noBits && db->v.tileBits && db->nT <= 40 * 1024 * 8) ? (db->nT + 31) / 32 + 1 : 0;   // (+ the array's word of slack)
     const int ctgStaged = (!noBits && db->nCtg <= 1024) ? db->nCtg : 0;                // ... and the two contig tables (8 KiB at most)
     // ... and the workgroup's region of tuples, put together in the same LDS before it is written out (SP_Q queries + 1/8 for
     // second tiles: 54 KiB; with the kernel's 8.3 KiB of counters within the 64 KiB a launch gets without asking)
@@ -93,21 +93,26 @@ static int launch_split(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_
     const int stageCap = (noBits || noRegion) ? 0 : SP_Q + SP_Q / 8;
     size_t ldsLocal = (size_t)bitsWords * 4 + (size_t)ctgStaged * 8;
     if (ldsLocal < (size_t)stageCap * 12 + 16) ldsLocal = (size_t)stageCap * 12 + 16;
-    k_split_local<<<nWG, SP_WG, ldsLocal, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
+    static const bool noFast = getenv("IGD_HIP_SPLIT_NOFAST") != nullptr;           // A/B: the general per-query code for every database
+    if (!noFast && bitsWords && ctgStaged && db->v.vshift < 0 && db->v.shift >= 0 && db->spShift >= 2)
+    k_split_local<true><<<nWG, SP_WG, ldsLocal, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
                                          db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal, blong, bitsWords, ctgStaged, stageCap);
+    else
+    k_split_local<false><<<nWG, SP_WG, ldsLocal, st>>>(db->v, d_ichr, d_qs, d_qe, nq, rule, packed, db->spShift, db->spCoarse, db->d_spTable,
+                                         db->d_spT, db->d_long, db->d_ctl, gate, db->epoch, zeroHits, zeroTotal, blong, bitsWords, ctgStaged, stageCap);
+    // staging area of the usual bucket (split_fine_whole): twice the bucket's share of an evenly spread batch, within 64 KiB of LDS
+    static const bool noStage = getenv("IGD_HIP_SPLIT_NOSTAGE") != nullptr;       // A/B: segments walked from memory, twice (until round 5)
+    const size_t ldsCnt = (size_t)2 * 4 << db->spShift;
+    int64_t cap = 2 * (((int64_t)nq + nq / 8) / db->spCoarse) + 256;
+    if (cap < 1024) cap = 1024;
+    if (cap > (int64_t)((65536 - 256 - ldsCnt) / 12)) cap = (int64_t)((65536 - 256 - ldsCnt) / 12);
+    if (noStage || cap < 256) cap = 0;
     if (!shared)
-    k_split_fine<<<db->spCoarse, SPF_WG, (size_t)2 * 4 << db->spShift, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
+    k_split_fine<<<db->spCoarse, SPF_WG, ldsCnt + (size_t)cap * 12, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable,
                                                                           db->d_spT,
                                                                           db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs,
-                                                                          db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr);
+                                                                          db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr, (int)cap);
     else {
-        // staging area of the usual bucket (split_fine_whole): twice the bucket's share of an evenly spread batch, within 64 KiB of LDS
-        static const bool noStage = getenv("IGD_HIP_SPLIT_NOSTAGE") != nullptr;       // A/B: segments walked from memory, twice (until round 5)
-        const size_t ldsCnt = (size_t)2 * 4 << db->spShift;
-        int64_t cap = 2 * (((int64_t)nq + nq / 8) / db->spCoarse) + 256;
-        if (cap < 1024) cap = 1024;
-        if (cap > (int64_t)((65536 - 256 - ldsCnt) / 12)) cap = (int64_t)((65536 - 256 - ldsCnt) / 12);
-        if (noStage || cap < 256) cap = 0;
         k_split_fine_a<<<db->spCoarse * SPF_S, SPF_WG, ldsCnt + (size_t)cap * 12, st>>>(db->nT, db->spShift, db->spCoarse, nWG, db->d_spTable, db->d_spT,
             db->d_spSub, bases, blong, db->d_pairN, db->d_pairPos, (int2 *)db->d_pairs, db->d_ctl, gate, db->d_ctl, db->epoch, packed ? db->d_heavy : nullptr, (int)cap);
         // (an empty launch when no bucket is piled up: 4.5 us, with 96 workgroups as with 512)

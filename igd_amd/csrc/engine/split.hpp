@@ -23,8 +23,18 @@
 #endif
 #define SP_CAP (SP_Q * IGD_SHORT_TILES)
 #define SP_LONG (SP_Q / 4)     // pairs of one k_split_local workgroup in one coarse bucket from which the bucket counts as piled up
+#ifndef SP_MAXC
 #define SP_MAXC 1024
+#endif
+#ifndef SP_MINSHIFT
+#define SP_MINSHIFT 8          // log2 of the smallest coarse bucket (tiles)
+#endif
 
+// FAST: the usual database (its own power-of-two tiles, tile bits and contig tables staged in LDS, coarse buckets of >= 4 tiles):
+// the per-query part written without branches -- both kinds of kernel spend their time issuing instructions (800 vector + 490
+// scalar per wave in the general form, whose four unrolled queries each carry the re-tiled copy's gate, C division and the
+// tile-by-tile loops).
+template <bool FAST>
 __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t *__restrict__ ichr,
                                                        const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                                        int nq, int rule, int packed, int shift, int nCoarse,
@@ -48,7 +58,8 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
     }
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
     IGD_QSTAMP(0);                                        // (diagnostic build -DIGD_EXP=0x1000000: tools/sp_stamps.py)
-    __shared__ uint32_t hist[SP_MAXC], cur[SP_MAXC], wsum[SP_WG / IGD_WAVE];
+    __shared__ uint32_t hist[SP_MAXC], wsum[SP_WG / IGD_WAVE];
+    uint32_t *cur = hist;                                 // (a bucket's count is read, then its cursor written, by the one thread that owns the bucket)
     for (int b = threadIdx.x; b < nCoarse; b += SP_WG) hist[b] = 0;
     // "does tile t hold records" is asked once or twice per query, of tiles all over the genome: out of tileCnt[] that is a
     // 4-byte gather that moves a cache line per query (10^6 queries: 128 MB through the L2s -- 3/4 of this kernel's time went
@@ -74,6 +85,41 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
     const int spanRule = (rule & ~0xff) | IGD_HIP_RULE_FLAT;
     const bool nestTest = (rule & 0xff) == IGD_HIP_RULE_NEST && db.vshift < 0;
     int gt0[SP_PER], ntl[SP_PER];
+    if (FAST) {
+        const int sh = db.shift;
+#pragma unroll
+        for (int k = 0; k < SP_PER; k++) {
+            const int c = c_[k], s = qs_[k], e = qe_[k];
+            const bool valid = (unsigned)c < (unsigned)db.nCtg;      // (i >= nq: c = -1)
+            const int cc = valid ? c : 0;
+            const int mT = sCtgN[cc] - 1;
+            const int n1 = tile_shift(s, sh);
+            int n2 = tile_shift((int)((unsigned)e - 1u), sh);
+            bool ok = valid && n1 >= 0 && n1 <= mT;           // (:459-462)
+            n2 = n2 > mT ? mT : n2;
+            const int n = n2 > n1 ? n2 - n1 + 1 : 1;
+            const int g = ok ? sCtgB[cc] + n1 : 0;
+            // the four tiles from g on, one bit each (two words of the staged bits; one word of slack behind the last)
+            const uint32_t w0 = sl_bits[g >> 5], w1 = sl_bits[(g >> 5) + 1];
+            const uint32_t four = (uint32_t)(((((unsigned long long)w1) << 32) | w0) >> (g & 31)) & 0xFu;
+            if ((rule & 0xff) == IGD_HIP_RULE_NEST) ok = ok && (four & 1u);     // (:468)
+            const bool longQ = n > IGD_SHORT_TILES;
+            const bool rare = ok && (longQ || (packed && e <= (int)((unsigned)n1 << sh)));   // walk_kind: WALK_ALL / WALK_FIRST
+            const uint32_t live = (ok && !rare) ? (four & ((1u << (n & 7)) - 1u)) : 0u;      // (n <= 4 here)
+            gt0[k] = g; ntl[k] = (int)live;
+            if (rare) {
+                const int i = blockIdx.x * SP_Q + k * SP_WG + threadIdx.x;
+                longList[atomicAdd(&ctl[CTL_NLONG + (epoch & 1)], 1)] = make_int2(i, longQ ? WALK_ALL : WALK_FIRST);
+                if (longQ) cover_tiles(db, ctl, 1, epoch, g + 1, g + n - 1);
+            }
+            if (live) {      // a coarse bucket holds >= 256 tiles: the query's <= 4 tiles lie in one bucket, or in two neighbours
+                const int b0 = g >> shift, jb = ((b0 + 1) << shift) - g;
+                const uint32_t lo = live & ((jb < 4 ? 1u << jb : 16u) - 1u);
+                if (lo) atomicAdd(&hist[b0], (uint32_t)__popc(lo));
+                if (live != lo) atomicAdd(&hist[b0 + 1], (uint32_t)__popc(live ^ lo));
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < SP_PER; k++) {
         const int i = blockIdx.x * SP_Q + k * SP_WG + threadIdx.x;
@@ -137,6 +183,25 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
     for (int k = 0; k < SP_WG / IGD_WAVE; k++) nPairs += wsum[k];
     const bool staged = nPairs <= (uint32_t)stageCap;
     SpTuple *stg = (SpTuple *)sl_bits;
+    if (FAST) {
+#pragma unroll
+        for (int k = 0; k < SP_PER; k++) {
+            const uint32_t live = (uint32_t)ntl[k];
+            if (live) {
+                const int g = gt0[k], b0 = g >> shift, jb = ((b0 + 1) << shift) - g;
+                const uint32_t lo = live & ((jb < 4 ? 1u << jb : 16u) - 1u);
+                uint32_t pLo = lo ? atomicAdd(&cur[b0], (uint32_t)__popc(lo)) : 0u;
+                uint32_t pHi = live != lo ? atomicAdd(&cur[b0 + 1], (uint32_t)__popc(live ^ lo)) : 0u;
+#pragma unroll
+                for (int j = 0; j < IGD_SHORT_TILES; j++)
+                    if ((live >> j) & 1u) {
+                        const uint32_t pos = ((lo >> j) & 1u) ? pLo++ : pHi++;
+                        SpTuple tu; tu.t = g + j; tu.s = qs_[k]; tu.e = qe_[k];
+                        if (staged) stg[pos] = tu; else reg[rb + pos] = tu;
+                    }
+            }
+        }
+    } else
 #pragma unroll
     for (int k = 0; k < SP_PER; k++)
         for (int live = ntl[k], j = 0; live; live >>= 1, j++)
@@ -160,6 +225,9 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
 }
 
 #define SP_ROWS 4     // table rows a thread keeps in flight
+#ifndef SPF_FLY
+#define SPF_FLY 8     // tuples a thread of the staged path keeps in flight
+#endif
 __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int nCoarse, int nWG, const uint32_t *__restrict__ table,
                                                       const SpTuple *__restrict__ reg,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
@@ -172,11 +240,12 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
     __shared__ uint32_t wsum[SPF_WG / IGD_WAVE], baseSh;
     const int t0 = b << shift;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    IGD_QSTAMP(0);                                        // (diagnostic build, IGD_HIP_SPLIT_ONE=1: tools/sp_stamps.py fine)
     for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
     // The usual bucket (round 5): all of its segments are short and its pairs fit the workgroup's staging area (cap tuples
     // of LDS behind the counters).  One thread per segment walked its tuples one dependent load after the other, twice
     // (count, then place): ~11 memory round trips in a row at 3 waves per SIMD.  Now the segments are laid out flat -- every
-    // thread expands its own into a list of tuple addresses in LDS -- and thread k fetches tuple k, k + 256, ... (four loads
+    // thread expands its own into a list of tuple addresses in LDS -- and thread k fetches tuple k, k + 256, ... (SPF_FLY loads
     // in flight), counts it and keeps it in LDS, from where the second pass places it: the tuples are read from memory once,
     // in one or two round trips.
     int nStaged = -1;
@@ -193,6 +262,7 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         for (int o = 32; o > 0; o >>= 1) offs += (uint32_t)__shfl_xor((int)offs, o);
         if (lane == 63) { wsumN[wv] = incl; wsumO[wv] = offs; }
         anyLong = __syncthreads_or(anyLong);
+        IGD_QSTAMP(1);                                    // table column arrived, summed
         uint32_t at0 = incl - mine, N = 0, O = 0;
         for (int k = 0; k < SPF_WG / IGD_WAVE; k++) { if (k < wv) at0 += wsumN[k]; N += wsumN[k]; O += wsumO[k]; }
         if (!anyLong && N <= (uint32_t)cap) {
@@ -204,15 +274,18 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
                 for (int j = 0, c = (int)(e[r] >> 16); j < c; j++) stT[at0++] = at + (unsigned)j;
             }
             __syncthreads();
-            for (int k0 = 0; k0 < nStaged; k0 += 4 * SPF_WG) {
-                SpTuple tu[4];
+            IGD_QSTAMP(2);                                // segments laid out
+            // (eight in flight: a bucket of the benchmark's batch holds ~1400 tuples, 5-6 per thread -- in rounds of four the second
+            // round trip, to tuples another XCD has just written, was a fifth of the workgroup's time)
+            for (int k0 = 0; k0 < nStaged; k0 += SPF_FLY * SPF_WG) {
+                SpTuple tu[SPF_FLY];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < SPF_FLY; u++) {       // (no branch around a load: behind one the compiler waits for each load before it asks for the next)
                     const int k = k0 + u * SPF_WG + (int)threadIdx.x;
-                    if (k < nStaged) tu[u] = reg[stT[k]];
+                    tu[u] = reg[stT[k < nStaged ? k : 0]];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < SPF_FLY; u++) {
                     const int k = k0 + u * SPF_WG + (int)threadIdx.x;
                     if (k < nStaged) { const uint32_t f = (uint32_t)(tu[u].t - t0); atomicAdd(&cnt[f], 1u); stT[k] = f; stS[k] = (uint32_t)tu[u].s; stE[k] = (uint32_t)tu[u].e; }
                 }
@@ -264,6 +337,7 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         }
     };
     if (nStaged < 0) walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
+    IGD_QSTAMP(3);                                        // wave 0's tuples fetched, counted, staged
     __syncthreads();
     {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
         const int per0 = F >= SPF_WG ? F / SPF_WG : 1, f0 = threadIdx.x * per0;
@@ -296,12 +370,18 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         }
     }
     __syncthreads();
+    IGD_QSTAMP(4);                                        // tiles' first places known
     if (nStaged >= 0) {       // (placed straight from LDS; putting the bucket's pairs in order in LDS first and writing them out side by side
                               // -- what pays in k_split_local -- cost 3 us here: the places of one bucket lie within a dozen KB)
         for (int k = (int)threadIdx.x; k < nStaged; k += SPF_WG) {
             const uint32_t pos = atomicAdd(&start[stT[k]], 1u);
             pairs[pos] = make_int2((int)stS[k], (int)stE[k]);
         }
+#if IGD_EXP & 0x1000000
+        IGD_QSTAMP(5);                                    // pairs issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        IGD_QSTAMP(6);                                    // stores drained
+#endif
         return;
     }
     walk([&](const SpTuple &tu) {
@@ -314,10 +394,10 @@ __global__ __launch_bounds__(SPF_WG) void k_split_fine(int nT, int shift, int nC
                                                       const SpTuple *__restrict__ reg,
                                                       int32_t *__restrict__ pairN, int32_t *__restrict__ pairPos,
                                                       int2 *__restrict__ pairs, const int32_t *__restrict__ ctl, int gate,
-                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy)
+                                                      int32_t *__restrict__ ctlw, int epoch, int32_t *__restrict__ heavy, int cap)
 {
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
-    split_fine_whole((int)blockIdx.x, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy);
+    split_fine_whole((int)blockIdx.x, nT, shift, nCoarse, nWG, table, reg, pairN, pairPos, pairs, ctl, gate, ctlw, epoch, heavy, cap);
 }
 
 // Several workgroups per coarse bucket for the buckets of a PILED-UP batch (round 4).  One workgroup per bucket walks ALL pairs

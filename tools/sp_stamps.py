@@ -12,5 +12,7 @@ def q(x): return "min %7d  p10 %7d  p50 %7d  p90 %7d  max %7d" % (x.min(), np.pe
 print("workgroups %d, span %d ticks" % (len(a), a[:, 6].max() - t0))
 print("start (after the first)   ", q(a[:, 0] - t0))
 names = ["counters cleared (barr.) ", "wave 0 counted its pairs ", "all waves (barrier)      ", "prefix, table row (barr.)", "tuples issued            ", "stores drained           "]
+if len(sys.argv) > 2 and sys.argv[2] == "fine":      # the LAST kernel that stamped was k_split_fine (IGD_HIP_SPLIT_ONE=1): split_fine_whole's staged path
+    names = ["table column, sums (barr)", "segments laid out (barr.)", "tuples fetched + counted ", "prefix over tiles (barr.)", "pairs issued             ", "stores drained           "]
 for k in range(6): print(names[k], q(a[:, k + 1] - a[:, k]))
 print("whole workgroup           ", q(a[:, 6] - a[:, 0]))
