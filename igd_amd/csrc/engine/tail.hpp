@@ -85,15 +85,30 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                 const int n = __builtin_amdgcn_readlane(vur.n, e);
                 const int64_t off = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(vur.offHi, e) << 32) |
                                               (unsigned)__builtin_amdgcn_readlane(vur.offLo, e));
-                w.live = 0;
+                // Records are ordered by start, so the slots that can hold a hit are the first nOn.  Their loads are bounds-checked
+                // buffer loads over [0, min(n, 64 nOn)): a lane beyond reads 0 (s' = 65535: beyond every qe') and touches no memory, and
+                // -- the point -- no load sits behind a branch: behind `if (i < n)` the compiler waited for each slot's words before
+                // it asked for the next slot's (s_waitcnt after every pair of loads), five round trips per walk where one will do.
+                int nOn = 0;
 #pragma unroll
-                for (int r = 0; r < IGD_SLOTS; r++) {
-                    const int i = r * IGD_WAVE + lane;
-                    const bool on = r * IGD_WAVE < n && (int)(65535u - ((unsigned)__builtin_amdgcn_readlane(vur.w[r], e) & 0xFFFFu)) < w.qe2;   // wave-uniform
-                    w.pa[r] = 0xFFFFu; w.px[r] = 0u;     // (s' = 0: counts nothing)
-                    if (on) {
-                        w.live |= 1 << r;
-                        if (i < n) { w.pa[r] = db.pse[off + i]; w.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                for (int r = 0; r < IGD_SLOTS; r++)
+                    nOn += (r * IGD_WAVE < n && (int)(65535u - ((unsigned)__builtin_amdgcn_readlane(vur.w[r], e) & 0xFFFFu)) < w.qe2) ? 1 : 0;   // wave-uniform; monotone
+                w.live = (1 << nOn) - 1;
+                const int m = n < nOn * IGD_WAVE ? n : nOn * IGD_WAVE;
+                const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pse + off), 0, m * 4, 0x00020000);
+                if (USE_V) {
+                    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.pxv + off), 0, m * 4, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        w.pa[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, r * 256, 0);
+                        w.px[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsX, lane * 4, r * 256, 0);
+                    }
+                } else {
+                    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)(db.px + off), 0, m * 2, 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < IGD_SLOTS; r++) {
+                        w.pa[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, lane * 4, r * 256, 0);
+                        w.px[r] = (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsX, lane * 2, r * 128, 0);
                     }
                 }
             };
@@ -126,7 +141,9 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                         C.pa[r] = 0xFFFFu; C.px[r] = 0u;
                         if (r * IGD_WAVE < n) {
                             C.live |= 1 << r;
-                            if (i < n) { C.pa[r] = db.pse[off + i]; C.px[r] = USE_V ? db.pxv[off + i] : (uint32_t)db.px[off + i]; }
+                            const int64_t at = off + (i < n ? i : 0);
+                            const uint32_t p0 = db.pse[at], x0 = USE_V ? db.pxv[at] : (uint32_t)db.px[at];
+                            if (i < n) { C.pa[r] = p0; C.px[r] = x0; }
                         }
                     }
                     count(C);
@@ -174,10 +191,12 @@ __device__ __forceinline__ void exact_walk_body(const DbView &db, const ScanArgs
                     for (int r = 0; r < IGD_SLOTS; r++) {
                         const int i = rec0 + r * IGD_WAVE + lane;
                         const bool ok = i < tcnt;
-                        st[r] = ok ? db.start[toff + i] : INT_MAX;
-                        en[r] = ok ? db.end[toff + i] : INT_MIN;
-                        ix[r] = ok ? db.idx[toff + i] : 0;
-                        if (USE_V) va[r] = ok ? db.value[toff + i] : INT_MIN;
+                        const int64_t at = toff + (ok ? i : 0);      // (every lane loads -- a lane beyond the tile its first record: no load behind a branch, see `issue` above)
+                        const int s0 = db.start[at], e0 = db.end[at], x0 = db.idx[at];
+                        st[r] = ok ? s0 : INT_MAX;
+                        en[r] = ok ? e0 : INT_MIN;
+                        ix[r] = ok ? x0 : 0;
+                        if (USE_V) { const int v0 = db.value[at]; va[r] = ok ? v0 : INT_MIN; }
                     }
                     if (__builtin_amdgcn_readfirstlane(st[0]) >= qe) break;    // sorted: nothing further
 #pragma unroll
