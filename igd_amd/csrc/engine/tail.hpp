@@ -454,8 +454,13 @@ __global__ __launch_bounds__(256) void k_exact_walk(SortK K, ScanArgs a, const i
 }
 
 // slab rows -> int64 hits[] (+ batch total).  grid = (ceil(nFiles/IGD_TAIL_WG), IGD_REDUCE_GROUPS)
+#ifndef IGD_TAIL_OCC
+#define IGD_TAIL_ATTR
+#else
+#define IGD_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(IGD_TAIL_OCC, IGD_TAIL_OCC)))   // A/B: registers cut to what IGD_TAIL_OCC waves per SIMD leave each
+#endif
 template <bool USE_V>
-__global__ __launch_bounds__(IGD_TAIL_WG) void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
+__global__ __launch_bounds__(IGD_TAIL_WG) IGD_TAIL_ATTR void k_reduce_slabs(SortK K, const u64 *__restrict__ slab, int rows, int nFiles,
                                                       u64 *__restrict__ hits, u64 *__restrict__ total,
                                                       const int32_t *__restrict__ ctl, int brokenIf,
                                                       ScanArgs wa, const int2 *__restrict__ fixList,
