@@ -40,6 +40,12 @@ def batch(rng, n, genome_len, nbp):
     return c.astype(np.int32), qs.astype(np.int32), qe.astype(np.int32)
 
 
+# IGD_FUZZ_B="14,15": only these tile widths (the file's own tiles: k_split_local<FAST>, the DIRECT step, no re-tiled copy);
+# IGD_FUZZ_BUILDS=",D": only these builds ("" = as shipped)
+TILE_LOGS = [int(x) for x in os.environ.get("IGD_FUZZ_B", "10,11,12,13,14,15,16,17,18,19").split(",")]
+BUILDS = os.environ["IGD_FUZZ_BUILDS"].split(",") if "IGD_FUZZ_BUILDS" in os.environ else ["", "0", "1", "D"]
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -48,7 +54,7 @@ def main():
         rng = np.random.default_rng(seed0 + ci)
         d = tempfile.mkdtemp(prefix="ige", dir="/tmp")
         try:
-            b = int(rng.choice([10, 11, 12, 13, 14, 15, 16, 17, 18, 19])); files = int(rng.choice([1, 7, 60, 300, 300, 21000]))
+            b = int(rng.choice(TILE_LOGS)); files = int(rng.choice([1, 7, 60, 300, 300, 21000]))
             per = int(rng.choice([200, 3000, 20000])); gtype = int(rng.choice([0, 1, 1])); cl = bool(rng.random() < 0.3)
             if files > 10000: per = int(rng.choice([15, 150]))        # (more files than LDS counters: windows of files)
             path = os.path.join(d, "f.igd")
@@ -60,7 +66,7 @@ def main():
             srt = (ichr[o], qs[o], qe[o])
             msg = []
             orc = Oracle(path)
-            for build in ("", "0", "1", "D"):
+            for build in BUILDS:
                 # "D" (round 5): every promised-sorted batch takes the DIRECT step (engine/scan_direct.hpp) over the file's own tiles
                 for k in ("IGD_HIP_RANK", "IGD_HIP_DIRECT", "IGD_HIP_NO_RETILE"): os.environ.pop(k, None)
                 if build == "D": os.environ["IGD_HIP_DIRECT"] = "1"; os.environ["IGD_HIP_NO_RETILE"] = "1"
