@@ -4,13 +4,17 @@
 // Bucket path without global atomics ("split"): 10^6 random atomicAdds on the per-tile counters cost
 // ~40 us each way on this part (device-scope atomics are resolved beyond the XCD-private L2s), so the
 // (query, tile) pairs are grouped in two levels with LDS atomics only:
-//   k_split_local   a workgroup takes 1024 queries, counts their pairs per COARSE bucket (tile >> shift,
+//   k_split_local   a workgroup takes 4096 queries, counts their pairs per COARSE bucket (tile >> shift,
 //                   <= 1024 buckets) in LDS, and writes them, grouped by bucket, into its own region
 //                   + one table row (offset | count << 16 per bucket);
 //   k_split_fine    one workgroup per bucket collects the bucket's segments from all regions, counts per
 //                   tile in LDS (the bucket spans 2^shift tiles), writes pairN/pairPos of its tiles and
 //                   the pairs, tile by tile, into `pairs`.
 // Output = exactly what count/scan/scatter leave (pairN, pairPos = END of each tile's range, pairs).
+// Round 5 (LABNOTES R5-11): neither kernel gathers from memory any more -- k_split_local keeps one bit per tile ("holds
+// records") and the contig tables in LDS, puts its region together in LDS and writes it out side by side; the fine kernel
+// lays a bucket's segments out flat, fetches every tuple once (eight loads in flight per thread, none behind a branch) and
+// places the pairs from LDS.  Each stage has the older form behind it for what does not fit (IGD_HIP_SPLIT_NO* switches).
 #ifndef SP_WG
 #define SP_WG 1024
 #endif
