@@ -260,21 +260,39 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
         UnitRegs ur = load_unit_regs(db.units + u0 + (lane < cnt ? lane : 0));
         const int tile = ur.tile, tile0 = __builtin_amdgcn_readfirstlane(tile);
         const int bd = db.tileBd[tile];                  // (a covered tile is never the first of its contig)
+        // (every load below is asked for with a clamped index and masked afterwards: a load per loop round, or behind `k < gap`,
+        // is a round trip of its own -- up to 16 + 3 + 4 of them in a row at the head of every wave's share, LABNOTES R5-12)
         int p0;
         {
-            const int blk = tile0 >> IGD_COV_SHIFT;
+            const int blk = tile0 >> IGD_COV_SHIFT, t0 = blk << IGD_COV_SHIFT;
             int sum = 0;
-            for (int c = lane; c < blk; c += IGD_WAVE) sum += coarse[c];
-            for (int t = (blk << IGD_COV_SHIFT) + lane; t <= tile0; t += IGD_WAVE) sum += diff[t];
+            for (int c0 = 0; c0 < blk; c0 += 4 * IGD_WAVE) {            // coarse sums of the blocks before: four per lane in flight
+                int v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int c = c0 + k * IGD_WAVE + lane; v[k] = coarse[c < blk ? c : 0]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum += c0 + k * IGD_WAVE + lane < blk ? v[k] : 0;
+            }
+            constexpr int PER = (1 << IGD_COV_SHIFT) / IGD_WAVE;        // the block's fine differences up to tile0: all of a lane's in flight
+            int v[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) { const int t = t0 + k * IGD_WAVE + lane; v[k] = diff[t <= tile0 ? t : tile0]; }
+#pragma unroll
+            for (int k = 0; k < PER; k++) sum += t0 + k * IGD_WAVE + lane <= tile0 ? v[k] : 0;
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             p0 = sum;
         }
         const int before = __shfl_up(tile, 1);
         const int gap = (lane == 0 || lane >= cnt) ? 0 : tile - before;   // tiles since the unit before (0: same tile; > 1: empty tiles between)
         int d = 0;
-        if (gap <= 4) {
+        {
+            int v[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) d += k < gap ? diff[tile - k] : 0;
+            for (int k = 0; k < 4; k++) v[k] = diff[tile - k >= 0 ? tile - k : 0];
+            if (gap <= 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) d += k < gap ? v[k] : 0;
+            }
         }
         for (unsigned long long m = __ballot(gap > 4); m; m &= m - 1) {   // a run of empty tiles (a centromere): summed by the whole wave
             const int src = __builtin_ctzll(m);
