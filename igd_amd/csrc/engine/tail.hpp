@@ -341,9 +341,11 @@ __device__ __forceinline__ void coverage_body(const DbView &db, const ScanArgs &
 #pragma unroll
             for (int r = 0; r < IGD_SLOTS; r++) {
                 const int i = r * IGD_WAVE + lane;
-                w.st[r] = i < n ? db.start[off + i] : INT_MIN;
-                w.ix[r] = i < n ? db.idx[off + i] : 0;
-                if (USE_V) w.va[r] = i < n ? db.value[off + i] : INT_MIN;
+                const int64_t at = off + (i < n ? i : 0);      // (every lane loads: no load behind a branch)
+                const int s0 = db.start[at], x0 = db.idx[at];
+                w.st[r] = i < n ? s0 : INT_MIN;
+                w.ix[r] = i < n ? x0 : 0;
+                if (USE_V) { const int v0 = db.value[at]; w.va[r] = i < n ? v0 : INT_MIN; }
             }
         };
         auto count = [&](const Cov &w) {
