@@ -11,4 +11,4 @@ for d in igd_amd/lib igd_amd/libv_*; do
   IGD_AMD_LIBDIR=$PWD/$d python bench.py --no-cpu --no-extra --no-cold --steps 200 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('headline step', d['ms_per_step']*1e3, d.get('matches_oracle'))" >> $O/tail_ab.txt
 done
 done
-IGD_AMD_LIBDIR=$PWD/igd_amd/libv_occ6 timeout 900 python -m pytest tests/test_gpu_long.py tests/test_gpu_stress.py tests/test_gpu_skew.py -q -x 2>&1 | tail -2 >> $O/tail_ab.txt
+IGD_AMD_LIBDIR=$PWD/igd_amd/libv_o5w640 timeout 900 python -m pytest tests/test_gpu_long.py tests/test_gpu_stress.py tests/test_gpu_skew.py -q -x 2>&1 | tail -2 >> $O/tail_ab.txt
