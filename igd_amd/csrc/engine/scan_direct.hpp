@@ -420,8 +420,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
 #pragma unroll
                 for (int r = 0; r < IGD_SLOTS; r++) {
                     const int at = pos[r] + step - 1;
-                    const int v0 = a.q_qs[f0 + (at < c0 ? at : 0)];      // (every lane loads: the slots' probes of one level go out together, not one round trip each)
-                    vq[r] = at < c0 ? v0 : INT_MAX;
+                    vq[r] = at < c0 ? a.q_qs[f0 + at] : INT_MAX;
                 }
                 // qs' <= e' on the raw starts: a start before the tile (qs' = 1) is below every e', one beyond it above
 #pragma unroll
