@@ -559,6 +559,8 @@ def extra_configs(db, dev, stream, args, box):
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100, "config2_sorted_q1000000_v500"),
              ("10^6 queries in generation order (flags = IGD_HIP_FLAG_BUCKET, what the command line tool's parser passes for a file it has seen out of order)",
               shuf, 0, 2, 100, "config2_sorted_q1000000_v0"),
+             ("the same 10^6 queries in generation order with flags = 0: the device checks the order itself and then takes the bucket path", shuf, 0, 0, 100,
+              "config2_sorted_q1000000_v0"),
              ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, SHORT, 30, "config4_share_q12500000_v0"),
              ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, SHORT, 30,
               "config4_slab0_of_8_v0"),

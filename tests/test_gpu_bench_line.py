@@ -38,7 +38,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 15 and not any("error" in e for e in x), x
+        assert len(x) == 16 and not any("error" in e for e in x), x
         assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
         assert sum(e["workload"].startswith("stress:") for e in x) == 6
         # every row but `-f` carries the comparison with the oracle's fixture (None here: not the fixture's database size)
