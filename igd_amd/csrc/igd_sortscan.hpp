@@ -115,10 +115,16 @@ static __global__ void __launch_bounds__(RS_WG) ss_rs_hist(const uint32_t *__res
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_BLOCK;
+    uint32_t kv[RS_STRIPS];
+#pragma unroll
+    for (int k = 0; k < RS_STRIPS; k++) {                 // (all of the thread's keys asked for at once: a load inside `if (i < n)` is waited for before the next one goes out)
+        const int64_t i = base + k * RS_WG + threadIdx.x;
+        kv[k] = keys[i < n ? i : base];
+    }
 #pragma unroll
     for (int k = 0; k < RS_STRIPS; k++) {
         const int64_t i = base + k * RS_WG + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(kv[k] >> shift) & 255u], 1u);
     }
     __syncthreads();
     hist[(int64_t)threadIdx.x * nBlocks + blockIdx.x] = h[threadIdx.x];      // digit-major: one scan gives every base
