@@ -1,9 +1,11 @@
-"""What the compiler makes of the three places where this round's measurements turned on the generated code (no GPU needed:
+"""What the compiler makes of the places where this round's measurements turned on the generated code (no GPU needed:
 hipcc cross-compiles gfx950):
   * the lean build of igd_scan_sorted -- the dominant kernel -- keeps 8 waves per SIMD (<= 64 VGPRs) and spills nothing;
   * its pairwise compare loop is the written-out one (s_bitset0_b64 on VCC, branch on VCC itself: match_slot_asm);
   * the workgroup's LDS counters of the batch's last launch are reached with LDS atomics (ds_add_u64), not with flat atomics
-    that resolve to LDS at run time (TailHist).
+    that resolve to LDS at run time (TailHist);
+  * (round 5) the loads of the exact walk, of k_split_fine_a's staged path and of the radix sort's histogram go out back to back,
+    not one round trip each (no load behind a divergent branch).
 The device code is compiled to assembly once per session (~35 s)."""
 import os
 import re
@@ -61,3 +63,31 @@ def test_last_launch_counts_in_lds_with_lds_atomics(isa):
         code, _ = body(isa, sym)
         assert "flat_atomic" not in code, sym + ": a flat atomic (an LDS counter reached through a generic pointer?)"
         assert "ds_add_u64" in code, sym + ": no LDS atomic for the workgroup's counters"
+
+
+def _longest_run_of_loads(code, what):
+    """Longest run of vector-memory loads matching `what` with no s_waitcnt vmcnt between them."""
+    best = run = 0
+    for line in code.split("\n"):
+        t = line.strip()
+        if re.match(what, t):
+            run += 1
+            best = max(best, run)
+        elif t.startswith("s_waitcnt") and "vmcnt" in t:
+            run = 0
+    return best
+
+
+def test_no_round_trip_per_load_where_round_5_found_them(isa):
+    """LABNOTES R5-12: a load behind a divergent branch (`if (i < n) x = p[i];` with a default in x) is waited for before the next
+    one is asked for.  The three places where that cost measurable time must keep their loads back to back:
+      * the exact walk of a long query's last tile: five record words + five dataset numbers of a walk in one go (was: a wait per
+        slot, five round trips per walk);
+      * k_split_fine_a's staged path: a thread's eight tuples (was: eight round trips);
+      * the radix sort's histogram: a thread's eight keys."""
+    code, _ = body(isa, "_Z14k_reduce_slabsILb0EEv5SortK")
+    assert _longest_run_of_loads(code, r"buffer_load_(dword|ushort) ") >= 10, "the walk's loads are waited for one by one again"
+    code, _ = body(isa, "_Z14k_split_fine_a")
+    assert _longest_run_of_loads(code, r"global_load_dwordx3 ") >= 8, "k_split_fine_a's tuple loads are waited for one by one again"
+    code, _ = body(isa, "_ZL10ss_rs_hist")
+    assert _longest_run_of_loads(code, r"global_load_dword ") >= 8, "ss_rs_hist's key loads are waited for one by one again"
