@@ -65,6 +65,8 @@ def parse_args(argv=None):
     ap.add_argument("--v", type=int, default=0, help="`-v N` signal filter (config 3)")
     ap.add_argument("--dir", default="/tmp/igdb")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--extra-out", default="", help="where the whole record goes (default: bench_extra.json beside bench.py); stdout carries "
+                                                     "ONE compact line of at most 8 KB")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs runs")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache runs of the headline batch (profiling runs: their launches would be averaged in)")
     ap.add_argument("--slab-of", type=int, default=0, metavar="G",
@@ -188,28 +190,37 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
     """Wall time of the PRODUCT command line -- load the .igd, upload, parse, kernels, print -- on the headline's files,
     next to the reference CLI's seconds in cpu_baseline (report it separately): best of `repeats`."""
     exe = os.path.join(ROOT, "bin", "igd")
-    out = {"command": "bin/igd search <db> -q <the headline's 10^6-query BED> [..]", "repeats": repeats}
+    limit = host_route_limit()
+    nq = sum(1 for _ in open(bed_path, "rb"))
+    out = {"command": "bin/igd search <db> -q <the headline's 10^6-query BED> [..]", "repeats": repeats, "host_route_limit": limit,
+           "default_route": "host" if (limit and nq <= limit) else "engine",
+           "routes": "every size is timed on BOTH routes: *_seconds = the tool's own routing (default_route says who counted: `host` = "
+                     "CPU threads, igd_hostpath.c -- NOT an MI355X number), *_engine_seconds / q_engine_only_* = the same command with "
+                     "IGD_HOST_MAX_QUERIES=0 (the GPU engine whatever the size)"}
+    eng_env = dict(os.environ, IGD_HOST_MAX_QUERIES="0")
     for name, extra in (("q", []), ("q_v500", ["-v", "500"]), ("q_f", ["-f"])):
-        best, worst, ok = None, None, None
-        for _ in range(repeats if name != "q_f" else 3):
-            t = time.perf_counter()
-            p = subprocess.run([exe, "search", igd_path, "-q", bed_path] + extra,
-                               stdout=subprocess.DEVNULL if name == "q_f" else subprocess.PIPE, stderr=subprocess.DEVNULL)
-            dt = time.perf_counter() - t
-            if p.returncode != 0:
-                best = None
-                break
-            best = dt if best is None else min(best, dt)
-            worst = dt if worst is None else max(worst, dt)
-            if name == "q":
-                tot = [int(l.split(":")[1]) for l in p.stdout.decode().splitlines()[-2:] if l.startswith("Total:")]
-                ok = bool(tot) and tot[0] == expect_total
-        out[name + "_seconds"] = best
-        out[name + "_seconds_slowest"] = worst
-        if ok is not None:
-            out["q_total_matches_gpu"] = ok
-    out["q_route"] = ("the host's threads (igd_hostpath.c: the file is below igdc_host_limit() = 250 000 queries per usable thread, <= 4e6 -- where "
-                      "the host route takes as long as the engine route's best run); q_engine_only_* = the same command with IGD_HOST_MAX_QUERIES=0")
+        for route, env in (("", None), ("_engine", eng_env)):
+            if name == "q" and route:
+                continue                                    # (timed below with the phase table)
+            best, worst, ok = None, None, None
+            for _ in range(repeats if name != "q_f" else 3):
+                t = time.perf_counter()
+                p = subprocess.run([exe, "search", igd_path, "-q", bed_path] + extra, env=env,
+                                   stdout=subprocess.DEVNULL if name == "q_f" else subprocess.PIPE, stderr=subprocess.DEVNULL)
+                dt = time.perf_counter() - t
+                if p.returncode != 0:
+                    best = None
+                    break
+                best = dt if best is None else min(best, dt)
+                worst = dt if worst is None else max(worst, dt)
+                if name == "q":
+                    tot = [int(l.split(":")[1]) for l in p.stdout.decode().splitlines()[-2:] if l.startswith("Total:")]
+                    ok = bool(tot) and tot[0] == expect_total
+            out[name + route + "_seconds"] = best
+            out[name + route + "_seconds_slowest"] = worst
+            if ok is not None:
+                out["q_total_matches_gpu"] = ok
+    out["q_f_route"] = "engine" if not (limit is not None and 0 < nq <= host_route_limit_enum()) else "host"
     # the same file sent to the GPU whatever its size, with the tool's own phase table (IGD_TIMING) of the fastest and the
     # slowest of the repeats: what a search costs before its first kernel varies from run to run on one box
     try:
@@ -225,6 +236,7 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
             runs.sort(key=lambda r: r[0])
             out["q_engine_only_seconds"] = runs[0][0]
             out["q_engine_only_seconds_slowest"] = runs[-1][0]
+            out["q_engine_only_seconds_median"] = runs[len(runs) // 2][0]
             out["q_engine_only_phases_fastest"] = runs[0][1]
             out["q_engine_only_phases_slowest"] = runs[-1][1]
         try:
@@ -246,7 +258,7 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
             q = os.path.join(os.path.dirname(bed_path), "q%d.bed" % n)
             if not os.path.exists(q):
                 subprocess.check_call([synth_exe, "queries", q, "--n", str(n)], stdout=subprocess.DEVNULL)
-            row = {"queries": n}
+            row = {"queries": n, "product_route": "host" if (limit and n <= limit) else "engine"}
             outs = {}
             for who, cmd, env in (("reference", [ref], None), ("product", [exe], None),
                                   ("product_engine_only", [exe], dict(os.environ, IGD_HOST_MAX_QUERIES="0"))):
@@ -266,8 +278,8 @@ def cli_end_to_end(igd_path, bed_path, expect_total, repeats=5):
             row["stdout_identical"] = len(set(outs.values())) == 1 and len(outs) >= 2
             rows.append(row)
         out["small_files"] = rows
-        out["small_files_note"] = ("files of at most IGD_HOST_MAX_QUERIES queries (default: 250 000 per usable host thread, at most 4e6 -- the size at which "
-                                   "the host route takes as long as the engine route's best run) are counted on the host (igd_hostpath.c, product code); "
+        out["small_files_note"] = ("files of at most igdc_host_limit() queries (25 000 per usable host thread; IGD_HOST_MAX_QUERIES overrides) are "
+                                   "counted on the host (igd_hostpath.c, product code): product_route says who counted product_seconds; "
                                    "product_engine_only = the same file sent to the GPU")
     except Exception as e:
         out["small_files"] = {"error": str(e)}
@@ -558,9 +570,9 @@ def extra_configs(db, dev, stream, args, box):
     slab8 = synth.make_queries_slab(8 * CONFIG4_PER_GPU, 0, CONFIG4_PER_GPU, seed=7, genome=synth.HG38)
     cases = [("config 3: -v 500, 10^6 position-sorted queries", base, 500, 1, 100, "config2_sorted_q1000000_v500"),
              ("10^6 queries in generation order (flags = IGD_HIP_FLAG_BUCKET, what the command line tool's parser passes for a file it has seen out of order)",
-              shuf, 0, 2, 100, "config2_sorted_q1000000_v0"),
+              shuf, 0, 2, 100, "shuffled_bucket_q1000000_v0=config2_sorted_q1000000_v0"),
              ("the same 10^6 queries in generation order with flags = 0: the device checks the order itself and then takes the bucket path", shuf, 0, 0, 100,
-              "config2_sorted_q1000000_v0"),
+              "shuffled_auto_q1000000_v0=config2_sorted_q1000000_v0"),
              ("config 4 per-GPU share: 1.25e7 position-sorted queries in one batch on one GPU", dense, 0, SHORT, 30, "config4_share_q12500000_v0"),
              ("config 4 as one of 8 GPUs sees it: slab 0 (1.25e7 queries) of the 10^8 position-sorted queries", slab8, 0, SHORT, 30,
               "config4_slab0_of_8_v0"),
@@ -619,13 +631,17 @@ def extra_configs(db, dev, stream, args, box):
         except Exception as e:
             out.append({"workload": "stress: database " + tag, "error": str(e)})
     for (name, (ichr, qs, qe), v, gflags, steps, gkey), db in zip(cases, dbs):
+        # "row=fixture": the row's short name and the oracle fixture its counts are compared with (a shuffled batch has the
+        # counts of the same queries position-sorted)
+        rkey, _, gkey = gkey.partition("=")
+        gkey = gkey or rkey
         try:
             job = Job(db, dev, stream, ichr, qs, qe, v, gflags, args.query_layout)
             el, prof = job.run(steps, 3)
             rl = job.roofline(prof)
             hj = job.d_hits.cpu().numpy()
             assert (hj % steps == 0).all(), "hits[] is not K times one batch"
-            ent = {"workload": name, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
+            ent = {"key": rkey, "workload": name, "flags": gflags, "value": len(qs) * steps / el, "unit": "query-intervals/s", "steps": steps,
                    "ms_per_step": 1e3 * el / steps, "kernel": rl["kernel"], "kernel_ms": prof["scan_ms"], "pipeline_ms": prof["pipeline_ms"],
                    "roofline_frac": rl["frac"],
                    "bytes_per_launch": rl["bytes_per_launch"], "algorithmic_frac": rl["algorithmic_frac"],
@@ -640,7 +656,7 @@ def extra_configs(db, dev, stream, args, box):
             out.append(ent)
             del job
         except Exception as e:                              # a side measurement must not lose the line
-            out.append({"workload": name, "error": str(e)})
+            out.append({"key": rkey, "workload": name, "error": str(e)})
     db = dbs[0]
     for odb in others:
         odb.close()
@@ -656,7 +672,7 @@ def extra_configs(db, dev, stream, args, box):
             best = dt if best is None else min(best, dt)
         nbytes = 16 * tot
         d2h = box.get("d2h_GBps") or 0.0
-        out.append({"workload": "config 5: -f enumeration of 10^6 position-sorted queries, overlaps streamed to pinned host memory "
+        out.append({"key": "config5_f_q1000000", "workload": "config 5: -f enumeration of 10^6 position-sorted queries, overlaps streamed to pinned host memory "
                                 "(igd_hip_enumerate_stream, H2D of the queries included)",
                     "value": Q / best, "unit": "query-intervals/s", "ms_per_call": 1e3 * best, "overlaps": int(tot),
                     "records_per_s": tot / best, "output_bytes": int(nbytes),
@@ -664,7 +680,7 @@ def extra_configs(db, dev, stream, args, box):
                                  "frac": (nbytes / best / 1e9 / d2h) if d2h else None,
                                  "peak_source": "pinned device->host hipMemcpyAsync of 256 MiB measured in this run"}})
     except Exception as e:
-        out.append({"workload": "config 5: -f", "error": str(e)})
+        out.append({"key": "config5_f_q1000000", "workload": "config 5: -f", "error": str(e)})
     return out
 
 
@@ -689,6 +705,145 @@ def scale_anchor(extras):
            "note": "efficiency above 1 is expected: a slab of a larger sorted set touches fewer tiles (N = 8: one tile in eight, "
                    "530 queries per tile), so a rank's step gets SHORTER as N grows"}
     return out
+
+
+LINE_CAP = 8192      # the driver keeps the last ~8 KB of stdout: the final line must fit whole
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (the compact line's numbers; the side file keeps them whole)"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def host_route_limit():
+    """igdc_host_limit() of the product library: query files of at most this many lines are counted by the host's threads"""
+    try:
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(ROOT, "igd_amd", "lib", "libigd.so"))
+        lib.igdc_host_limit.restype = ctypes.c_int64
+        return int(lib.igdc_host_limit())
+    except Exception:
+        return None
+
+
+def host_route_limit_enum():
+    try:
+        import ctypes
+        lib = ctypes.CDLL(os.path.join(ROOT, "igd_amd", "lib", "libigd.so"))
+        lib.igdc_host_limit_enum.restype = ctypes.c_int64
+        return int(lib.igdc_host_limit_enum())
+    except Exception:
+        return 0
+
+
+def compact_line(full, extra_path):
+    """The ONE stdout line: the contract keys, the roofline and cpu_baseline objects and a few numbers per side measurement --
+    everything else (phase tables, per-P sweeps, byte breakdowns, long workload descriptions) lives in the side file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: _r(full[k]) for k in keep}
+    cfg = full["config"]
+    out["config"] = {k: cfg[k] for k in ("workload", "queries_per_gpu", "queries_per_step_all_gpus", "nfiles", "parallelism",
+                                         "grouping", "collective") if k in cfg}
+    rl = full["roofline"]
+    o = {k: _r(rl.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "traffic", "kernel_ms",
+                                    "pipeline_ms", "launches_timed", "frac_pmc", "step_frac", "algorithmic_bytes_per_launch",
+                                    "algorithmic_frac")}
+    o["bytes_source"] = "compulsory bytes of the launch, computed in this run (igd_hip_batch_traffic)"
+    if rl.get("traffic_source"):
+        o["traffic_source"] = rl["traffic_source"][:90]
+    for c in ("cold", "cold_after_writes"):
+        if isinstance(rl.get(c), dict) and rl[c].get("kernel_ms"):
+            o[c] = {"kernel_ms": _r(rl[c]["kernel_ms"]), "frac": _r(rl[c].get("frac"))}
+    if isinstance(rl.get("box"), dict):
+        o["box"] = {k: _r(v, 4) for k, v in rl["box"].items() if isinstance(v, (int, float))}
+    out["roofline"] = o
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "kind", "seconds", "totals_match_gpu")}
+        c["sample"] = (cb.get("sample") or "")[:200]
+        c["cpu_model"] = (cb.get("host") or {}).get("cpu_model")
+        ac = cb.get("all_cores")
+        if isinstance(ac, dict) and ac.get("value"):
+            c["all_cores"] = {"value": _r(ac["value"]), "cores": ac.get("cores"), "seconds": _r(ac.get("seconds")),
+                              "totals_match_gpu": ac.get("totals_match_gpu")}
+        al = cb.get("all_cores_large")
+        if isinstance(al, dict) and al.get("value"):
+            c["all_cores_large"] = {"value": _r(al["value"]), "cores": al.get("cores"), "queries": al.get("queries"),
+                                    "seconds": _r(al.get("seconds")), "totals_match_oracle_fixture": al.get("totals_match_oracle_fixture")}
+        out["cpu_baseline"] = c
+    for k in ("matches_oracle", "n_ranks_seen", "dist_backend", "hits_per_step_total", "hits_checksum", "efficiency_vs_anchor"):
+        if k in full:
+            out[k] = _r(full[k])
+    out["db_open_s"] = _r(full.get("db_open_s"), 3)
+    if "devices" in full:
+        out["devices"] = [d[:60] for d in full["devices"]][:8]
+    if "extra_configs" in full:                 # one short row per side measurement: key, step, dominant kernel, fraction, parity
+        rows = []
+        for e in full["extra_configs"]:
+            row = {"workload": e.get("key") or e.get("workload", "")[:40]}
+            if "error" in e:
+                row["error"] = str(e["error"])[:80]
+            else:
+                row["ms_per_step"] = _r(e.get("ms_per_step", e.get("ms_per_call")), 4)
+                if e.get("kernel_ms") is not None:
+                    row["kernel"] = (e.get("kernel") or "").replace("igd_scan_", "")
+                    row["kernel_ms"] = _r(e["kernel_ms"], 4)
+                fr = e.get("roofline_frac", (e.get("roofline") or {}).get("frac"))
+                row["frac"] = _r(fr, 3)
+                if "matches_oracle" in e:
+                    row["matches_oracle"] = e["matches_oracle"]
+            rows.append(row)
+        out["extra_configs"] = rows
+    sa = full.get("scale_anchor")
+    if isinstance(sa, dict):
+        if "step_ms" in sa:
+            out["scale_anchor"] = {"step_ms": {k: _r(v, 4) for k, v in sa["step_ms"].items()}}
+        elif "ms_per_step" in sa:
+            out["scale_anchor"] = {"ms_per_step": _r(sa["ms_per_step"], 4), "value": _r(sa.get("value"))}
+        else:
+            out["scale_anchor"] = {"error": str(sa.get("error"))[:80]}
+    sp = full.get("scale_prediction")
+    if isinstance(sp, dict) and "step_ms" in sp:
+        out["scale_prediction"] = {"step_ms": sp["step_ms"], "source": str(sp.get("source"))[:120], "this_run_vs_predicted_step": _r(sp.get("this_run_vs_predicted_step"), 4)}
+    ce = full.get("cli_end_to_end")
+    if isinstance(ce, dict) and "error" not in ce:
+        out["cli_end_to_end"] = {"what": "wall seconds of `bin/igd search <db> -q <the workload's BED>`, best of N; route = who counts: "
+                                         "engine (MI355X) or host (CPU threads, files below igdc_host_limit)",
+                                 "default_route": ce.get("default_route"), "default_seconds": _r(ce.get("q_seconds"), 4),
+                                 "engine_seconds": _r(ce.get("q_engine_only_seconds"), 4),
+                                 "engine_seconds_median": _r(ce.get("q_engine_only_seconds_median"), 4),
+                                 "engine_seconds_slowest": _r(ce.get("q_engine_only_seconds_slowest"), 4),
+                                 "engine_v500_seconds": _r(ce.get("q_v500_engine_seconds"), 4),
+                                 "engine_f_seconds": _r(ce.get("q_f_engine_seconds"), 4),
+                                 "reference_seconds": _r(ce.get("reference_q_seconds"), 4),
+                                 "total_matches_gpu": ce.get("q_total_matches_gpu")}
+    out["extra_file"] = extra_path
+    text = json.dumps(out, separators=(",", ":"))
+    # never lose the line to its size: drop the optional parts, largest first, until it fits
+    for k in ("devices", "cli_end_to_end", "scale_prediction", "extra_configs", "scale_anchor"):
+        if len(text) <= LINE_CAP - 200:
+            break
+        out.pop(k, None)
+        out["dropped_for_size"] = out.get("dropped_for_size", []) + [k]
+        text = json.dumps(out, separators=(",", ":"))
+    return text
+
+
+def write_extra(full, path):
+    """The whole record (every side measurement in full) as a file beside bench.py; returns the path it was written to."""
+    for cand in (path, os.path.join("/tmp", os.path.basename(path))):
+        try:
+            os.makedirs(os.path.dirname(cand) or ".", exist_ok=True)
+            with open(cand, "w") as fh:
+                json.dump(full, fh, indent=1)
+                fh.write("\n")
+            return cand
+        except OSError:
+            continue
+    return None
 
 
 def main():
@@ -897,7 +1052,11 @@ def main():
                     line["scale_prediction"]["this_run_vs_predicted_step"] = (1e3 * elapsed / args.steps) / pm
             except Exception as e:
                 line["scale_prediction"] = {"error": str(e)}
-        print(json.dumps(line), flush=True)
+        extra_path = write_extra(line, args.extra_out or os.path.join(ROOT, "bench_extra.json"))
+        log("[bench] the whole record (%d bytes as one JSON line) is in %s" % (len(json.dumps(line)), extra_path))
+        text = compact_line(line, os.path.relpath(extra_path, ROOT) if extra_path and extra_path.startswith(ROOT) else extra_path)
+        assert len(text) <= LINE_CAP and "\n" not in text, len(text)
+        print(text, flush=True)
     del job
     db.close()
     if grouped:

@@ -416,7 +416,11 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     // 2. One lane per wave reports (hundreds of thousands of stores to ONE address would queue up for tens of
     // microseconds), and a wave that has seen disorder leaves: nothing it would still produce is going to be read.
     {
-        const unsigned long long bu = __ballot(unordered), bs = __ballot(notStart);
+        // IGD_HIP_FLAG_SORTED promises the order (contig, START): starts that decrease inside a tile break it like anything else,
+        // and the batch adds nothing -- whichever step it would have taken (the DIRECT step's rank method needs that order in
+        // every tile, its heavy-tile slices in the last launch included: found HERE, before anything is counted).  Without the
+        // promise such a batch is a legal merge-join batch: the pairwise compares hold, the rank method is switched off.
+        const unsigned long long bu = __ballot(unordered || (promised && notStart)), bs = __ballot(notStart);
         if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
                                                                             // the merge join still holds, the rank method does not
         if (bu) {

@@ -73,7 +73,7 @@
 #ifndef IGD_WG
 #define IGD_WG 1024                          // threads per scan workgroup (16 waves; 2 workgroups per CU)
 #endif
-#define IGD_MAX_BATCH (1ll << 24)            // queries per device batch
+#define IGD_MAX_BATCH ((long long)IGD_HIP_MAX_BATCH_DEFAULT)   // queries per device batch (include/igd_hip.h)
 #define IGD_SCAN_ITEMS 16                    // elements per thread in the tile scan
 #define IGD_SCAN_BLOCK 256
 #define IGD_SCAN_TILE (IGD_SCAN_ITEMS * IGD_SCAN_BLOCK)
@@ -178,9 +178,7 @@ extern "C" int igd_hip_device_count(void)
 static int64_t max_batch(void)
 {
     static const int64_t m = []() -> int64_t {
-        const char *e = getenv("IGD_HIP_MAX_BATCH");
-        const long long x = e && *e ? atoll(e) : 0;
-        return x >= 1 && x < IGD_MAX_BATCH ? (int64_t)x : (int64_t)IGD_MAX_BATCH;
+        return igd_hip_max_batch_rule(getenv("IGD_HIP_MAX_BATCH"));      // (include/igd_hip.h: shared with igd_hip_lazy.c)
     }();
     return m;
 }

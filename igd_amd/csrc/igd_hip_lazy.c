@@ -84,9 +84,7 @@ int igd_hip_device_count(void)
  * engine's max_batch(): 2^24 queries, lowered by the TEST-ONLY variable IGD_HIP_MAX_BATCH. */
 int64_t igd_hip_max_batch(void)
 {
-    const char *e = getenv("IGD_HIP_MAX_BATCH");
-    const long long x = e && *e ? atoll(e) : 0;
-    return x >= 1 && x < ((long long)1 << 24) ? (int64_t)x : ((int64_t)1 << 24);
+    return igd_hip_max_batch_rule(getenv("IGD_HIP_MAX_BATCH"));    /* (include/igd_hip.h: the one definition) */
 }
 
 int igd_hip_open(const igd_hip_desc *desc, int device, igd_hip_db **out)

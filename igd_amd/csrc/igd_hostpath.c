@@ -33,20 +33,15 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-/* Where the engine starts to pay: a model of two measured rates, not a constant.
- *   engine route  t_e(n) = F + n * p        F = what a command line search costs before its first kernel -- HIP runtime,
- *                                           851 MB through PCIe, transposes: 0.18 s at best on the pool's hosts (2 x EPYC 9575F
- *                                           + MI355X), 0.40-0.48 s in every third run of the same command on the same box
- *                                           (runtime start-up and first allocations vary that much; profiles/r05/cli_walls.txt);
- *                                           p = 7 ns per query (the threaded parser; the kernels are below 0.1 ns)
- *   host route    t_h(n) = 0.03 s + n * h / T   h = 0.55 us per query and counting thread (the reference's per-query algorithm
- *                                           over pread, this file), T = min(threads, 16): measured 0.068 / 0.087 / 0.166 s for
- *                                           1 / 2 / 4 x 10^6 queries at T = 16, 0.086 / 0.118 / 0.170 s at T = 8
- * t_h(n) = t_e(n) with F = 0.18 s gives n = 0.15 s * T / 0.53 us = 280 000 * T: the limit is 250 000 queries per usable thread,
- * at most 4 x 10^6 -- where the host route takes as long as the engine route's BEST run (reference: 1.13 s).  A host whose
- * threads do not scale (the 8-vCPU build sandbox: 1.4 us per query whatever T) would want a lower limit; there is no way to know
- * without timing, so IGD_HOST_MAX_QUERIES overrides it (0: every file goes to the GPU).
- * `-f` prints ~35 bytes per overlap and its host route formats on fewer threads: it keeps the round-4 limit (25 000 per thread). */
+/* Where the engine takes over.  The host route exists for SMALL query files -- a search of 10^3 .. 10^5 lines should not pay
+ * the accelerator's start-up (HIP runtime + 851 MB through PCIe: 0.18 s at best, 0.4-0.5 s in many runs, LABNOTES R5-3) --
+ * not to carry the product's headline workloads on CPU threads.  Round 6: the limit is back at
+ * the conservative round-4 value, 25 000 queries per usable thread (<= 400 000), the same as `-f`'s.  Round 5's model
+ * (engine F + n * 7 ns against host 0.03 s + n * 0.55 us / T, crossing at ~280 000 * T) assumed the engine route's BEST start-up
+ * and threads that scale; on a host where they do not (1.4 us per query whatever T) it sent 2e6-query files to a 2.8 s host
+ * route.  With this limit the worst case of the model's error is ~0.1 s either way, and a 10^6-query file -- BASELINE config 2
+ * -- is counted by the MI355X.  IGD_HOST_MAX_QUERIES overrides it (0: every file goes to the GPU).  This file is frozen:
+ * bench.py times every size on BOTH routes and labels who counted. */
 static int64_t host_threads_usable(void)
 {
     long t = sysconf(_SC_NPROCESSORS_ONLN);
@@ -67,8 +62,7 @@ int64_t igdc_host_limit(void)
 {
     const int64_t e = host_limit_env();
     if (e >= 0) return e;
-    const int64_t lim = 250000 * host_threads_usable();
-    return lim > 4000000 ? 4000000 : lim;
+    return 25000 * host_threads_usable();
 }
 int64_t igdc_host_limit_enum(void)
 {

@@ -93,6 +93,9 @@ int64_t igd_hip_resident_bytes(const igd_hip_db *db); /* HBM held by the SoA ima
  *   IGD_HIP_FLAG_SORTED   the caller PROMISES that order, which skips enqueueing the bucket
  *                         kernels.  The promise is verified on the device: if it does not hold,
  *                         that batch adds nothing and igd_hip_sync returns IGD_HIP_ERR_UNSORTED.
+ *                         The promise is (contig index, START) -- starts that decrease inside one
+ *                         tile break it too, whichever step the batch takes (without the promise
+ *                         such a batch is counted by the merge join's pairwise compares).
  *   IGD_HIP_FLAG_BUCKET   the caller KNOWS the batch is not in that order (the command line tool's
  *                         parser saw a line out of order): no order check, no merge-join launch,
  *                         always the counting sort.  Never wrong -- the counting sort takes any
@@ -139,6 +142,15 @@ int igd_hip_search_dev(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_q
 int igd_hip_search_runs_dev(igd_hip_db *db, const int32_t *d_run_start, const int32_t *d_qs, const int32_t *d_qe,
                             int64_t nq, int32_t v, int rule, int flags, int64_t *d_hits, int64_t *d_total, void *stream);
 int64_t igd_hip_max_batch(void);   /* queries per call of the host-buffer entry points (2^24; test-only IGD_HIP_MAX_BATCH lowers it) */
+/* The rule behind igd_hip_max_batch(), in ONE place: the engine (igd_hip.hip) and the host flavours' lazy binding
+ * (igd_hip_lazy.c, which answers without mapping the engine) both evaluate this -- they cannot drift apart. */
+#define IGD_HIP_MAX_BATCH_DEFAULT ((int64_t)1 << 24)
+static inline int64_t igd_hip_max_batch_rule(const char *env /* getenv("IGD_HIP_MAX_BATCH") or NULL */)
+{
+    long long x = 0;
+    if (env && *env) { int neg = 0; const char *p = env; if (*p == '-') { neg = 1; p++; } while (*p >= '0' && *p <= '9' && x < ((long long)1 << 40)) x = x * 10 + (*p++ - '0'); if (neg) x = -x; }
+    return x >= 1 && x < IGD_HIP_MAX_BATCH_DEFAULT ? (int64_t)x : IGD_HIP_MAX_BATCH_DEFAULT;
+}
 int  igd_hip_sync(igd_hip_db *db, void *stream);      /* wait + surface async errors         */
 int  igd_hip_sync_spin(igd_hip_db *db, void *stream); /* the same, polling hipStreamQuery instead of sleeping on the signal */
 

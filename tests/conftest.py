@@ -36,7 +36,7 @@ def pytest_sessionstart(session):
 
 @pytest.fixture(autouse=True)
 def _gpu_tests_send_every_query_file_to_the_engine(request, monkeypatch):
-    """Query files of at most IGD_HOST_MAX_QUERIES lines (default: 250 000 per usable host thread, at most 4 000 000 -- igdc_host_limit; `-f`: 25 000 per thread) are counted on the host by the flavours' file
+    """Query files of at most IGD_HOST_MAX_QUERIES lines (default: 25 000 per usable host thread -- igdc_host_limit, igdc_host_limit_enum) are counted on the host by the flavours' file
     entry points (igd_hostpath.c: the reference's cheap start for small jobs).  The `-m gpu` tests are the parity tests of
     the HIP path and their fixtures are small, so they run with the limit at 0: every file goes to the engine.  A GPU test
     that wants the product's default behaviour carries the marker `hostpath`."""

@@ -12,17 +12,45 @@ import pytest
 from helpers import ROOT, short_tmpdir
 
 pytestmark = pytest.mark.gpu
+LINE_CAP = 8192          # bench.py's LINE_CAP: what the driver's stdout tail holds
 
 
 def test_bench_prints_one_json_line_with_the_contract_keys():
     d = short_tmpdir("igb")
     try:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--files", "40", "--per-file", "3000", "--queries", "20000",
-                            "--steps", "3", "--warmup", "1", "--dir", d], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                            "--steps", "3", "--warmup", "1", "--dir", d, "--extra-out", os.path.join(d, "bench_extra.json")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
         assert p.returncode == 0, p.stderr.decode()[-800:]
         lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
         assert len(lines) == 1
-        j = json.loads(lines[0])
+        # the driver keeps the last ~8 KB of stdout: the line must fit whole (round 5's 20 KB line was never parsed)
+        assert len(lines[0]) <= LINE_CAP, len(lines[0])
+        c = json.loads(lines[0])
+        assert "dropped_for_size" not in c
+        # the compact line: the contract keys + roofline + cpu_baseline + one short row per side measurement
+        for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+            assert isinstance(c[k], t), k
+        assert c["n_gpus"] == 1 and c["steps"] == 3 and c["warmup"] == 1 and c["vs_baseline"] is None and "workload" in c["config"]
+        assert abs(c["value"] - 20000 * 3 / (c["ms_per_step"] * 3e-3)) / c["value"] < 1e-4
+        cr = c["roofline"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "traffic", "kernel_ms"):
+            assert k in cr, k
+        assert cr["bound"] == "hbm" and cr["peak"] == 8000.0 and 0 < cr["frac"] <= 1.0 and abs(cr["frac"] - cr["achieved"] / 8000.0) < 1e-4
+        cc = c["cpu_baseline"]
+        assert cc["kind"] in ("reference", "port") and cc["cores"] == 1 and cc["value"] > 0 and cc["seconds"] > 0 and cc["totals_match_gpu"] is True
+        assert c["n_ranks_seen"] == 1 and "matches_oracle" not in c     # (not the fixture's database size)
+        xr = c["extra_configs"]
+        assert len(xr) == 16 and len(set(r["workload"] for r in xr)) == 16 and not any("error" in r for r in xr), xr
+        assert all(r["ms_per_step"] > 0 and set(r) <= {"workload", "ms_per_step", "kernel", "kernel_ms", "frac", "matches_oracle"} for r in xr)
+        ce = c["cli_end_to_end"]
+        assert ce["default_route"] in ("host", "engine") and ce["engine_seconds"] > 0 and ce["default_seconds"] > 0
+        assert set(c["scale_anchor"]["step_ms"]) == {"1", "2", "4", "8"}
+        # ... and the whole record in the side file the line names
+        assert c["extra_file"] and os.path.exists(os.path.join(d, "bench_extra.json"))
+        j = json.load(open(os.path.join(d, "bench_extra.json")))
+        assert abs(j["value"] - c["value"]) / j["value"] < 1e-5 and j["roofline"]["kernel"] == cr["kernel"]
         for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
             assert isinstance(j[k], t), k
@@ -39,6 +67,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         c = j["cpu_baseline"]
         x = j["extra_configs"]
         assert len(x) == 16 and not any("error" in e for e in x), x
+        assert [e["key"] for e in x] == [r["workload"] for r in xr]
         assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
         assert sum(e["workload"].startswith("stress:") for e in x) == 6
         # every row but `-f` carries the comparison with the oracle's fixture (None here: not the fixture's database size)
@@ -54,6 +83,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert [row["queries"] for row in small] == [1000, 10000, 100000, 300000, 1000000, 3000000] and all(row["product_seconds"] > 0 for row in small)
         assert all(row["stdout_identical"] for row in small if "reference_seconds" in row)
         assert e2e["q_seconds"] > 0 and e2e["q_v500_seconds"] > 0 and e2e["q_f_seconds"] > 0 and e2e["q_total_matches_gpu"] is True
+        # both routes at every size, each labelled with who counted
+        assert e2e["default_route"] in ("host", "engine") and e2e["q_v500_engine_seconds"] > 0 and e2e["q_f_engine_seconds"] > 0
+        assert all(row["product_route"] in ("host", "engine") and row["product_engine_only_seconds"] > 0 for row in small)
         # the engine route's own seconds with the tool's phase table of the fastest and the slowest repeat
         assert e2e["q_engine_only_seconds"] > 0 and e2e["q_engine_only_seconds_slowest"] >= e2e["q_engine_only_seconds"]
         assert any("HIP runtime init" in l for l in e2e["q_engine_only_phases_fastest"]) and e2e["q_engine_only_phases_slowest"]
@@ -89,7 +121,7 @@ def test_bench_two_ranks_config4_slabs_and_allreduce(launcher):
         env.pop("WORLD_SIZE", None)
         env.pop("RANK", None)
         tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", str(files), "--per-file", str(per_file),
-                "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d]
+                "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d, "--extra-out", os.path.join(d, "bench_extra.json")]
         if launcher == "self-spawn":
             cmd = [sys.executable] + tail
         else:
@@ -99,6 +131,7 @@ def test_bench_two_ranks_config4_slabs_and_allreduce(launcher):
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
         assert len(lines) == 1, p.stdout.decode()[-800:]
+        assert len(lines[0]) <= LINE_CAP, len(lines[0])
         j = json.loads(lines[0])
         assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 3
         assert "config 4" in j["config"]["workload"] and "all-reduce" in j["config"]["collective"]
@@ -168,7 +201,7 @@ def test_bench_one_rank_forced_through_the_collective_path():
                    MASTER_PORT=str(29900 + os.getpid() % 40), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("IGD_DIST_BACKEND", None)
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--files", "40", "--per-file", "3000", "--queries", "20000",
-                            "--steps", "3", "--warmup", "1", "--dir", d, "--no-extra", "--no-cpu"],
+                            "--steps", "3", "--warmup", "1", "--dir", d, "--no-extra", "--no-cpu", "--extra-out", os.path.join(d, "bench_extra.json")],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         j = json.loads([l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")][0])
@@ -190,7 +223,7 @@ def test_bench_fails_fast_when_a_rank_dies():
         env.pop("RANK", None)
         t = time.time()
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--files", "40", "--per-file", "3000",
-                            "--queries", "15000", "--steps", "3", "--warmup", "1", "--dir", d],
+                            "--queries", "15000", "--steps", "3", "--warmup", "1", "--dir", d, "--extra-out", os.path.join(d, "bench_extra.json")],
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
         assert p.returncode != 0 and time.time() - t < 120
         assert b"rank 1 failed" in p.stderr, p.stderr.decode()[-800:]
@@ -227,14 +260,16 @@ def test_bench_eight_ranks_control_flow_on_one_gpu():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
                "--master-addr", "127.0.0.1", "--master-port", str(29300 + os.getpid() % 250),
                os.path.join(ROOT, "bench.py"), "--gpus", "8", "--files", str(files), "--per-file", str(per_file),
-               "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d]
+               "--queries", str(q), "--steps", "3", "--warmup", "1", "--dir", d, "--extra-out", os.path.join(d, "bench_extra.json")]
         t = time.time()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
         wall = time.time() - t
         assert p.returncode == 0, p.stderr.decode()[-1500:]
         lines = [l for l in p.stdout.decode().splitlines() if l.strip().startswith("{")]
         assert len(lines) == 1, p.stdout.decode()[-800:]
+        assert len(lines[0]) <= LINE_CAP, len(lines[0])
         j = json.loads(lines[0])
+        assert "dropped_for_size" not in j and j["roofline"]["kernel_ms"] > 0
         assert j["n_gpus"] == 8 and j["n_ranks_seen"] == 8 and len(j["devices"]) == 8 and j["scaling"] == "weak"
         assert all(("rank %d:" % r) in j["devices"][r] for r in range(8))
         assert j["config"]["queries_per_gpu"] == q and j["config"]["queries_per_step_all_gpus"] == 8 * q

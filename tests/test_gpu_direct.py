@@ -216,6 +216,59 @@ def test_broken_promises_add_nothing_and_leave_the_handle_usable(workdir, monkey
         db.close(); orc.close()
 
 
+def test_broken_start_order_inside_a_heavy_tile_adds_nothing(workdir, monkeypatch):
+    """a tile with more than IGD_HEAVY_FIRST (8192) queries is left to the batch's last launch, whose slices
+    add to the caller's hits[] with global atomics -- after k_reduce_slabs has looked at the order mark.  Two starts swapped
+    INSIDE such a tile must be found before anything is counted (the bounds pass reads every start): the raw batch reports
+    IGD_HIP_ERR_UNSORTED and adds nothing; Database.search repairs it exactly (no double count).  Same contract on the
+    ordinary step (flags SORTED without SHORT on a sparse-on-average batch)."""
+    import torch
+    from igd_amd import Database, synth
+    from igd_amd.database import IgdError
+    path = os.path.join(workdir, "hv.igd")
+    synth.make_db(path, files=20, per_file=4000, seed=9, nbp_log=14, genome=synth.SMALL)
+    orc, db = Oracle(path), Database(path)
+    try:
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(12)
+        ntiles = sum(db.ntile)
+        base = synth.make_queries(30 * ntiles, seed=5, genome=synth.SMALL, min_len=100, max_len=1999, sorted_=True)
+        # + 20 000 queries inside tile 3 of contig 0: a heavy tile
+        ps = (3 * 16384 + rng.integers(0, 16384, 20000)).astype(np.int32)
+        ichr = np.concatenate([base[0], np.zeros(20000, np.int32)])
+        qs = np.concatenate([base[1], ps])
+        qe = np.concatenate([base[2], (ps + rng.integers(100, 1999, 20000)).astype(np.int32)])
+        o = np.lexsort((qs, ichr))
+        ichr, qs, qe = ichr[o], qs[o], qe[o]
+        want, wtot = orc.search(ichr, qs, qe, 0)
+        got, gtot, kern = _dev_search(db, torch, ichr, qs, qe, flags=FLAG_SORTED | FLAG_SHORT)
+        assert kern == "igd_scan_direct" and gtot == wtot
+        np.testing.assert_array_equal(got, want)
+        inside = np.flatnonzero((ichr == 0) & (qs // 16384 == 3))
+        assert len(inside) > 8192 * 2
+        for where in (inside[10], inside[len(inside) // 2], inside[-3]):        # first slice, a middle slice, the last one
+            k = where + 1
+            while qs[k] == qs[where]:
+                k += 1
+            assert ichr[k] == 0 and qs[k] // 16384 == 3
+            p = np.arange(len(qs)); p[where], p[k] = p[k], p[where]
+            a, b, c = ichr[p], qs[p], qe[p]
+            for flags in (FLAG_SORTED | FLAG_SHORT, FLAG_SORTED):
+                hits = torch.zeros(db.nfiles, dtype=torch.int64, device=dev)
+                with pytest.raises(IgdError):
+                    _dev_search(db, torch, a, b, c, flags=flags, hits=hits)
+                assert int(hits.sum().item()) == 0, (where, flags)
+                h2, t2 = db.search(a, b, c, 0, flags=flags)
+                assert t2 == wtot
+                np.testing.assert_array_equal(h2, want)
+            # unpromised, the same batch is an ordinary merge-join batch (pairwise compares; CTL_NOTSTART)
+            got, gtot, _ = _dev_search(db, torch, a, b, c, flags=0)
+            assert gtot == wtot
+            np.testing.assert_array_equal(got, want)
+    finally:
+        db.close(); orc.close()
+
+
 def test_the_engine_picks_the_direct_step_for_dense_short_sorted_batches_only(workdir):
     import torch
     from igd_amd import Database, synth
