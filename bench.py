@@ -660,25 +660,33 @@ def extra_configs(db, dev, stream, args, box):
     db = dbs[0]
     for odb in others:
         odb.close()
-    # config 5: -f through the C API (count + scan + chunked fill + pinned D2H, result in host memory)
+    # config 5: -f through the C API (count + scan + chunked fill + pinned D2H, result in host memory): the packed stream (8 bytes
+    # per overlap, round 6 -- what the command line tool moves) and the 16-byte igd_hip_hit stream beside it
     try:
         ichr, qs, qe = base
-        db.enumerate_stream(ichr, qs, qe)                   # warm: workspace + pinned buffers
-        best, tot = None, 0
-        for _ in range(3):
-            t = time.perf_counter()
-            _, tot = db.enumerate_stream(ichr, qs, qe)
-            dt = time.perf_counter() - t
-            best = dt if best is None else min(best, dt)
-        nbytes = 16 * tot
         d2h = box.get("d2h_GBps") or 0.0
-        out.append({"key": "config5_f_q1000000", "workload": "config 5: -f enumeration of 10^6 position-sorted queries, overlaps streamed to pinned host memory "
-                                "(igd_hip_enumerate_stream, H2D of the queries included)",
-                    "value": Q / best, "unit": "query-intervals/s", "ms_per_call": 1e3 * best, "overlaps": int(tot),
-                    "records_per_s": tot / best, "output_bytes": int(nbytes),
-                    "roofline": {"bound": "pcie-d2h", "achieved": nbytes / best / 1e9, "peak": d2h, "unit": "GB/s",
-                                 "frac": (nbytes / best / 1e9 / d2h) if d2h else None,
-                                 "peak_source": "pinned device->host hipMemcpyAsync of 256 MiB measured in this run"}})
+        for key, fn, per, what in (("config5_f_q1000000", db.enumerate_stream8, 8, "igd_hip_enumerate_stream8: 8 bytes per overlap (start | length | idx)"),
+                                   ("config5_f_hit16_q1000000", db.enumerate_stream, 16, "igd_hip_enumerate_stream: 16-byte igd_hip_hit records")):
+            if per == 8 and db.hit8_idx_bits() < 0:
+                continue
+            fn(ichr, qs, qe)                                # warm: workspace + pinned buffers
+            best, tot = None, 0
+            for _ in range(3):
+                t = time.perf_counter()
+                _, tot = fn(ichr, qs, qe)
+                dt = time.perf_counter() - t
+                best = dt if best is None else min(best, dt)
+            nbytes = per * tot
+            ent = {"key": key, "workload": "config 5: -f enumeration of 10^6 position-sorted queries, overlaps streamed to pinned host memory "
+                                           "(%s, H2D of the queries included)" % what,
+                   "value": Q / best, "unit": "query-intervals/s", "ms_per_call": 1e3 * best, "overlaps": int(tot),
+                   "records_per_s": tot / best, "output_bytes": int(nbytes),
+                   "roofline": {"bound": "pcie-d2h", "achieved": nbytes / best / 1e9, "peak": d2h, "unit": "GB/s",
+                                "frac": (nbytes / best / 1e9 / d2h) if d2h else None,
+                                "peak_source": "pinned device->host hipMemcpyAsync of 256 MiB measured in this run"}}
+            g = golden_counts("config2_sorted_q1000000_v0") if (args.files == 1900 and args.per_file == 26316) else None
+            ent["matches_oracle"] = (int(tot) == g[0]) if g else None      # (the number of overlaps = the counted total; the records: tests/test_gpu_fullsize.py)
+            out.append(ent)
     except Exception as e:
         out.append({"key": "config5_f_q1000000", "workload": "config 5: -f", "error": str(e)})
     return out
@@ -743,7 +751,7 @@ def compact_line(full, extra_path):
     everything else (phase tables, per-P sweeps, byte breakdowns, long workload descriptions) lives in the side file."""
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
-    out = {k: _r(full[k]) for k in keep}
+    out = {k: (full[k] if k in ("value", "ms_per_step") else _r(full[k])) for k in keep}    # (value = queries / time exactly)
     cfg = full["config"]
     out["config"] = {k: cfg[k] for k in ("workload", "queries_per_gpu", "queries_per_step_all_gpus", "nfiles", "parallelism",
                                          "grouping", "collective") if k in cfg}

@@ -106,6 +106,7 @@ class HipTraffic(C.Structure):
 
 
 ENUM_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_void_p)
+ENUM_SINK8 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int)
 
 IGD_HIP_NO_VALUE_FILTER = -(2 ** 31)
 IGD_HIP_FLAG_SORTED = 1
@@ -154,6 +155,9 @@ def hip():
         L.igd_hip_free.argtypes = [C.c_void_p]
         L.igd_hip_enumerate_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                                C.c_void_p, ENUM_SINK, C.c_void_p, i64p]
+        L.igd_hip_enumerate_stream8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                C.c_void_p, ENUM_SINK8, C.c_void_p, i64p]
+        L.igd_hip_hit8_idx_bits.argtypes = [C.c_void_p]
         L.igd_hip_batch_traffic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                             C.c_int32, C.c_int, C.c_int, C.POINTER(HipTraffic)]
         L.igd_hip_measure_rates.argtypes = [C.c_int, C.POINTER(C.c_double)]

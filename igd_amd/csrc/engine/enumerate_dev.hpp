@@ -25,11 +25,12 @@ __device__ __forceinline__ int seq_similarity_bits(int qs, int qe, int s, int e)
 // L2 / HBM (2.2 KB per (query, tile) pair; < 1 ms per 10^6 queries either way).
 //   COUNT (FILL = false): qcount[q] = overlaps of query q            (all its tiles)
 //   FILL                : out[qoff[q] - base0 + rank] = the overlaps of queries [qa, qb), reference order
-template <bool FILL, bool SEQ = false>
+//   PACK8 (with FILL)   : 8 bytes per overlap -- start | (end - start) << idxBits | idx (igd_hip_hit8; `out` is an array of those)
+template <bool FILL, bool SEQ = false, bool PACK8 = false>
 __global__ __launch_bounds__(256) void igd_enum_queries(
     DbView db, const int32_t *__restrict__ q_ichr, const int32_t *__restrict__ q_qs,
     const int32_t *__restrict__ q_qe, int qa, int qb, int64_t *__restrict__ qcount,
-    const int64_t *__restrict__ qoff, int64_t base0, igd_hip_hit *__restrict__ out)
+    const int64_t *__restrict__ qoff, int64_t base0, igd_hip_hit *__restrict__ out, int idxBits = 0)
 {
     const int lane = threadIdx.x & 63;
     const int gwave = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -60,6 +61,10 @@ __global__ __launch_bounds__(256) void igd_enum_queries(
                     const int e = ok ? db.end[toff + i] : INT_MIN;
                     const bool hit = (s < qe) & (s >= lob) & (e > qs);
                     const u64 m = __ballot(hit);
+                    if (FILL && PACK8 && hit) {
+                        const uint32_t hi32 = ((uint32_t)(e - s) << idxBits) | (uint32_t)db.idx[toff + i];
+                        ((uint2 *)out)[base + cnt + __popcll(m & above)] = make_uint2((uint32_t)s, hi32);
+                    } else
                     if (FILL && hit) {
                         igd_hip_hit h;
                         h.q = q; h.idx = db.idx[toff + i]; h.start = s; h.end = e;
@@ -132,4 +137,16 @@ __global__ __launch_bounds__(IGD_SCAN_BLOCK) void k_scan64_apply(const int64_t *
         run += v[k];
         if (base + k == n - 1) out[n] = run;             // the grand total closes the offsets
     }
+}
+
+// the largest (uint32_t)(end - start) over all records: whether (length, idx) fit one word of igd_hip_hit8 (-f in 8 bytes per overlap)
+__global__ __launch_bounds__(256) void k_max_len(const int32_t *__restrict__ start, const int32_t *__restrict__ end, int64_t n, unsigned int *__restrict__ out)
+{
+    unsigned int m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned int d = (unsigned int)(end[i] - start[i]);
+        m = d > m ? d : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned int t = __shfl_down(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }

@@ -56,9 +56,14 @@ static int ensure_enum_workspace(igd_hip_db *db, int64_t nq, int64_t chunkHits, 
 
 // whole != nullptr: the chunks are copied straight to their place in `whole` (pinned, qoff[nq] records);
 // otherwise every chunk is handed to `sink` from one of the two pinned chunk buffers.
+// sink8 != nullptr: the packed stream -- 8 bytes per overlap in the same chunk buffers (twice the overlaps per chunk)
 static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq,
-                          int64_t *qoff, bool wantWhole, igd_hip_hit **wholeOut, igd_hip_enum_sink sink, void *ctx, int64_t *total)
+                          int64_t *qoff, bool wantWhole, igd_hip_hit **wholeOut, igd_hip_enum_sink sink, void *ctx, int64_t *total,
+                          igd_hip_enum_sink8 sink8 = nullptr)
 {
+    const bool p8 = sink8 != nullptr;
+    const int idxBits = db->hit8Bits;
+    const bool anySink = sink != nullptr || p8;
     const char *tenv = getenv("IGD_TIMING");
     const bool tim = tenv && *tenv && *tenv != '0';
     double t0 = wall_s();
@@ -90,7 +95,7 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
     if (total) *total = tot;
     if (tot == 0) {
         // no overlap at all: the sink still sees the batch's queries once (the command line tool prints a line per query)
-        if (sink && sink(ctx, 0, nq, qoff, nullptr) != 0) {
+        if (anySink && (p8 ? sink8(ctx, 0, nq, qoff, nullptr, idxBits) : sink(ctx, 0, nq, qoff, nullptr)) != 0) {
             snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream: stopped by the sink");
             return IGD_HIP_ERR_ARG;
         }
@@ -98,8 +103,8 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
     }
     int64_t maxq = 0;
     for (int64_t i = 0; i < nq; i++) if (qoff[i + 1] - qoff[i] > maxq) maxq = qoff[i + 1] - qoff[i];
-    if (maxq > db->enumChunkCap) {                         // one query larger than a chunk buffer: grow them
-        rc = ensure_enum_workspace(db, nq, maxq, !wantWhole);
+    if (maxq > db->enumChunkCap * (p8 ? 2 : 1)) {          // one query larger than a chunk buffer: grow them
+        rc = ensure_enum_workspace(db, nq, p8 ? (maxq + 1) / 2 : maxq, !wantWhole);
         if (rc != IGD_HIP_OK) return rc;
     }
     igd_hip_hit *whole = nullptr;
@@ -112,7 +117,8 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
         ENUM_PHASE("pinned result buffer");
     }
     static const bool zeroCopy = getenv("IGD_ENUM_ZEROCOPY") != nullptr;   // A/B: the fill kernel stores straight into pinned host memory
-    const int64_t cap = db->enumChunkCap;
+    const int64_t cap = db->enumChunkCap * (p8 ? 2 : 1);   // overlaps per chunk buffer
+    const size_t hitBytes = p8 ? sizeof(igd_hip_hit8) : sizeof(igd_hip_hit);
     int64_t qa = 0, prevA = 0, prevB = 0;
     int k = 0;
     hipError_t e = hipSuccess;
@@ -133,22 +139,27 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
             igd_hip_hit *hostDst = whole ? whole + qoff[qa] : db->h_enumPin[b];
             if (k >= 2) e = hipStreamWaitEvent(st, db->evCopy[b], 0);          // the buffer's previous copy is done
             if (e != hipSuccess) break;
+            if (p8)
+                igd_enum_queries<true, false, true><<<egrid, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, (int)qa, (int)qb, nullptr,
+                                                                           db->d_qoff, qoff[qa], zeroCopy ? hostDst : db->d_enumOut[b], idxBits);
+            else
             igd_enum_queries<true><<<egrid, 256, 0, st>>>(db->v, db->d_qc, db->d_qs, db->d_qe, (int)qa, (int)qb, nullptr,
                                                           db->d_qoff, qoff[qa], zeroCopy ? hostDst : db->d_enumOut[b]);
             e = hipEventRecord(db->evFill[b], st);
             if (e == hipSuccess) e = hipStreamWaitEvent(db->copyStream, db->evFill[b], 0);
             if (e == hipSuccess && !zeroCopy)
-                e = hipMemcpyAsync(hostDst, db->d_enumOut[b], (size_t)nh * sizeof(igd_hip_hit), hipMemcpyDeviceToHost, db->copyStream);
+                e = hipMemcpyAsync(hostDst, db->d_enumOut[b], (size_t)nh * hitBytes, hipMemcpyDeviceToHost, db->copyStream);
             if (e == hipSuccess) e = hipEventRecord(db->evCopy[b], db->copyStream);
             if (e != hipSuccess) break;
         }
-        if (sink && k >= 1 && prevB > prevA) {            // hand out the previous chunk while this one is produced
+        if (anySink && k >= 1 && prevB > prevA) {         // hand out the previous chunk while this one is produced
             if (qoff[prevB] > qoff[prevA]) e = hipEventSynchronize(db->evCopy[(k - 1) & 1]);
-            if (e == hipSuccess) sinkRc = sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
+            if (e == hipSuccess) sinkRc = p8 ? sink8(ctx, prevA, prevB, qoff, (const igd_hip_hit8 *)db->h_enumPin[(k - 1) & 1], idxBits)
+                                             : sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
         }
         prevA = qa; prevB = qb;
         qa = qb;
-        if (nh > 0 || sink) k++;
+        if (nh > 0 || anySink) k++;
     }
     {   // both streams are drained whatever happened: after a failed call an earlier chunk's copy may still be writing into
         // `whole` or a pinned chunk buffer, which are released / reused right below
@@ -157,7 +168,9 @@ static int enumerate_core(igd_hip_db *db, const int32_t *ichr, const int32_t *qs
         if (e == hipSuccess) e = e2;
     }
     if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess && sink && sinkRc == 0 && prevB > prevA) sinkRc = sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
+    if (e == hipSuccess && anySink && sinkRc == 0 && prevB > prevA)
+        sinkRc = p8 ? sink8(ctx, prevA, prevB, qoff, (const igd_hip_hit8 *)db->h_enumPin[(k - 1) & 1], idxBits)
+                    : sink(ctx, prevA, prevB, qoff, db->h_enumPin[(k - 1) & 1]);
     ENUM_PHASE("fill + D2H (+ sink)");
 #undef ENUM_PHASE
     if (e != hipSuccess) {
@@ -199,4 +212,51 @@ extern "C" int igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, con
     if (nq == 0) return IGD_HIP_OK;
     if (db->nT == 0) return sink(ctx, 0, nq, qoff, nullptr) == 0 ? IGD_HIP_OK : IGD_HIP_ERR_ARG;
     return enumerate_core(db, ichr, qs, qe, nq, qoff, false, nullptr, sink, ctx, total);
+}
+
+// Whether this database's records fit igd_hip_hit8, and how its second word is split (looked at once: one pass over the exact
+// start / end arrays, 0.1 ms for 5 x 10^7 records).
+extern "C" int igd_hip_hit8_idx_bits(igd_hip_db *db)
+{
+    if (!db) return -1;
+    if (db->hit8State == 0) {
+        if (hipSetDevice(db->device) != hipSuccess) return -1;
+        int bits = 0;
+        while (bits < 31 && (1ll << bits) < (long long)db->nFiles) bits++;
+        unsigned int mx = 0, *d_mx = nullptr;
+        bool ok = db->nFiles >= 1 && (1ll << bits) >= (long long)db->nFiles && hipMalloc((void **)&d_mx, 4) == hipSuccess;
+        if (ok && db->nRec > 0) {
+            ok = hipMemsetAsync(d_mx, 0, 4, db->stream) == hipSuccess;
+            if (ok) {
+                k_max_len<<<db->grid * 4, 256, 0, db->stream>>>(db->v.start, db->v.end, (int64_t)db->nRec, d_mx);
+                ok = hipMemcpyAsync(&mx, d_mx, 4, hipMemcpyDeviceToHost, db->stream) == hipSuccess && hipStreamSynchronize(db->stream) == hipSuccess;
+            }
+        }
+        if (d_mx) (void)hipFree(d_mx);
+        if (!ok) return -1;                              // (not remembered: a transient failure)
+        // the length field holds 32 - bits bits; end < start shows as a huge unsigned length
+        db->hit8Bits = bits;
+        db->hit8State = (bits >= 32 || (bits > 0 && ((unsigned long long)mx >> (32 - bits)) != 0ull)) ? 2 : 1;
+    }
+    return db->hit8State == 1 ? db->hit8Bits : -1;
+}
+
+extern "C" int igd_hip_enumerate_stream8(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                                         int64_t nq, int64_t *qoff, igd_hip_enum_sink8 sink, void *ctx, int64_t *total)
+{
+    if (!db || !qoff || !sink || nq < 0 || nq > max_batch() || (nq > 0 && (!ichr || !qs || !qe))) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream8: bad argument (batch limit %lld)", (long long)max_batch());
+        return IGD_HIP_ERR_ARG;
+    }
+    const int bits = igd_hip_hit8_idx_bits(db);
+    if (bits < 0) {
+        snprintf(g_err, sizeof g_err, "igd_hip_enumerate_stream8: a record of this database does not fit 8 bytes (igd_hip_hit8_idx_bits() < 0): "
+                                      "use igd_hip_enumerate_stream");
+        return IGD_HIP_ERR_ARG;
+    }
+    if (total) *total = 0;
+    for (int64_t i = 0; i <= nq; i++) qoff[i] = 0;
+    if (nq == 0) return IGD_HIP_OK;
+    if (db->nT == 0) return sink(ctx, 0, nq, qoff, nullptr, bits) == 0 ? IGD_HIP_OK : IGD_HIP_ERR_ARG;
+    return enumerate_core(db, ichr, qs, qe, nq, qoff, false, nullptr, nullptr, ctx, total, sink);
 }

@@ -456,6 +456,7 @@ typedef struct {
     const igdc_queries *q; char **names; const iGD_t *G; const size_t *flen;
     int64_t q0;                       /* first query of the engine call this block belongs to   */
     const int64_t *qoff; const igd_hip_hit *hit;   /* hit[h - hbase] = overlap h of the call    */
+    const igd_hip_hit8 *hit8; int bits;            /* ... or the packed stream (8 bytes per overlap; bits = those of idx) */
     int64_t hbase;
     int64_t i0, i1;                   /* queries [i0, i1) of that call                           */
     obuf o;
@@ -496,6 +497,18 @@ static void *fmt_run(void *arg)
         ob_str(o, ", ", 2); ob_int(o, qs); ob_str(o, ", ", 2); ob_int(o, qe);
         ob_str(o, ": \n", 3);
         uint32_t k = 0;
+        if (J->hit8) {                                            /* start | (end - start) << bits | idx: expanded while it is printed */
+            const igd_hip_hit8 *h = J->hit8 + (J->qoff[i] - J->hbase), *he = J->hit8 + (J->qoff[i + 1] - J->hbase);
+            const int bits = J->bits;
+            const uint32_t fmask = bits ? (1u << bits) - 1u : 0u;
+            for (; h < he; h++, k++) {
+                const uint32_t f = h->lenidx & fmask;
+                const int32_t st = (int32_t)h->start, en = (int32_t)(h->start + (h->lenidx >> bits));
+                ob_uint(o, k); ob_str(o, "\t ", 2); ob_int(o, st); ob_str(o, "\t ", 2);
+                ob_int(o, en); ob_str(o, "\t ", 2); ob_str(o, G->finfo[f].fileName, J->flen[f]); o->buf[o->n++] = '\n';
+            }
+            continue;
+        }
         const igd_hip_hit *h = J->hit + (J->qoff[i] - J->hbase), *he = J->hit + (J->qoff[i + 1] - J->hbase);
         for (; h < he; h++, k++) {
             const int32_t f = h->idx;
@@ -513,8 +526,17 @@ typedef struct {
                                          allocations per chunk would spend the time in page faults, not in formatting */
 } print_ctx;
 
-/* igd_hip_enum_sink: one chunk = queries [b0,b1) of the call, its overlaps in pinned memory */
+/* igd_hip_enum_sink / igd_hip_enum_sink8: one chunk = queries [b0,b1) of the call, its overlaps in pinned memory */
+static int print_chunk_any(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, const igd_hip_hit *hit, const igd_hip_hit8 *hit8, int bits);
 static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, const igd_hip_hit *hit)
+{
+    return print_chunk_any(ctx, b0, b1, qoff, hit, NULL, 0);
+}
+static int print_chunk8(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, const igd_hip_hit8 *hit8, int bits)
+{
+    return print_chunk_any(ctx, b0, b1, qoff, NULL, hit8, bits);
+}
+static int print_chunk_any(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, const igd_hip_hit *hit, const igd_hip_hit8 *hit8, int bits)
 {
     print_ctx *P = (print_ctx *)ctx;
     const int nt = P->nt;
@@ -535,7 +557,7 @@ static int print_chunk(void *ctx, int64_t b0, int64_t b1, const int64_t *qoff, c
             i1 = lo > i0 ? lo : i0 + 1;
         }
         fmt_job *J = &job[used];
-        J->q = P->q; J->names = P->names; J->G = P->G; J->flen = P->flen; J->q0 = P->q0; J->qoff = qoff; J->hit = hit;
+        J->q = P->q; J->names = P->names; J->G = P->G; J->flen = P->flen; J->q0 = P->q0; J->qoff = qoff; J->hit = hit; J->hit8 = hit8; J->bits = bits;
         J->hbase = qoff[b0];
         J->i0 = i0; J->i1 = i1;
         const size_t need = (size_t)(i1 - i0) * 96 + (size_t)(qoff[i1] - qoff[i0]) * (40 + P->maxL) + 64;
@@ -599,7 +621,10 @@ static int64_t enumerate_and_print(const igdc_queries *q, char **names)
     for (int64_t q0 = 0; q0 < q->n; q0 += step) {
         int64_t m = q->n - q0 < step ? q->n - q0 : step;
         P.q0 = q0;
-        int rc = igd_hip_enumerate_stream(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, print_chunk, &P, &total);
+        /* 8 bytes per overlap over PCIe when the database's records fit them (igd_hip_hit8), else 16 */
+        int rc = (!getenv("IGD_ENUM_HIT16") && igd_hip_hit8_idx_bits(dev) >= 0)
+                     ? igd_hip_enumerate_stream8(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, print_chunk8, &P, &total)
+                     : igd_hip_enumerate_stream(dev, q->ichr + q0, q->qs + q0, q->qe + q0, m, qoff, print_chunk, &P, &total);
         if (rc != IGD_HIP_OK) { engine_failed("enumerate", rc); break; }
         grand += total;
     }

@@ -310,6 +310,7 @@ struct igd_hip_db {
     int64_t enumQCap, enumChunkCap;          // capacity in queries / overlaps per chunk buffer
     igd_hip_hit *d_enumOut[2], *h_enumPin[2];
     bool enumPinned;
+    int hit8State, hit8Bits;                 // igd_hip_hit8 (8 bytes per overlap): 0 not looked at yet, 1 fits (hit8Bits = bits of idx), 2 does not
     hipStream_t copyStream;
     hipEvent_t evFill[2], evCopy[2];
     // host-API staging

@@ -134,6 +134,22 @@ int igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, const int32_t 
     return fn ? fn(db, ichr, qs, qe, nq, qoff, sink, ctx, total) : IGD_HIP_ERR_DEVICE;
 }
 
+int igd_hip_enumerate_stream8(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *qoff,
+                              igd_hip_enum_sink8 sink, void *ctx, int64_t *total)
+{
+    typedef int (*fn_t)(igd_hip_db *, const int32_t *, const int32_t *, const int32_t *, int64_t, int64_t *, igd_hip_enum_sink8, void *, int64_t *);
+    RESOLVE(fn_t, "igd_hip_enumerate_stream8");
+    return fn ? fn(db, ichr, qs, qe, nq, qoff, sink, ctx, total) : IGD_HIP_ERR_DEVICE;
+}
+
+int igd_hip_hit8_idx_bits(igd_hip_db *db)
+{
+    typedef int (*fn_t)(igd_hip_db *);
+    if (!db) return -1;
+    RESOLVE(fn_t, "igd_hip_hit8_idx_bits");
+    return fn ? fn(db) : -1;
+}
+
 int igd_hip_hitmap(igd_hip_db *db, int use_v, int32_t v, uint32_t *hitmap, int64_t *total)
 {
     typedef int (*fn_t)(igd_hip_db *, int, int32_t, uint32_t *, int64_t *);

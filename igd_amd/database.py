@@ -198,6 +198,42 @@ class Database:
                                               qoff.ctypes.data, cb, None, C.byref(total)), "igd_hip_enumerate_stream")
         return qoff, total.value
 
+    def hit8_idx_bits(self):
+        """How the packed `-f` record (igd_hip_hit8: 8 bytes per overlap) splits its second word for this database -- the low
+        `bits` hold idx, the rest end - start -- or -1 when a record does not fit (igd_hip_hit8_idx_bits)."""
+        return int(self._H.igd_hip_hit8_idx_bits(self.dev))
+
+    def enumerate_stream8(self, ichr, qs, qe, on_chunk=None):
+        """`-f`, streamed in 8 bytes per overlap (igd_hip_enumerate_stream8): on_chunk(q0, q1, qoff, rec, bits) is called per chunk
+        with rec = uint32[n,2] VIEW of the pinned chunk buffer: rec[:,0] = start, rec[:,1] = (end - start) << bits | idx.
+        Returns (qoff, total)."""
+        ichr, qs, qe = _i32(ichr), _i32(qs), _i32(qe)
+        nq = len(qs)
+        qoff = np.zeros(nq + 1, np.int64)
+        total = C.c_int64(0)
+
+        def sink(ctx, q0, q1, qoff_p, hits_p, bits):
+            if on_chunk is not None:
+                n = int(qoff[q1] - qoff[q0])
+                rec = (np.ctypeslib.as_array(C.cast(hits_p, C.POINTER(C.c_uint32)), shape=(n * 2,)).reshape(n, 2)
+                       if n else np.zeros((0, 2), np.uint32))
+                on_chunk(int(q0), int(q1), qoff, rec, int(bits))
+            return 0
+
+        cb = N.ENUM_SINK8(sink)
+        _chk(self._H.igd_hip_enumerate_stream8(self.dev, ichr.ctypes.data, qs.ctypes.data, qe.ctypes.data, nq,
+                                               qoff.ctypes.data, cb, None, C.byref(total)), "igd_hip_enumerate_stream8")
+        return qoff, total.value
+
+    @staticmethod
+    def expand_hit8(rec, bits):
+        """(start, end, idx) int32 arrays of packed records (igd_hip_hit8_expand)."""
+        start = rec[:, 0].astype(np.uint32)
+        hi = rec[:, 1].astype(np.uint32)
+        idx = (hi & np.uint32((1 << bits) - 1)) if bits else np.zeros(len(hi), np.uint32)
+        end = (start + (hi >> np.uint32(bits))).astype(np.uint32)
+        return start.view(np.int32), end.view(np.int32), idx.astype(np.int32)
+
     def hitmap(self, v=0):
         """`-m`: (uint32[nfiles,nfiles], pairs); v>0 keeps records with value > v (getMap_v)."""
         m = np.zeros((self.nfiles, self.nfiles), np.uint32)

@@ -192,6 +192,28 @@ typedef int (*igd_hip_enum_sink)(void *ctx, int64_t q0, int64_t q1, const int64_
 int  igd_hip_enumerate_stream(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
                               int64_t nq, int64_t *qoff, igd_hip_enum_sink sink, void *ctx, int64_t *total);
 
+/* The same stream in HALF the bytes (round 6; `-f` is bound by the bytes that cross PCIe, 0.81 of the link at 16 per overlap):
+ * one overlap = 8 bytes.  `q` is implied by qoff[]; start is kept whole; (end - start) and idx share the second word, split
+ * per DATABASE: idx takes idx_bits = ceil(log2(nFiles)) low bits, the length the 32 - idx_bits above them (1900 files: 11 + 21
+ * bits, lengths up to 2 097 151 bp).  igd_hip_hit8_idx_bits() returns that split, or -1 when a record of this database does not
+ * fit it (a length of 2^(32 - idx_bits) or more, or end < start): such a database streams through igd_hip_enumerate_stream only.
+ * Expansion: start = (int32_t)h.start, idx = h.lenidx & ((1u << idx_bits) - 1), end = start + (int32_t)(h.lenidx >> idx_bits)
+ * (igd_hip_hit8_expand).  Order, chunking, qoff and the sink's contract are those of igd_hip_enumerate_stream. */
+typedef struct { uint32_t start, lenidx; } igd_hip_hit8;
+typedef int (*igd_hip_enum_sink8)(void *ctx, int64_t q0, int64_t q1, const int64_t *qoff, const igd_hip_hit8 *hits, int idx_bits);
+int  igd_hip_hit8_idx_bits(igd_hip_db *db);
+int  igd_hip_enumerate_stream8(igd_hip_db *db, const int32_t *ichr, const int32_t *qs, const int32_t *qe,
+                               int64_t nq, int64_t *qoff, igd_hip_enum_sink8 sink, void *ctx, int64_t *total);
+static inline igd_hip_hit igd_hip_hit8_expand(igd_hip_hit8 h, int idx_bits, int32_t q)
+{
+    igd_hip_hit r;
+    r.q = q;
+    r.start = (int32_t)h.start;
+    r.idx = (int32_t)(idx_bits ? (h.lenidx & ((1u << idx_bits) - 1u)) : 0u);
+    r.end = (int32_t)(h.start + (idx_bits < 32 ? (h.lenidx >> idx_bits) : 0u));
+    return r;
+}
+
 /* `-m`: dataset x dataset hit map, getMap src/igd_search.c:772-826 (use_v = 0) and getMap_v
  * :829-886 (use_v = 1: both records need value > v, strictly).  hitmap is nFiles x nFiles uint32,
  * row-major, caller-allocated, ADDED to; *total (may be NULL) receives the number of pairs.

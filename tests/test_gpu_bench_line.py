@@ -42,7 +42,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert cc["kind"] in ("reference", "port") and cc["cores"] == 1 and cc["value"] > 0 and cc["seconds"] > 0 and cc["totals_match_gpu"] is True
         assert c["n_ranks_seen"] == 1 and "matches_oracle" not in c     # (not the fixture's database size)
         xr = c["extra_configs"]
-        assert len(xr) == 16 and len(set(r["workload"] for r in xr)) == 16 and not any("error" in r for r in xr), xr
+        assert len(xr) == 17 and len(set(r["workload"] for r in xr)) == 17 and not any("error" in r for r in xr), xr
         assert all(r["ms_per_step"] > 0 and set(r) <= {"workload", "ms_per_step", "kernel", "kernel_ms", "frac", "matches_oracle"} for r in xr)
         ce = c["cli_end_to_end"]
         assert ce["default_route"] in ("host", "engine") and ce["engine_seconds"] > 0 and ce["default_seconds"] > 0
@@ -66,12 +66,13 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert r["algorithmic_bytes_per_launch"] > 0 and r["box"]["hbm_copy_GBps"] > 500 and r["box"]["d2h_GBps"] > 1
         c = j["cpu_baseline"]
         x = j["extra_configs"]
-        assert len(x) == 16 and not any("error" in e for e in x), x
+        assert len(x) == 17 and not any("error" in e for e in x), x
         assert [e["key"] for e in x] == [r["workload"] for r in xr]
-        assert all(e["value"] > 0 for e in x) and x[-1]["roofline"]["bound"] == "pcie-d2h" and x[-1]["overlaps"] > 0
+        assert all(e["value"] > 0 for e in x) and all(e["roofline"]["bound"] == "pcie-d2h" and e["overlaps"] > 0 for e in x[-2:])
+        assert x[-2]["key"] == "config5_f_q1000000" and x[-2]["output_bytes"] * 2 == x[-1]["output_bytes"]       # 8 against 16 bytes per overlap
         assert sum(e["workload"].startswith("stress:") for e in x) == 6
         # every row but `-f` carries the comparison with the oracle's fixture (None here: not the fixture's database size)
-        assert all("matches_oracle" in e for e in x[:-1]), [e["workload"] for e in x[:-1] if "matches_oracle" not in e]
+        assert all("matches_oracle" in e for e in x), [e["workload"] for e in x if "matches_oracle" not in e]
         assert r["cold"]["kernel_ms"] > 0 and 0 < r["cold"]["frac"] <= 1.0
         # what the fraction is a fraction of, and the like-for-like anchors of the weak-scaling curve
         assert r["frac_of"] and r["step_frac"] > 0 and r["step_frac"] <= r["frac"] and "frac_pmc" in r

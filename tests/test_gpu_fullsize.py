@@ -116,6 +116,27 @@ def test_config5_enumeration_of_all_queries_streamed_equals_counts_and_whole_arr
     assert nch == seen["chunks"] and crc == seen["crc"]
 
 
+def test_config5_packed_stream_expands_to_the_whole_array(big):
+    """Config 5 through the 8-byte stream (igd_hip_enumerate_stream8: what the command line tool now moves over PCIe): 1900 files
+    -> 11 bits of idx + 21 bits of length; every chunk expanded equals the same range of the one-array API's 16-byte records."""
+    db, path, (ichr, qs, qe) = big
+    qoff2, whole = db.enumerate(ichr, qs, qe)
+    bits = db.hit8_idx_bits()
+    assert bits == 11
+    seen = {"q": 0, "n": 0, "chunks": 0}
+
+    def on_chunk(q0, q1, qoff, rec, b):
+        assert b == bits and q0 == seen["q"] and q1 > q0 and len(rec) == qoff[q1] - qoff[q0] and qoff[q0] == seen["n"]
+        st, en, ix = db.expand_hit8(rec, b)
+        w = whole[qoff[q0]:qoff[q1]]
+        assert np.array_equal(ix, w[:, 1]) and np.array_equal(st, w[:, 2]) and np.array_equal(en, w[:, 3])
+        seen["q"], seen["n"], seen["chunks"] = q1, seen["n"] + len(rec), seen["chunks"] + 1
+
+    qoff, total = db.enumerate_stream8(ichr, qs, qe, on_chunk)
+    np.testing.assert_array_equal(qoff, qoff2)
+    assert seen["q"] == Q and seen["n"] == total == qoff[-1] and seen["chunks"] >= 3
+
+
 def test_config5_cli_f_on_all_queries_is_byte_identical_to_the_reference(big):
     """`bin/igd search db -q 10^6.bed -f` (1.2 GB of text, streamed chunk by chunk) against the real reference
     binary's stdout: same bytes (md5 + length), when oracle/_ref/igd travelled; otherwise against the oracle CLI."""

@@ -159,6 +159,78 @@ def test_streamed_enumeration_in_small_chunks_matches_oracle(chunk_hits, workdir
         orc.close()
 
 
+@pytest.mark.parametrize("case,chunk_hits", [(0, 64), (1, 1000), (2, 50000), (3, 1000), (5, 0)])
+def test_packed_stream_of_8_bytes_per_overlap_matches_oracle(case, chunk_hits, workdir, monkeypatch):
+    """igd_hip_enumerate_stream8 (round 6: `-f` moves 8 instead of 16 bytes per overlap over PCIe): the packed records --
+    start | (end - start) << bits | idx, bits = ceil(log2(nFiles)) per database -- expand to exactly the oracle's enumeration
+    (src/igd_search.c:575-579,608-612 order), chunk seams and zero-overlap queries included, on gType 0 and 1 databases."""
+    from igd_amd import Database
+    if chunk_hits:
+        monkeypatch.setenv("IGD_ENUM_CHUNK_HITS", str(chunk_hits))
+    rng = random.Random(99 + case)
+    nbp, gtype, nfiles, nctg, span_tiles, dens, hot = CASES[case]
+    path, ctgs, span = _random_db(rng, workdir, "p8_%d" % case, nbp, gtype, nfiles, nctg, span_tiles, dens, hot)
+    orc, db = Oracle(path), Database(path)
+    try:
+        bits = db.hit8_idx_bits()
+        assert bits >= 0 and (1 << bits) >= nfiles and (bits == 0 or (1 << (bits - 1)) < nfiles)
+        ichr, qs, qe = _random_queries(rng, list(range(nctg)) + [-1], nbp, span, 3000)
+        wqoff, wrec = orc.enumerate(ichr, qs, qe)
+        parts, ranges = [], []
+
+        def on_chunk(q0, q1, qoff, rec, b):
+            assert b == bits and len(rec) == wqoff[q1] - wqoff[q0]
+            ranges.append((q0, q1))
+            parts.append(rec.copy())
+
+        gqoff, total = db.enumerate_stream8(ichr, qs, qe, on_chunk)
+        np.testing.assert_array_equal(gqoff, wqoff)
+        assert total == wqoff[-1]
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(qs) and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        if chunk_hits and chunk_hits <= 1000:
+            assert len(ranges) > 3
+        rec = np.concatenate(parts) if parts else np.zeros((0, 2), np.uint32)
+        st, en, ix = Database.expand_hit8(rec, bits)
+        np.testing.assert_array_equal(np.stack([ix, st, en], axis=1), wrec)           # idx, start, end in reference order
+        # the 16-byte stream on the same handle (shared chunk buffers) still agrees
+        q2, r2 = db.enumerate(ichr, qs, qe)
+        np.testing.assert_array_equal(r2[:, 1:], wrec)
+    finally:
+        db.close(); orc.close()
+
+
+def test_packed_stream_refuses_a_database_whose_records_do_not_fit(workdir):
+    """A record longer than the length field holds (2^(32 - bits) bp) or with end < start: igd_hip_hit8_idx_bits() = -1, the
+    packed call is an argument error, and the command line tool streams 16-byte records -- same text as the oracle's."""
+    import subprocess
+    from helpers import ORACLE_BIN
+    from igd_amd import Database
+    from igd_amd.database import IgdError
+    nbp = 1 << 14
+    # 70 000 files (17 bits of idx -> 15 bits of length) and one interval of 40 000 bp
+    files = [[] for _ in range(70000)]
+    files[5] = [("chr1", 100, 40100, 1)]
+    files[7] = [("chr1", 16000, 17000, 3)]
+    files[69999] = [("chr1", 200, 900, 2)]
+    path = os.path.join(workdir, "p8big.igd")
+    write_igd_numpy(path, files, nbp=nbp, gtype=1)
+    db = Database(path)
+    try:
+        assert db.hit8_idx_bits() == -1
+        with pytest.raises(IgdError):
+            db.enumerate_stream8(np.zeros(2, np.int32), np.array([0, 150], np.int32), np.array([50000, 300], np.int32))
+        qoff, rec = db.enumerate(np.zeros(2, np.int32), np.array([0, 150], np.int32), np.array([50000, 300], np.int32))
+        assert qoff[-1] == len(rec) >= 3
+    finally:
+        db.close()
+    qb = os.path.join(workdir, "p8big_q.bed")
+    open(qb, "w").write("chr1\t0\t50000\nchr1\t150\t300\n")
+    env = dict(os.environ, IGD_HOST_MAX_QUERIES="0")
+    a = subprocess.run([os.path.join(ROOT, "bin", "igd"), "search", path, "-q", qb, "-f"], stdout=subprocess.PIPE, env=env, check=True).stdout
+    b = subprocess.run([ORACLE_BIN, "search", path, "-q", qb, "-f"], stdout=subprocess.PIPE, check=True).stdout
+    assert a == b and b.count(b"\n") >= 5
+
+
 def test_accumulates_into_caller_hits(workdir):
     """hits is caller-zeroed and ADDED to (src/igd_search.c:491): two calls sum up."""
     from igd_amd import Database
