@@ -391,7 +391,8 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
     }
     // 1. keys and order of the thread's queries (query i0 + v fills firstQ[lo[v]..key[v]] = i0 + v)
     int cBase[VEC], cMT[VEC];
-    bool unordered = false, notStart = false;
+    bool unordered = false, notStart = false, brokenStart = false;
+    int prevC = pc;
 #pragma unroll
     for (int v = 0; v < VEC; v++) {
         const int i = i0 + v;
@@ -407,6 +408,10 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
             const int k = c < 0 ? (BONLY ? -1 : 0) : (c >= db.nCtg ? (BONLY ? db.nT : db.nT - 1) : cb + n1c);
             unordered |= k < prevKey;
             notStart |= k == prevKey && s0 < ps;
+            // (the promise is about (contig, start): contig numbers outside the database share the key of the first / last
+            // tile here -- their starts are not compared with those of the contig whose tile that is)
+            brokenStart |= k == prevKey && c == prevC && s0 < ps;
+            prevC = c;
             lo[v] = i == 0 ? k + 1 : prevKey + 1;           // the tiles up to the first query's key: filled by the whole grid (below)
             key[v] = k;
             cBase[v] = cb; cMT[v] = cOk ? cm : -1;
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         // and the batch adds nothing -- whichever step it would have taken (the DIRECT step's rank method needs that order in
         // every tile, its heavy-tile slices in the last launch included: found HERE, before anything is counted).  Without the
         // promise such a batch is a legal merge-join batch: the pairwise compares hold, the rank method is switched off.
-        const unsigned long long bu = __ballot(unordered || (promised && notStart)), bs = __ballot(notStart);
+        const unsigned long long bu = __ballot(unordered || (promised && brokenStart)), bs = __ballot(notStart);
         if (bs && lane == __builtin_ctzll(bs)) ctl[CTL_NOTSTART] = epoch;   // ordered by tile but not by start inside a tile:
                                                                             // the merge join still holds, the rank method does not
         if (bu) {

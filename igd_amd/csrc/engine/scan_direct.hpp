@@ -73,6 +73,8 @@ struct DirArgs {
     const int32_t *firstQ;       // [nT + 1] (k_query_bounds<.., BONLY>)
     const int4 *tileD;           // [nT] (k_tile_desc)
     const int32_t *q_qs, *q_qe;
+    const int32_t *q_ichr;       // igd_scan_chunks: the queries' contig numbers (the round-5 kernel never reads them)
+    u64 *zeroHits, *zeroTotal;   // igd_scan_chunks under IGD_HIP_FLAG_ZERO_FIRST: the caller's hits[] / total, cleared by the batch's first kernel
     int32_t *ctl;
     int2 *fix;                   // the batch's exact-walk list (CTL_NFIX)
     int32_t *heavyS, *farList;   // tiles with more than IGD_HEAVY_FIRST queries / units that could overflow a 32-bit counter: the batch's last launch
@@ -193,7 +195,8 @@ __device__ __forceinline__ void d_walk_exact(const DbView &db, const DirArgs &a,
 // atomics (the batch's last launch: slices of very dense tiles, units that could overflow a 32-bit counter), else to the
 // workgroup's 32-bit LDS counters.  prevQ: the start of the query before f0 when that one belongs to the same tile's range
 // (a slice), else INT_MIN.
-template <bool USE_V, bool GLOBAL, bool KA>
+// CHK: the order of the starts is verified here (igd_scan_direct); igd_scan_chunks has verified it while it cut its pass up.
+template <bool USE_V, bool GLOBAL, bool KA, bool CHK = true>
 __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, const DRegs &L, int kk, int lane, DRaw &R, unsigned int *hits32,
                                           unsigned short *sl, unsigned int *hist, unsigned short *sb, int prevQ, bool *appDirty)
 {
@@ -257,7 +260,7 @@ __device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, co
     auto batch = [&](const int p, const int qs_, const int qe_) {
         const int idx = p + lane;
         const int a_ = qs_ - T0, d_ = qe_ - T0;
-        if (first && !(IGD_D_EXP & 16)) {                // the order of the starts, where they are read
+        if (CHK && first && !(IGD_D_EXP & 16)) {         // the order of the starts, where they are read
             // lane i gets lane i-1's start, lane 0 keeps the last start of the batch before (DPP wave_shr:1 -- one instruction)
             const int pq = __builtin_amdgcn_update_dpp(carryQ, qs_, 0x138, 0xf, 0xf, false);
             disorder = disorder || (idx < c0 && qs_ < pq);

@@ -27,6 +27,9 @@ from test_gpu_rank import _dense_queries
 
 pytestmark = pytest.mark.gpu
 FLAG_SORTED, FLAG_SHORT = 1, 16
+# the DIRECT step's scan kernel: igd_scan_chunks (round 6: query-partitioned, no pre-pass) or, with IGD_HIP_CHUNKS=0 or when the
+# database does not fit it, round 5's igd_scan_direct behind the bounds-only pass
+DIRECT_KERNELS = ("igd_scan_direct", "igd_scan_chunks")
 
 
 @pytest.fixture(scope="module")
@@ -69,13 +72,13 @@ def test_forced_direct_step_matches_the_oracle_on_every_query_kind(case, workdir
             for v in (0, 300):
                 want, wtot = orc.search(ichr, qs, qe, v)
                 got, gtot, kern = _dev_search(db, torch, ichr, qs, qe, v=v)
-                assert kern == "igd_scan_direct"
+                assert kern in DIRECT_KERNELS
                 assert gtot == wtot, (case, n, v)
                 np.testing.assert_array_equal(got, want, err_msg="case %d n %d v %d" % (case, n, v))
             # rule FLAT without a value filter: later tiles count behind an empty first tile
             ref = db.search(ichr, qs, qe, rule=1, flags=2)[0]           # (the bucket path, checked against the oracle elsewhere)
             got, _, kern = _dev_search(db, torch, ichr, qs, qe, rule=1)
-            assert kern == "igd_scan_direct"
+            assert kern in DIRECT_KERNELS
             np.testing.assert_array_equal(got, ref)
             # the run-table form of the same batch (known contigs only)
             ok = (ichr >= 0) & (ichr < nctg)
@@ -83,7 +86,7 @@ def test_forced_direct_step_matches_the_oracle_on_every_query_kind(case, workdir
             runs = Database.contig_runs(a, nctg)
             want, wtot = orc.search(a, b, c, 0)
             got, gtot, kern = _dev_search(db, torch, a, b, c, runs=runs)
-            assert kern == "igd_scan_direct" and gtot == wtot
+            assert kern in DIRECT_KERNELS and gtot == wtot
             np.testing.assert_array_equal(got, want)
     finally:
         db.close(); orc.close()
@@ -112,7 +115,7 @@ def test_short_queries_next_tile_fuller_than_what_rides_along(workdir, monkeypat
         for v in (0, 400):
             want, wtot = orc.search(ichr, qs, qe, v)
             got, gtot, kern = _dev_search(db, torch, ichr, qs, qe, v=v)
-            assert kern == "igd_scan_direct" and gtot == wtot
+            assert kern in DIRECT_KERNELS and gtot == wtot
             np.testing.assert_array_equal(got, want)
     finally:
         db.close(); orc.close()
@@ -143,7 +146,7 @@ def test_a_tile_with_more_queries_than_one_wave_takes(workdir, monkeypatch):
         for v in (0, 300):
             want, wtot = orc.search(ichr, qs2, qe2, v)
             got, gtot, kern = _dev_search(db, torch, ichr, qs2, qe2, v=v)
-            assert kern == "igd_scan_direct" and gtot == wtot, v
+            assert kern in DIRECT_KERNELS and gtot == wtot, v
             np.testing.assert_array_equal(got, want)
     finally:
         db.close(); orc.close()
@@ -169,7 +172,7 @@ def test_alternating_batches_and_accumulation_on_one_handle(workdir, monkeypatch
             ichr, qs, qe = _dense_queries(rng, nctg, nbp, span, n)
             flags = FLAG_SORTED if k % 4 != 3 else 0             # (flags 0: the device decides -- never the DIRECT step)
             got, _, kern = _dev_search(db, torch, ichr, qs, qe, flags=flags, hits=acc)
-            assert (kern == "igd_scan_direct") == (flags == FLAG_SORTED)
+            assert (kern in DIRECT_KERNELS) == (flags == FLAG_SORTED)
             want_acc += orc.search(ichr, qs, qe, 0)[0]
             np.testing.assert_array_equal(got, want_acc, err_msg="batch %d" % k)
     finally:
@@ -242,7 +245,7 @@ def test_broken_start_order_inside_a_heavy_tile_adds_nothing(workdir, monkeypatc
         ichr, qs, qe = ichr[o], qs[o], qe[o]
         want, wtot = orc.search(ichr, qs, qe, 0)
         got, gtot, kern = _dev_search(db, torch, ichr, qs, qe, flags=FLAG_SORTED | FLAG_SHORT)
-        assert kern == "igd_scan_direct" and gtot == wtot
+        assert kern in DIRECT_KERNELS and gtot == wtot
         np.testing.assert_array_equal(got, want)
         inside = np.flatnonzero((ichr == 0) & (qs // 16384 == 3))
         assert len(inside) > 8192 * 2
@@ -285,7 +288,7 @@ def test_the_engine_picks_the_direct_step_for_dense_short_sorted_batches_only(wo
             for v in (0, 500):
                 want, wtot = orc.search(*q, v)
                 got, gtot, kern = _dev_search(db, torch, *q, v=v, flags=flags)
-                assert (kern == "igd_scan_direct") == direct, (flags, kern)
+                assert (kern in DIRECT_KERNELS) == direct, (flags, kern)
                 assert gtot == wtot
                 np.testing.assert_array_equal(got, want)
     finally:
