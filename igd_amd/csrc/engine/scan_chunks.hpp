@@ -27,6 +27,7 @@
 #define IGD_C_PASS 960                                  // queries per pass: 15 blocks of 64; < the LDS array of query starts (sbCap = 1024)
 #define IGD_C_BLOCKS (IGD_C_PASS / IGD_WAVE)
 #define IGD_C_SEGS 64                                   // segments per pass: one per lane
+#define IGD_C_HAND 512                                  // a wave's border moves to the next tile's first query when that lies within this many queries
 
 template <bool USE_V>
 __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_WPE_DIR, IGD_WPE_DIR))) void igd_scan_chunks(DirK K)
@@ -73,28 +74,65 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
     __syncthreads();
     const int gwave = (int)blockIdx.x * wavesPerWG + wid;
     const long long nwaves = (long long)gridDim.x * wavesPerWG;
-    const int q0 = (int)((long long)a.nq * gwave / nwaves), q1 = (int)((long long)a.nq * (gwave + 1) / nwaves);
     const int sh = db.shift, nT = db.nT;
-    // passes of equal size (a last pass of a few queries would still pay a pass's round trips)
-    const int nPass = (q1 - q0 + IGD_C_PASS - 1) / IGD_C_PASS;
-    const int passLen = nPass > 0 ? (q1 - q0 + nPass - 1) / nPass : 0;
     // (the segment list lives in the array of query starts, which no unit is using while a pass is being cut up; the running
     // item counts are needed while units are counted: an area of their own behind it)
     int32_t *segG = (int32_t *)sb;                        // [64] a segment's tile
-    unsigned short *segP = sb + 2 * IGD_C_SEGS;           // [65] a segment's first query (relative to the pass), closed by the pass's end
+    int32_t *segP = segG + IGD_C_SEGS;                    // [65] a segment's first query (relative to the pass), closed by the pass's end
     int32_t *segI = (int32_t *)(sb + KARGD(a.sbCap));     // [64] running number of items up to and including a segment
     const unsigned long long below = (1ull << lane) - 1ull;
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)KARGD(a.q_ichr), 0, a.nq * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)a.q_qs, 0, a.nq * 4, 0x00020000);
+    const int vo4 = lane * 4;
+    auto key_of = [&](int c, int s, bool &ok) -> int {
+        const bool cOk = (unsigned)c < (unsigned)nCtg;
+        const int cb = cOk ? sBase[c] : 0, cm = cOk ? sNTile[c] - 1 : -1;
+        const int n1r = tile_shift(s, sh);
+        const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
+        ok = cOk && cm >= 0;                              // (a contig without tiles holds nothing: :462)
+        return c < 0 ? -1 : (c >= nCtg ? nT : cb + n1c);
+    };
+    // ---- 0. the wave's range, handed over at tile boundaries ----
+    // Nominally [nq * w / nwaves, nq * (w + 1) / nwaves).  A tile cut by such a border would be counted in two parts -- twice the
+    // per-unit work (staging, prefix sums, the bisections of term B) for the same records -- so a border moves forward to the
+    // first query of the next tile when one begins within IGD_C_HAND queries: handover(q) is a function of the queries around q
+    // alone, and the two waves on either side of a border work it out alike.
+    auto handover = [&](int q) -> int {
+        if (q <= 0) return 0;
+        if (q >= a.nq) return a.nq;
+        int C[IGD_C_HAND / IGD_WAVE], S[IGD_C_HAND / IGD_WAVE];
+#pragma unroll
+        for (int p = 0; p < IGD_C_HAND / IGD_WAVE; p++) {
+            C[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, vo4, (q + p * IGD_WAVE) * 4, 0);
+            S[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (q + p * IGD_WAVE) * 4, 0);
+        }
+        const int pc = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, 0, (q - 1) * 4, 0);
+        const int ps = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, 0, (q - 1) * 4, 0);
+        bool ok;
+        int carryG = key_of(pc, ps, ok);
+        carryG = __builtin_amdgcn_readfirstlane(ok ? carryG : -1);
+        int found = -1;
+#pragma unroll
+        for (int p = 0; p < IGD_C_HAND / IGD_WAVE; p++) {
+            if (found >= 0) continue;
+            const int k = key_of(C[p], S[p], ok);
+            const int g = ok ? k : -1;
+            const int pg = __builtin_amdgcn_update_dpp(carryG, g, 0x138, 0xf, 0xf, false);
+            carryG = __builtin_amdgcn_readlane(g, IGD_WAVE - 1);
+            const unsigned long long m = __ballot(q + p * IGD_WAVE + lane < a.nq && g != pg);
+            if (m) found = q + p * IGD_WAVE + __builtin_ctzll(m);
+        }
+        return found >= 0 ? found : q;
+    };
+    const int q0 = handover((int)((long long)a.nq * gwave / nwaves)), q1 = handover((int)((long long)a.nq * (gwave + 1) / nwaves));
     DRaw A, B;
     bool appDirty = false;
     bool broken = false;
     for (int cur = q0; cur < q1 && !broken;) {
-        const int n = q1 - cur < passLen ? q1 - cur : passLen;
+        const int n = q1 - cur < IGD_C_PASS ? q1 - cur : IGD_C_PASS;
         // ---- 1. keys, order, segments ----
         int nseg = 0, nEff = n;
         {
-            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)KARGD(a.q_ichr), 0, a.nq * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)a.q_qs, 0, a.nq * 4, 0x00020000);
-            const int vo4 = lane * 4;
             int C[IGD_C_BLOCKS], S[IGD_C_BLOCKS];
 #pragma unroll
             for (int p = 0; p < IGD_C_BLOCKS; p++) {
@@ -110,14 +148,6 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
                 pc = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, 0, (cur - 1) * 4, 0);
                 ps = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, 0, (cur - 1) * 4, 0);
             }
-            auto key_of = [&](int c, int s, bool &ok) -> int {
-                const bool cOk = (unsigned)c < (unsigned)nCtg;
-                const int cb = cOk ? sBase[c] : 0, cm = cOk ? sNTile[c] - 1 : -1;
-                const int n1r = tile_shift(s, sh);
-                const int n1c = n1r < 0 ? 0 : (n1r > cm ? cm : n1r);
-                ok = cOk && cm >= 0;                      // (a contig without tiles holds nothing: :462)
-                return c < 0 ? -1 : (c >= nCtg ? nT : cb + n1c);
-            };
             bool pok;
             int carryK = cur > 0 ? key_of(pc, ps, pok) : INT_MIN, carryS = cur > 0 ? ps : INT_MIN, carryG = INT_MIN, carryC = pc;
             carryK = __builtin_amdgcn_readfirstlane(carryK); carryS = __builtin_amdgcn_readfirstlane(carryS); carryC = __builtin_amdgcn_readfirstlane(carryC);
@@ -145,7 +175,7 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
                 const bool nb = valid && (idx == 0 || g != pg);
                 const unsigned long long m = __ballot(nb);
                 const int slot = nseg + __popcll(m & below);
-                if (nb && slot < IGD_C_SEGS) { segG[slot] = g; segP[slot] = (unsigned short)idx; }
+                if (nb && slot < IGD_C_SEGS) { segG[slot] = g; segP[slot] = idx; }
                 const int cnt = __popcll(m);
                 if (nseg + cnt > IGD_C_SEGS) {            // more tiles than lanes: the pass ends where segment 65 would begin
                     const unsigned long long mc = __ballot(nb && slot == IGD_C_SEGS);
@@ -157,7 +187,13 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
             }
             if (nseg > IGD_C_SEGS) nseg = IGD_C_SEGS;
             if (__ballot(bad)) { d_mark_broken<true>(a, lane); broken = true; }
-            if (lane == 0) segP[nseg] = (unsigned short)nEff;          // closes the last segment
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // A pass ends where a tile ends: the window's last segment is cut short by the window (its tile goes on behind it)
+            // unless the window ends with the wave's range -- left to the next pass, which starts at its first query.  (A tile
+            // with more queries than a window holds is counted window by window: no boundary to wait for.)
+            if (nEff == n && cur + n < q1 && nseg >= 2) { nseg--; nEff = segP[nseg]; }
+            else if (lane == 0) segP[nseg] = nEff;       // closes the last segment
         }
         if (broken) break;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
