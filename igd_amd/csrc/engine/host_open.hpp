@@ -396,9 +396,9 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
             db->ldsDirect = hitB + (IGD_WG_DIR / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
-            // igd_scan_chunks: + 64 running item counts per wave and the two contig tables per workgroup; it needs the array of
-            // query starts to hold a whole pass (IGD_C_PASS < sbCap) and two workgroups per CU
-            db->ldsChunks = hitB + (IGD_WG_DIR / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap + 4 * IGD_C_SEGS) + 8 * d->nCtg;
+            // igd_scan_chunks: + the two contig tables per workgroup; it needs the array of query starts to hold a whole run
+            // (IGD_C_PASS < sbCap) and two workgroups per CU
+            db->ldsChunks = db->ldsDirect + 8 * d->nCtg;
             if (db->sbCap <= IGD_C_PASS || 2 * (db->ldsChunks + 256) > 160 * 1024) db->ldsChunks = 0;
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU

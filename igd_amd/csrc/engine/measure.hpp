@@ -116,7 +116,7 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (path == 2 ? 8ll * (db->nT + 1) : sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
         if (direct) out->unit_bytes = (int64_t)(sizeof(Unit) + 8 + 16) * db->nUnits;      // per unit: its descriptor, two entries of firstQ[], its tile's int4 of tileD[]
         const bool chunked = direct && db->lastChunks != 0;
-        if (chunked) out->unit_bytes = (int64_t)(sizeof(Unit) + 8 + 16) * (int64_t)acc[0];   // igd_scan_chunks: the VISITED units' descriptors, two entries of tileUnit0[], tileD[]
+        if (chunked) out->unit_bytes = 16ll * (int64_t)acc[0];   // igd_scan_chunks: one int4 of tileD[] per visited tile (charged per visited unit; no unit descriptors are read)
         // merge join, compact image: one 4-byte word per query (qw0), the compacted later-tile words (later[]: every entry is
         // read at least once), the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe;
         // bucket path: 8 B per pair

@@ -1,32 +1,35 @@
 // engine/scan_chunks.hpp -- part of igd_hip.hip (included there once; not a stand-alone header).
-// The DIRECT step, query-partitioned (round 6): ONE kernel reads every query once -- no pre-pass at all.
+// The DIRECT step as a merge of two ordered streams (round 6): ONE kernel reads every query once -- no pre-pass at all.
 // ------------------------------------------------------------------------------------------
 // Round 5's DIRECT step was k_query_bounds<.., BONLY> (firstQ[] = the first query of every tile: 8 bytes per query read, 21-24 us
 // for 1.25e7 queries) -> igd_scan_direct (units dealt to waves, each unit looks its tile's query range up in firstQ[] and reads
 // those queries: 8 more bytes per query) -> k_reduce_slabs.  Here the QUERIES are dealt to the waves instead:
-//   * wave w owns the contiguous range [nq * w / nwaves, nq * (w + 1) / nwaves) of the position-sorted batch and works through it
-//     in passes of at most IGD_C_PASS (960) queries;
-//   * a pass reads contig numbers and starts (8 bytes per query, coalesced), works out every query's key -- the global number
-//     of its first tile, clamped into its contig as src/igd_search.c:459-464 does -- checks the order promise on (key, start)
-//     with the pass's predecessor as seam, and cuts the pass where the key changes: <= 64 SEGMENTS (tile, first query, count);
-//   * the segments' tiles are expanded into (unit, first query, count) items, one per lane, and every item is counted by
-//     d_compute (scan_direct.hpp) exactly as round 5's kernel counted (unit, the tile's whole range): the rank method over the
-//     unit's records, the next tile's first records riding along, the exceptions listed for the exact walks.  d_compute reads
-//     the item's qs / qe itself (the starts a second time -- from L2, the wave has just read them).
+//   * wave w owns a contiguous range of the position-sorted batch -- nominally [nq * w / nwaves, nq * (w + 1) / nwaves), each
+//     border moved forward to the first query of the next tile when one begins within IGD_C_HAND queries (handover(): a
+//     function of the queries around the border alone, so that both neighbours work it out alike) -- and reads it as a STREAM:
+//     blocks of 64 queries (contig, start, end: 12 bytes per query, coalesced), the next block always in flight;
+//   * the first query of the stream names a tile (src/igd_search.c:459-464: first tile, clamped into the contig); the tile's
+//     first unit is counted by d_compute<.., STREAM> (scan_direct.hpp) against the RUN of queries that belong to the tile --
+//     found while they are counted: the run ends at the first query of another tile, at the wave's border or after
+//     IGD_C_PASS queries (the LDS array of starts; the tile then simply goes on as the next item) -- the rank method over the
+//     unit's records, the next tile's first records riding along, the exceptions listed for the exact walks, as in round 5;
+//     a tile's further units (> 320 records) are counted against the now known range [f0, f0 + c0) by the round-5 code;
+//   * a tile's records are in flight before its turn comes: the item after (tile g, unit r) is (g, r + 1) or -- what a dense
+//     batch makes true nearly always -- (g + 1, 0); a wrong guess (a tile without queries) costs a round trip.  The per-tile
+//     descriptors come from a 64-tile window of tileD[] held one per lane.
 // Why the sums are right: per record, hits = #{q: start < qe} - #{q: end <= qs} over the queries of a tile is additive over ANY
-// partition of those queries, so the waves on either side of a seam inside a tile each add their own part (src/igd_search.c:
-// 479-493: the reference counts query by query).  What the first unit of a tile does per query -- listing it for a walk of its
-// later tiles, pushing it into the next tile's first records -- is per query as well.
+// partition of those queries (src/igd_search.c:479-493: the reference counts query by query), so a tile cut by a border or
+// by IGD_C_PASS is counted in parts; what a tile's first unit does per query -- listing it for a walk of its later tiles,
+// pushing it into the next tile's first records -- is per query as well.
+// The order promise is verified on the way: keys of consecutive runs never decrease (a wave's first run against the query
+// before its range), starts inside a run never decrease, every query of a run has the run's contig and tile.
 // What goes away with the tile-keyed ranges: firstQ[], the bounds pass and its launch, the heavy-tile slices (a tile with 10^6
-// queries is simply 10^6 / 960 items spread over all waves) and every add that is not to a workgroup's own LDS counters: a
-// batch found out of order by ANY wave has added nothing when k_reduce_slabs looks at the mark.
+// queries is 10^6 / 960 items spread over all waves) and every add that is not to a workgroup's own LDS counters: a batch found
+// out of order by ANY wave has added nothing when k_reduce_slabs looks at the mark.
 // 32-bit counters: the host only takes this step when (queries per wave) x (records of the fullest tile + what rides along)
 // stays below a wave's share of 2^32 (chunks_fit): no run-time guard, no far list.
-// HBM bytes: 12 per query (contig, start, end: once) + 6 per record of a visited unit (+ the <= 64 appended) + descriptors.
+// HBM bytes: 12 per query (contig, start, end: once) + 6 per record of a visited unit (+ the <= 64 appended) + 16 per tile.
 
-#define IGD_C_PASS 960                                  // queries per pass: 15 blocks of 64; < the LDS array of query starts (sbCap = 1024)
-#define IGD_C_BLOCKS (IGD_C_PASS / IGD_WAVE)
-#define IGD_C_SEGS 64                                   // segments per pass: one per lane
 #define IGD_C_HAND 512                                  // a wave's border moves to the next tile's first query when that lies within this many queries
 
 template <bool USE_V>
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
     unsigned short *sl = (unsigned short *)(smem + hitBytes + (size_t)wid * (size_t)wlds);
     unsigned int *hist = (unsigned int *)(sl + IGD_D_SL);
     unsigned short *sb = (unsigned short *)(hist + IGD_D_H);
-    int32_t *sBase = (int32_t *)(smem + hitBytes + (size_t)wavesPerWG * (size_t)wlds);   // the two per-contig tables every query looks up
+    int32_t *sBase = (int32_t *)(smem + hitBytes + (size_t)wavesPerWG * (size_t)wlds);   // the two per-contig tables every run's first query looks up
     int32_t *sNTile = sBase + nCtg;
     // What every batch owes its caller and the NEXT batch (k_query_bounds does it for the other steps): hits[] cleared under
     // IGD_HIP_FLAG_ZERO_FIRST -- nothing is added to it before this kernel has ended -- and the other parity's list counters.
@@ -74,16 +77,14 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
     __syncthreads();
     const int gwave = (int)blockIdx.x * wavesPerWG + wid;
     const long long nwaves = (long long)gridDim.x * wavesPerWG;
-    const int sh = db.shift, nT = db.nT;
-    // (the segment list lives in the array of query starts, which no unit is using while a pass is being cut up; the running
-    // item counts are needed while units are counted: an area of their own behind it)
-    int32_t *segG = (int32_t *)sb;                        // [64] a segment's tile
-    int32_t *segP = segG + IGD_C_SEGS;                    // [65] a segment's first query (relative to the pass), closed by the pass's end
-    int32_t *segI = (int32_t *)(sb + KARGD(a.sbCap));     // [64] running number of items up to and including a segment
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)KARGD(a.q_ichr), 0, a.nq * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)a.q_qs, 0, a.nq * 4, 0x00020000);
+    const int sh = db.shift, nT = db.nT, nq = a.nq;
+    CStream st;
+    st.rsC = __builtin_amdgcn_make_buffer_rsrc((void *)KARGD(a.q_ichr), 0, nq * 4, 0x00020000);
+    st.rsS = __builtin_amdgcn_make_buffer_rsrc((void *)a.q_qs, 0, nq * 4, 0x00020000);
+    st.rsE = __builtin_amdgcn_make_buffer_rsrc((void *)a.q_qe, 0, nq * 4, 0x00020000);
     const int vo4 = lane * 4;
+    // key of a query: the global number of its first tile, clamped into its contig (k_query_bounds' BONLY form: contig numbers
+    // outside the database get -1 / nT); ok: a tile owns the query
     auto key_of = [&](int c, int s, bool &ok) -> int {
         const bool cOk = (unsigned)c < (unsigned)nCtg;
         const int cb = cOk ? sBase[c] : 0, cm = cOk ? sNTile[c] - 1 : -1;
@@ -92,176 +93,178 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
         ok = cOk && cm >= 0;                              // (a contig without tiles holds nothing: :462)
         return c < 0 ? -1 : (c >= nCtg ? nT : cb + n1c);
     };
-    // ---- 0. the wave's range, handed over at tile boundaries ----
-    // Nominally [nq * w / nwaves, nq * (w + 1) / nwaves).  A tile cut by such a border would be counted in two parts -- twice the
-    // per-unit work (staging, prefix sums, the bisections of term B) for the same records -- so a border moves forward to the
-    // first query of the next tile when one begins within IGD_C_HAND queries: handover(q) is a function of the queries around q
-    // alone, and the two waves on either side of a border work it out alike.
-    auto handover = [&](int q) -> int {
-        if (q <= 0) return 0;
-        if (q >= a.nq) return a.nq;
-        int C[IGD_C_HAND / IGD_WAVE], S[IGD_C_HAND / IGD_WAVE];
+    // ---- the wave's range, handed over at tile boundaries ----
+    // A tile cut by a border would be counted in two parts -- twice the per-unit work (staging, prefix sums, the bisections of
+    // term B) for the same records -- so a border moves forward to the first query of the next tile when one begins within
+    // IGD_C_HAND queries.  Both borders' windows are asked for at once.
+    const int n0 = (int)((long long)nq * gwave / nwaves), n1 = (int)((long long)nq * (gwave + 1) / nwaves);
+    int q0, q1;
+    {
+        constexpr int HB = IGD_C_HAND / IGD_WAVE;
+        int C0[HB], S0[HB], C1[HB], S1[HB];
 #pragma unroll
-        for (int p = 0; p < IGD_C_HAND / IGD_WAVE; p++) {
-            C[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, vo4, (q + p * IGD_WAVE) * 4, 0);
-            S[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (q + p * IGD_WAVE) * 4, 0);
+        for (int p = 0; p < HB; p++) {
+            C0[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, vo4, (n0 + p * IGD_WAVE) * 4, 0);
+            S0[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, vo4, (n0 + p * IGD_WAVE) * 4, 0);
+            C1[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, vo4, (n1 + p * IGD_WAVE) * 4, 0);
+            S1[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, vo4, (n1 + p * IGD_WAVE) * 4, 0);
         }
-        const int pc = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, 0, (q - 1) * 4, 0);
-        const int ps = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, 0, (q - 1) * 4, 0);
-        bool ok;
-        int carryG = key_of(pc, ps, ok);
-        carryG = __builtin_amdgcn_readfirstlane(ok ? carryG : -1);
-        int found = -1;
+        // (the query before a border; a border at 0 or nq reads nothing it uses)
+        const int pc0 = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, 0, (n0 > 0 ? n0 - 1 : 0) * 4, 0);
+        const int ps0 = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, 0, (n0 > 0 ? n0 - 1 : 0) * 4, 0);
+        const int pc1 = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, 0, (n1 > 0 ? n1 - 1 : 0) * 4, 0);
+        const int ps1 = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, 0, (n1 > 0 ? n1 - 1 : 0) * 4, 0);
+        auto handover = [&](int q, int pc, int ps, const int (&C)[HB], const int (&S)[HB]) -> int {
+            if (q <= 0) return 0;
+            if (q >= nq) return nq;
+            bool ok;
+            int carryG = key_of(pc, ps, ok);
+            carryG = __builtin_amdgcn_readfirstlane(ok ? carryG : -1);
+            int found = -1;
 #pragma unroll
-        for (int p = 0; p < IGD_C_HAND / IGD_WAVE; p++) {
-            if (found >= 0) continue;
-            const int k = key_of(C[p], S[p], ok);
-            const int g = ok ? k : -1;
-            const int pg = __builtin_amdgcn_update_dpp(carryG, g, 0x138, 0xf, 0xf, false);
-            carryG = __builtin_amdgcn_readlane(g, IGD_WAVE - 1);
-            const unsigned long long m = __ballot(q + p * IGD_WAVE + lane < a.nq && g != pg);
-            if (m) found = q + p * IGD_WAVE + __builtin_ctzll(m);
-        }
-        return found >= 0 ? found : q;
-    };
-    const int q0 = handover((int)((long long)a.nq * gwave / nwaves)), q1 = handover((int)((long long)a.nq * (gwave + 1) / nwaves));
-    DRaw A, B;
-    bool appDirty = false;
-    bool broken = false;
-    for (int cur = q0; cur < q1 && !broken;) {
-        const int n = q1 - cur < IGD_C_PASS ? q1 - cur : IGD_C_PASS;
-        // ---- 1. keys, order, segments ----
-        int nseg = 0, nEff = n;
-        {
-            int C[IGD_C_BLOCKS], S[IGD_C_BLOCKS];
-#pragma unroll
-            for (int p = 0; p < IGD_C_BLOCKS; p++) {
-                C[p] = 0; S[p] = 0;
-                if (p * IGD_WAVE < n) {
-                    C[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, vo4, (cur + p * IGD_WAVE) * 4, 0);
-                    S[p] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (cur + p * IGD_WAVE) * 4, 0);
-                }
-            }
-            // the query before the pass: the seam of the order check (the batch's first query has none)
-            int pc = -1, ps = INT_MIN;
-            if (cur > 0) {
-                pc = (int)__builtin_amdgcn_raw_buffer_load_b32(rsC, 0, (cur - 1) * 4, 0);
-                ps = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, 0, (cur - 1) * 4, 0);
-            }
-            bool pok;
-            int carryK = cur > 0 ? key_of(pc, ps, pok) : INT_MIN, carryS = cur > 0 ? ps : INT_MIN, carryG = INT_MIN, carryC = pc;
-            carryK = __builtin_amdgcn_readfirstlane(carryK); carryS = __builtin_amdgcn_readfirstlane(carryS); carryC = __builtin_amdgcn_readfirstlane(carryC);
-            bool bad = false;
-#pragma unroll
-            for (int p = 0; p < IGD_C_BLOCKS; p++) {
-                // (no `break`: the loop must unroll completely -- C[] / S[] are registers only then)
-                if (p * IGD_WAVE >= nEff || nseg > IGD_C_SEGS) continue;
-                const int idx = p * IGD_WAVE + lane;
-                const bool valid = idx < nEff;
-                bool ok;
+            for (int p = 0; p < HB; p++) {
                 const int k = key_of(C[p], S[p], ok);
-                const int g = (ok && valid) ? k : -1;     // the tile whose units count the query (-1: none does)
-                // lane i gets lane i - 1's value, lane 0 the last one of the block before (DPP wave_shr:1)
-                const int pk = __builtin_amdgcn_update_dpp(carryK, k, 0x138, 0xf, 0xf, false);
-                const int pq = __builtin_amdgcn_update_dpp(carryS, S[p], 0x138, 0xf, 0xf, false);
+                const int g = ok ? k : -1;
                 const int pg = __builtin_amdgcn_update_dpp(carryG, g, 0x138, 0xf, 0xf, false);
-                const int pcn = __builtin_amdgcn_update_dpp(carryC, C[p], 0x138, 0xf, 0xf, false);
-                // the promise: keys never decrease, and inside one contig's tile neither do the starts (k_query_bounds' rule)
-                bad = bad || (valid && (k < pk || (k == pk && C[p] == pcn && S[p] < pq)));
-                carryC = __builtin_amdgcn_readlane(C[p], IGD_WAVE - 1);
-                carryK = __builtin_amdgcn_readlane(k, IGD_WAVE - 1);
-                carryS = __builtin_amdgcn_readlane(S[p], IGD_WAVE - 1);
                 carryG = __builtin_amdgcn_readlane(g, IGD_WAVE - 1);
-                const bool nb = valid && (idx == 0 || g != pg);
-                const unsigned long long m = __ballot(nb);
-                const int slot = nseg + __popcll(m & below);
-                if (nb && slot < IGD_C_SEGS) { segG[slot] = g; segP[slot] = idx; }
-                const int cnt = __popcll(m);
-                if (nseg + cnt > IGD_C_SEGS) {            // more tiles than lanes: the pass ends where segment 65 would begin
-                    const unsigned long long mc = __ballot(nb && slot == IGD_C_SEGS);
-                    nEff = __builtin_amdgcn_readlane(idx, __builtin_ctzll(mc));
-                    nseg = IGD_C_SEGS + 1;                // (the blocks behind are skipped; the queries of this block beyond the cut
-                    continue;                             // are looked at again by the next pass, the order check included)
-                }
-                nseg += cnt;
+                const unsigned long long m = __ballot(q + p * IGD_WAVE + lane < nq && g != pg);
+                if (found < 0 && m) found = q + p * IGD_WAVE + __builtin_ctzll(m);
             }
-            if (nseg > IGD_C_SEGS) nseg = IGD_C_SEGS;
-            if (__ballot(bad)) { d_mark_broken<true>(a, lane); broken = true; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // A pass ends where a tile ends: the window's last segment is cut short by the window (its tile goes on behind it)
-            // unless the window ends with the wave's range -- left to the next pass, which starts at its first query.  (A tile
-            // with more queries than a window holds is counted window by window: no boundary to wait for.)
-            if (nEff == n && cur + n < q1 && nseg >= 2) { nseg--; nEff = segP[nseg]; }
-            else if (lane == 0) segP[nseg] = nEff;       // closes the last segment
+            return found >= 0 ? found : q;
+        };
+        q0 = handover(n0, pc0, ps0, C0, S0);
+        q1 = handover(n1, pc1, ps1, C1, S1);
+    }
+    if (q0 < q1) {
+        // ---- the stream ----
+        st.bpos = q0;
+        st.C = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, vo4, q0 * 4, 0);
+        st.S = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, vo4, q0 * 4, 0);
+        st.E = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsE, vo4, q0 * 4, 0);
+        c_stream_issue(st, lane);
+        int lastKey = INT_MIN, lastS = INT_MIN;           // key and start of the query before the next run (at first: before the range -- the order check's seam)
+        if (q0 > 0) {
+            const int pc = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, 0, (q0 - 1) * 4, 0);
+            const int ps = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, 0, (q0 - 1) * 4, 0);
+            bool ok;
+            lastKey = __builtin_amdgcn_readfirstlane(key_of(pc, ps, ok));
+            lastS = __builtin_amdgcn_readfirstlane(ok ? ps : INT_MIN);
         }
-        if (broken) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- 2. lane i = segment i: its tile's units ----
-        int sg = -1, sf0 = 0, sc0 = 0;
-        if (lane < nseg) {
-            sg = segG[lane];
-            const int pos = segP[lane], end = segP[lane + 1];
-            sf0 = cur + pos; sc0 = end - pos;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const bool okSeg = sg >= 0 && sg < nT;
-        int su0 = 0, snu = 0, sAppOff = 0, sAppMeta = 0;
-        if (okSeg) {
-            const int32_t *tu = KARGD(db.tileUnit0);
-            su0 = tu[sg]; snu = tu[sg + 1] - su0;
-            const int4 d = KARGD(a.tileD)[sg];
-            sAppOff = d.x; sAppMeta = d.y;
-        }
-        const int incl = wave_inclusive_sum(snu), excl = incl - snu;
-        const int total = __builtin_amdgcn_readlane(incl, IGD_WAVE - 1);
-        segI[lane] = incl;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int ib = 0; ib < total; ib += IGD_WAVE) {
-            // ---- 3. item ib + lane: which segment, which of its units ----
-            DRegs L;
-            L.offLo = L.n = L.jf = L.f0 = L.c0 = L.appOff = L.appMeta = 0;
-            {
-                const int k = ib + lane;
-                int s = 0;                                // the first segment whose running count exceeds k
+        int off = 0;                                      // lane of the current block at which the next run begins
+        // the 64-tile window of tileD[]: lane i holds tile wbase + i
+        int wbase = -(1 << 29);                          // (no window yet; g - wbase stays an int)
+        int4 dwin = make_int4(0, 0, 0, 0);
+        const int4 *tileD = KARGD(a.tileD);
+        auto window = [&](int g) {                        // (a round trip: once per 63 tiles)
+            if (g >= wbase && g < wbase + IGD_WAVE - 1) return;
+            wbase = g;
+            dwin = (g + lane < nT) ? tileD[g + lane] : make_int4(0, 0, 0, 0);
+        };
+        // one unit of tile g in the form d_compute takes it (the same unit in every lane, read with lane 0)
+        auto unit_regs = [&](int g, int r, DRegs &L) {
+            const int wl = g - wbase;
+            const int ao = __builtin_amdgcn_readlane(dwin.x, wl), am = __builtin_amdgcn_readlane(dwin.y, wl);
+            const int of = __builtin_amdgcn_readlane(dwin.z, wl), cn = __builtin_amdgcn_readlane(dwin.w, wl);
+            const int left = cn - r * IGD_CHUNK;
+            L.offLo = of + r * IGD_CHUNK;
+            L.n = left < IGD_CHUNK ? (left > 0 ? left : 0) : IGD_CHUNK;
+            L.jf = ((g - sBase[(am >> 13) & 1023]) << 4) | (r == 0 ? 1 : 0);
+            L.appOff = ao; L.appMeta = am;
+            L.f0 = 0; L.c0 = 1;
+        };
+        // the records of a unit, asked for (no queries: the stream brings them; a further unit's known range is read by d_compute)
+        auto issue = [&](const DRegs &L, DRaw &R) {
+            const int n = L.n, jf = L.jf, meta = L.appMeta;
+            const int appN = (jf & 1) ? (meta & 127) : 0;
+            R.c0 = 1; R.f0 = 0; R.n = n;
+            R.qs = 0; R.qe = 0;
+            const unsigned offLo = (unsigned)L.offLo, appOff = (unsigned)L.appOff;
+            const int end = (int)offLo + n, endA = (int)appOff + appN;
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, (int)((unsigned)end * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, appN ? (int)((unsigned)endA * 4u) : 0, 0x00020000);
 #pragma unroll
-                for (int step = 32; step > 0; step >>= 1) s += (segI[s + step - 1] <= k) ? step : 0;
-                s = s > 63 ? 63 : s;
-                const int bp = s * 4;
-                const int u0_ = __builtin_amdgcn_ds_bpermute(bp, su0), ex_ = __builtin_amdgcn_ds_bpermute(bp, excl);
-                const int f0_ = __builtin_amdgcn_ds_bpermute(bp, sf0), c0_ = __builtin_amdgcn_ds_bpermute(bp, sc0);
-                const int ao_ = __builtin_amdgcn_ds_bpermute(bp, sAppOff), am_ = __builtin_amdgcn_ds_bpermute(bp, sAppMeta);
-                if (k < total) {
-                    const Unit *up = KARGD(db.units) + (u0_ + (k - ex_));
-                    const int4 ua = ((const int4 *)up)[0];
-                    const int ujf = ((const int32_t *)up)[4];
-                    L.offLo = ua.x; L.n = ua.w; L.jf = ujf;
-                    L.f0 = f0_; L.c0 = c0_;
-                    L.appOff = ao_; L.appMeta = am_;
-                    // only a tile's first unit sees its queries when the tile holds no record (its placeholder)
-                    if (ua.w == 0 && !(ujf & 1)) L.c0 = 0;
+            for (int r = 0; r < IGD_SLOTS; r++) R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
+            R.a[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
+            d_load_x<USE_V>(db, R.x, offLo, n, appOff, appN, lane);
+        };
+        DRaw A, B;
+        DRegs LA, LB;
+        int gA = -2, rA = 0, gB = -2, rB = 0;             // the units whose records A / B hold (or wait for)
+        bool appDirty = false, broken = false;
+        for (;;) {
+            // ---- the next run: where the stream stands ----
+            if (off >= IGD_WAVE) { c_stream_advance(st, lane); off = 0; }
+            const int cur = st.bpos + off;
+            if (cur >= q1) break;
+            const int c_ = __builtin_amdgcn_readlane(st.C, off), s_ = __builtin_amdgcn_readlane(st.S, off);
+            bool ok;
+            const int k = key_of(c_, s_, ok);
+            // keys never decrease; k == lastKey: a tile that goes on (behind a border or IGD_C_PASS queries) -- its starts go on too
+            if (k < lastKey || (ok && k == lastKey && s_ < lastS)) { broken = true; break; }
+            lastKey = k;
+            if (!ok) {
+                // a run no tile owns (contig outside the database, contig without tiles): its keys must not decrease either
+                int carryK = k;
+                bool cont = false;                        // (behind the run's first block lane 0 is compared with the block before)
+                for (;;) {
+                    bool okl;
+                    const int kl = key_of(st.C, st.S, okl);
+                    const int pk = __builtin_amdgcn_update_dpp(carryK, kl, 0x138, 0xf, 0xf, false);
+                    const unsigned long long stop = __ballot(lane >= off && (okl || st.bpos + lane >= q1));
+                    const int e = stop ? __builtin_ctzll(stop) : IGD_WAVE;
+                    if (__ballot(lane >= off && lane < e && (lane > off || cont) && kl < pk)) broken = true;
+                    if (e > off) lastKey = __builtin_amdgcn_readlane(kl, e - 1);
+                    if (e < IGD_WAVE) { off = e; break; }
+                    carryK = __builtin_amdgcn_readlane(kl, IGD_WAVE - 1);
+                    c_stream_advance(st, lane);
+                    off = 0;
+                    cont = true;
                 }
+                lastS = INT_MIN;
+                if (broken) break;
+                continue;
             }
-            unsigned long long m = __ballot(L.c0 != 0);
-            int ka = -1, kb = -1;
-            if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
-            if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
-            d_issue<USE_V>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
-            while (ka >= 0) {
-                d_issue<USE_V>(db, a, L, kb < 0 ? 0 : kb, kb >= 0, lane, B);
-                d_compute<USE_V, false, true, false>(db, a, L, ka, lane, A, hits, sl, hist, sb, INT_MIN, &appDirty);
-                ka = -1;
-                if (m) { ka = __builtin_ctzll(m); m &= m - 1; }
-                d_issue<USE_V>(db, a, L, ka < 0 ? 0 : ka, ka >= 0, lane, A);
-                if (kb >= 0) d_compute<USE_V, false, true, false>(db, a, L, kb, lane, B, hits, sl, hist, sb, INT_MIN, &appDirty);
-                kb = -1;
-                if (m) { kb = __builtin_ctzll(m); m &= m - 1; }
+            // ---- tile k: its first unit against the run, its further units against the range the run turns out to be ----
+            const int g = k;
+            window(g);
+            if (!(gA == g && rA == 0)) {
+                if (gB == g && rB == 0) { A = B; LA = LB; gA = gB; rA = rB; gB = -2; }
+                else { unit_regs(g, 0, LA); issue(LA, A); gA = g; rA = 0; }       // (a wrong guess, or the wave's first tile: a round trip)
+            }
+            const int cnt = __builtin_amdgcn_readlane(dwin.w, g - wbase);
+            const int nu = cnt > 0 ? (cnt + IGD_CHUNK - 1) / IGD_CHUNK : 1;
+            // what comes next is asked for now: the tile's second unit, or the next tile's first
+            {
+                const int gN = nu > 1 ? g : g + 1, rN = nu > 1 ? 1 : 0;
+                if (gN < nT && gN - wbase < IGD_WAVE && !(gB == gN && rB == rN)) { unit_regs(gN, rN, LB); issue(LB, B); gB = gN; rB = rN; }
+            }
+            const int meta = LA.appMeta;
+            const int ctg = (meta >> 13) & 1023;
+            const int j = LA.jf >> 4, cm = sNTile[ctg] - 1;
+            const int f0 = cur;
+            int offOut = off;
+            const int c0 = d_compute<USE_V, false, true, false, true>(db, a, LA, 0, lane, A, hits, sl, hist, sb, INT_MIN, &appDirty,
+                                                                      &st, off, q1, ctg, j == 0 ? INT_MIN : j, j == cm ? INT_MAX : j, &offOut, &lastS);
+            off = offOut;
+            gA = -2;
+            if (c0 <= 0) { broken = true; break; }        // (cannot happen: the run's first query belongs to its tile)
+            for (int r = 1; r < nu; r++) {
+                // unit r is in B (asked for while unit r - 1 was counted); behind it comes unit r + 1 or the next tile
+                if (gB == g && rB == r) { A = B; LA = LB; } else { unit_regs(g, r, LA); issue(LA, A); }
+                gB = -2;
+                {
+                    const int gN = r + 1 < nu ? g : g + 1, rN = r + 1 < nu ? r + 1 : 0;
+                    if (gN < nT && gN - wbase < IGD_WAVE) { unit_regs(gN, rN, LB); issue(LB, B); gB = gN; rB = rN; }
+                }
+                LA.f0 = f0; LA.c0 = c0;
+                A.f0 = f0; A.c0 = c0;
+                // (the first 64 queries of the range: d_compute's first batch)
+                A.qs = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, vo4, f0 * 4, 0);
+                A.qe = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsE, vo4, f0 * 4, 0);
+                d_compute<USE_V, false, true, false>(db, a, LA, 0, lane, A, hits, sl, hist, sb, INT_MIN, &appDirty);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        cur += nEff;
+        if (broken) d_mark_broken<true>(a, lane);
     }
     __syncthreads();
     {
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
 static bool chunks_fit(int64_t nq, int grid, int64_t maxTileRecords)
 {
     const int64_t wavesPerWG = IGD_WG_DIR / IGD_WAVE, nwaves = (int64_t)grid * wavesPerWG;
-    const int64_t perWave = (nq + nwaves - 1) / nwaves + 1;
+    const int64_t perWave = (nq + nwaves - 1) / nwaves + 1 + IGD_C_HAND;
     const int64_t perTile = maxTileRecords + (int64_t)IGD_D_APP * ((maxTileRecords + IGD_CHUNK - 1) / IGD_CHUNK + 1);
     return perWave * perTile < ((int64_t)1 << 32) / wavesPerWG;
 }
