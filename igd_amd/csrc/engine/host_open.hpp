@@ -398,7 +398,7 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             db->ldsDirect = hitB + (IGD_WG_DIR / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
             // igd_scan_chunks: + the two contig tables per workgroup; it needs the array of query starts to hold a whole run
             // (IGD_C_PASS < sbCap) and two workgroups per CU
-            db->ldsChunks = db->ldsDirect + 8 * d->nCtg;
+            db->ldsChunks = db->ldsDirect + (IGD_WG_DIR / IGD_WAVE) * 16 * IGD_C_WIN + 8 * d->nCtg;   // + a window of tileD[] per wave
             if (db->sbCap <= IGD_C_PASS || 2 * (db->ldsChunks + 256) > 160 * 1024) db->ldsChunks = 0;
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU

@@ -439,6 +439,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
                 D.a.rule = rule; D.a.promised = 1; D.a.sbCap = db->sbCap; D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap;
                 D.a.out = db->d_slab; D.a.hitsOut = (u64 *)d_hits; D.a.totalOut = (u64 *)d_total;
                 if (chunks) {
+                    D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap + 16 * IGD_C_WIN;
                     if (useV) launch_sorted(db, igd_scan_chunks<true>, db->grid, IGD_WG_DIR, (size_t)db->ldsChunks, st, D);
                     else launch_sorted(db, igd_scan_chunks<false>, db->grid, IGD_WG_DIR, (size_t)db->ldsChunks, st, D);
                 } else

@@ -16,7 +16,7 @@
 //     a tile's further units (> 320 records) are counted against the now known range [f0, f0 + c0) by the round-5 code;
 //   * a tile's records are in flight before its turn comes: the item after (tile g, unit r) is (g, r + 1) or -- what a dense
 //     batch makes true nearly always -- (g + 1, 0); a wrong guess (a tile without queries) costs a round trip.  The per-tile
-//     descriptors come from a 64-tile window of tileD[] held one per lane.
+//     descriptors come from a 32-tile window of tileD[] in the wave's LDS.
 // Why the sums are right: per record, hits = #{q: start < qe} - #{q: end <= qs} over the queries of a tile is additive over ANY
 // partition of those queries (src/igd_search.c:479-493: the reference counts query by query), so a tile cut by a border or
 // by IGD_C_PASS is counted in parts; what a tile's first unit does per query -- listing it for a walk of its later tiles,
@@ -31,6 +31,7 @@
 // HBM bytes: 12 per query (contig, start, end: once) + 6 per record of a visited unit (+ the <= 64 appended) + 16 per tile.
 
 #define IGD_C_HAND 512                                  // a wave's border moves to the next tile's first query when that lies within this many queries
+#define IGD_C_WIN 32                                    // tiles of tileD[] a wave keeps in LDS
 
 template <bool USE_V>
 __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_WPE_DIR, IGD_WPE_DIR))) void igd_scan_chunks(DirK K)
@@ -151,20 +152,22 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
             lastS = __builtin_amdgcn_readfirstlane(ok ? ps : INT_MIN);
         }
         int off = 0;                                      // lane of the current block at which the next run begins
-        // the 64-tile window of tileD[]: lane i holds tile wbase + i
+        // a window of IGD_C_WIN tiles of tileD[] in the wave's LDS (behind its array of query starts): tile wbase + i at win[i]
         int wbase = -(1 << 29);                          // (no window yet; g - wbase stays an int)
-        int4 dwin = make_int4(0, 0, 0, 0);
+        int4 *win = (int4 *)(sb + KARGD(a.sbCap));
         const int4 *tileD = KARGD(a.tileD);
-        auto window = [&](int g) {                        // (a round trip: once per 63 tiles)
-            if (g >= wbase && g < wbase + IGD_WAVE - 1) return;
+        auto window = [&](int g) {                        // (a round trip: once per IGD_C_WIN - 1 tiles)
+            if (g >= wbase && g < wbase + IGD_C_WIN - 1) return;
             wbase = g;
-            dwin = (g + lane < nT) ? tileD[g + lane] : make_int4(0, 0, 0, 0);
+            if (lane < IGD_C_WIN) win[lane] = (g + lane < nT) ? tileD[g + lane] : make_int4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         };
         // one unit of tile g in the form d_compute takes it (the same unit in every lane, read with lane 0)
         auto unit_regs = [&](int g, int r, DRegs &L) {
-            const int wl = g - wbase;
-            const int ao = __builtin_amdgcn_readlane(dwin.x, wl), am = __builtin_amdgcn_readlane(dwin.y, wl);
-            const int of = __builtin_amdgcn_readlane(dwin.z, wl), cn = __builtin_amdgcn_readlane(dwin.w, wl);
+            const int4 d = win[g - wbase];
+            const int ao = __builtin_amdgcn_readfirstlane(d.x), am = __builtin_amdgcn_readfirstlane(d.y);
+            const int of = __builtin_amdgcn_readfirstlane(d.z), cn = __builtin_amdgcn_readfirstlane(d.w);
             const int left = cn - r * IGD_CHUNK;
             L.offLo = of + r * IGD_CHUNK;
             L.n = left < IGD_CHUNK ? (left > 0 ? left : 0) : IGD_CHUNK;
@@ -172,24 +175,36 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
             L.appOff = ao; L.appMeta = am;
             L.f0 = 0; L.c0 = 1;
         };
-        // the records of a unit, asked for (no queries: the stream brings them; a further unit's known range is read by d_compute)
-        auto issue = [&](const DRegs &L, DRaw &R) {
-            const int n = L.n, jf = L.jf, meta = L.appMeta;
-            const int appN = (jf & 1) ? (meta & 127) : 0;
-            R.c0 = 1; R.f0 = 0; R.n = n;
-            R.qs = 0; R.qe = 0;
+        // the record words of a unit, asked for ahead of its turn (no queries: the stream brings them) ...
+        auto issue = [&](int g, int r, uint32_t (&W)[IGD_SLOTS + 1]) {
+            DRegs L;
+            unit_regs(g, r, L);
+            const int n = L.n;
+            const int appN = (L.jf & 1) ? (L.appMeta & 127) : 0;
             const unsigned offLo = (unsigned)L.offLo, appOff = (unsigned)L.appOff;
             const int end = (int)offLo + n, endA = (int)appOff + appN;
             const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, (int)((unsigned)end * 4u), 0x00020000);
             const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)db.pse, 0, appN ? (int)((unsigned)endA * 4u) : 0, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < IGD_SLOTS; r++) R.a[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + r * 256, (int)(offLo * 4u), 0);
-            R.a[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
-            d_load_x<USE_V>(db, R.x, offLo, n, appOff, appN, lane);
+            for (int q = 0; q < IGD_SLOTS; q++) W[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsA, vo4 + q * 256, (int)(offLo * 4u), 0);
+            W[IGD_SLOTS] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsB, vo4, (int)(appOff * 4u), 0);
         };
-        DRaw A, B;
-        DRegs LA, LB;
-        int gA = -2, rA = 0, gB = -2, rB = 0;             // the units whose records A / B hold (or wait for)
+        // ... and its dataset numbers at its turn: they are first looked at when the unit's counts are flushed, behind all its
+        // batches (six registers that are not held while the unit waits)
+        auto take = [&](int g, int r, const uint32_t (&W)[IGD_SLOTS + 1], DRegs &L, DRaw &R) {
+            unit_regs(g, r, L);
+            const int appN = (L.jf & 1) ? (L.appMeta & 127) : 0;
+#pragma unroll
+            for (int q = 0; q <= IGD_SLOTS; q++) R.a[q] = W[q];
+            R.c0 = 1; R.f0 = 0; R.n = L.n; R.qs = 0; R.qe = 0;
+            d_load_x<USE_V>(db, R.x, (unsigned)L.offLo, L.n, (unsigned)L.appOff, appN, lane);
+        };
+        DRaw A;
+        DRegs LA;
+        uint32_t WB[IGD_SLOTS + 1];                       // the record words of the unit expected next (in flight)
+#pragma unroll
+        for (int q = 0; q <= IGD_SLOTS; q++) WB[q] = 0u;
+        int gB = -2, rB = 0;                              // ... which unit that is
         bool appDirty = false, broken = false;
         for (;;) {
             // ---- the next run: where the stream stands ----
@@ -227,16 +242,15 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
             // ---- tile k: its first unit against the run, its further units against the range the run turns out to be ----
             const int g = k;
             window(g);
-            if (!(gA == g && rA == 0)) {
-                if (gB == g && rB == 0) { A = B; LA = LB; gA = gB; rA = rB; gB = -2; }
-                else { unit_regs(g, 0, LA); issue(LA, A); gA = g; rA = 0; }       // (a wrong guess, or the wave's first tile: a round trip)
-            }
-            const int cnt = __builtin_amdgcn_readlane(dwin.w, g - wbase);
+            if (!(gB == g && rB == 0)) issue(g, 0, WB);   // (a wrong guess, or the wave's first tile: a round trip)
+            take(g, 0, WB, LA, A);
+            const int cnt = __builtin_amdgcn_readfirstlane(win[g - wbase].w);
             const int nu = cnt > 0 ? (cnt + IGD_CHUNK - 1) / IGD_CHUNK : 1;
             // what comes next is asked for now: the tile's second unit, or the next tile's first
             {
                 const int gN = nu > 1 ? g : g + 1, rN = nu > 1 ? 1 : 0;
-                if (gN < nT && gN - wbase < IGD_WAVE && !(gB == gN && rB == rN)) { unit_regs(gN, rN, LB); issue(LB, B); gB = gN; rB = rN; }
+                gB = -2;
+                if (gN < nT && gN - wbase < IGD_C_WIN) { issue(gN, rN, WB); gB = gN; rB = rN; }
             }
             const int meta = LA.appMeta;
             const int ctg = (meta >> 13) & 1023;
@@ -246,15 +260,15 @@ __global__ __launch_bounds__(IGD_WG_DIR) __attribute__((amdgpu_waves_per_eu(IGD_
             const int c0 = d_compute<USE_V, false, true, false, true>(db, a, LA, 0, lane, A, hits, sl, hist, sb, INT_MIN, &appDirty,
                                                                       &st, off, q1, ctg, j == 0 ? INT_MIN : j, j == cm ? INT_MAX : j, &offOut, &lastS);
             off = offOut;
-            gA = -2;
             if (c0 <= 0) { broken = true; break; }        // (cannot happen: the run's first query belongs to its tile)
             for (int r = 1; r < nu; r++) {
-                // unit r is in B (asked for while unit r - 1 was counted); behind it comes unit r + 1 or the next tile
-                if (gB == g && rB == r) { A = B; LA = LB; } else { unit_regs(g, r, LA); issue(LA, A); }
-                gB = -2;
+                // unit r was asked for while unit r - 1 was counted; behind it comes unit r + 1 or the next tile
+                if (!(gB == g && rB == r)) issue(g, r, WB);
+                take(g, r, WB, LA, A);
                 {
                     const int gN = r + 1 < nu ? g : g + 1, rN = r + 1 < nu ? r + 1 : 0;
-                    if (gN < nT && gN - wbase < IGD_WAVE) { unit_regs(gN, rN, LB); issue(LB, B); gB = gN; rB = rN; }
+                    gB = -2;
+                    if (gN < nT && gN - wbase < IGD_C_WIN) { issue(gN, rN, WB); gB = gN; rB = rN; }
                 }
                 LA.f0 = f0; LA.c0 = c0;
                 A.f0 = f0; A.c0 = c0;

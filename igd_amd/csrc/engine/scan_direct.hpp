@@ -401,10 +401,11 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
         if (inLds && there) sb[idx] = (unsigned short)(inTile ? (qs1 > 65535 ? 65535 : qs1) : (front ? 1 : 65535));
     };
     if constexpr (STREAM) {
-        // the run of the tile's queries, block by block from the wave's stream
+        // the run of the tile's queries, block by block from the wave's stream.  (The first block in straight-line code: a load
+        // inside a loop makes the compiler wait for everything in flight at the loop's head -- the next tile's records included.)
         const int sh_ = db.shift;
-        int run = 0, lo = off, carryS = INT_MIN;
-        for (;;) {
+        int run = 0, carryS = INT_MIN;
+        auto block = [&](const int lo) -> int {
             const int qs_ = st->S, qe_ = st->E;
             const int t_ = tile_shift(qs_, sh_);
             const bool mine = lane >= lo && st->bpos + lane < qEnd && run + (lane - lo) < IGD_C_PASS && st->C == ctgS && t_ >= tlo && t_ <= thi;
@@ -417,11 +418,15 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
             batch(run - lo, qs_, qe_, there);
             run += e - lo;
             if (e > lo) *lastSOut = __builtin_amdgcn_readlane(qs_, e - 1);   // (the run's last start so far: the seam of a tile that goes on)
-            if (e < IGD_WAVE) { *offOut = e; break; }
             carryS = __builtin_amdgcn_readlane(qs_, IGD_WAVE - 1);
+            return e;
+        };
+        int e = block(off);
+        while (e == IGD_WAVE) {
             c_stream_advance(*st, lane);
-            lo = 0;
+            e = block(0);
         }
+        *offOut = e;
         c0 = run;
     } else {
         // the next 64 queries are on their way while these are searched (past the batch's last query: no access)
