@@ -426,7 +426,18 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
             c_stream_advance(*st, lane);
             e = block(0);
         }
-        *offOut = e;
+        // The stream is set to the first query behind the run: the next run begins at lane 0 of its first block (a run that
+        // began in the middle of a block would take one batch more than its queries need -- at 66 queries per tile a third more
+        // batches).  Asked for HERE, ahead of this unit's term B, prefix sums and flush: the lines are in L2 (the block just
+        // read held them) and the loads have all of that to arrive.
+        if (e > 0) {
+            st->bpos += e;
+            st->C = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsC, lane * 4, st->bpos * 4, 0);
+            st->S = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsS, lane * 4, st->bpos * 4, 0);
+            st->E = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsE, lane * 4, st->bpos * 4, 0);
+            c_stream_issue(*st, lane);
+        }
+        *offOut = 0;
         c0 = run;
     } else {
         // the next 64 queries are on their way while these are searched (past the batch's last query: no access)
