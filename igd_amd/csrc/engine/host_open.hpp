@@ -142,7 +142,7 @@ extern "C" const char *igd_hip_last_scan_kernel(igd_hip_db *db)
     if (db && db->inner) return igd_hip_last_scan_kernel(db->inner);
     if (!db || db->epoch == 0) return "";
     if (db->lastMode == 2) return "igd_scan_tiles";
-    if (db->lastDirect) return db->lastChunks ? "igd_scan_chunks" : "igd_scan_direct";
+    if (db->lastDirect) return "igd_scan_direct";
     int32_t uns = 0;
     if (hipSetDevice(db->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
         hipMemcpy(&uns, db->d_ctl + CTL_UNSORTED, 4, hipMemcpyDeviceToHost) != hipSuccess) return "";
@@ -270,8 +270,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
         db->qbVec1 = getenv("IGD_HIP_QB_VEC1") != nullptr;
         const char *fd = getenv("IGD_HIP_DIRECT");
         db->forceDirect = fd && *fd ? atoi(fd) : -1;
-        const char *fc = getenv("IGD_HIP_CHUNKS");
-        db->chunksOn = fc && *fc ? atoi(fc) : 1;
         db->timing = tim;
     }
     db->nbp = d->nbp; db->gType = d->gType; db->nCtg = d->nCtg; db->nFiles = d->nFiles;
@@ -396,10 +394,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
             }
             db->ldsSorted = hitB + (IGD_WG_RANK / IGD_WAVE) * (IGD_WLDS_BYTES + 2 * db->sbCap);
             db->ldsDirect = hitB + (IGD_WG_DIR / IGD_WAVE) * (IGD_D_WLDS + 2 * db->sbCap);       // igd_scan_direct: the same, its waves' areas a little larger
-            // igd_scan_chunks: + the two contig tables per workgroup; it needs the array of query starts to hold a whole run
-            // (IGD_C_PASS < sbCap) and two workgroups per CU
-            db->ldsChunks = db->ldsDirect + (IGD_WG_DIR / IGD_WAVE) * 16 * IGD_C_WIN + 8 * d->nCtg;   // + a window of tileD[] per wave
-            if (db->sbCap <= IGD_C_PASS || 2 * (db->ldsChunks + 256) > 160 * 1024) db->ldsChunks = 0;
         }
         int perCU = (IGD_WPE * 256) / IGD_WG;             // IGD_WPE waves per SIMD = 4 * IGD_WPE per CU
         if (getenv("IGD_HIP_WG_PER_CU")) perCU = atoi(getenv("IGD_HIP_WG_PER_CU"));
@@ -596,10 +590,6 @@ extern "C" int igd_hip_open(const igd_hip_desc *d, int device, igd_hip_db **out)
     if (db->ldsDirect > 64 * 1024) {
         const void *dfn[] = {(const void *)igd_scan_direct<false>, (const void *)igd_scan_direct<true>};
         for (const void *fn : dfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsDirect));
-    }
-    if (db->ldsChunks > 64 * 1024) {
-        const void *cfn[] = {(const void *)igd_scan_chunks<false>, (const void *)igd_scan_chunks<true>};
-        for (const void *fn : cfn) TRYHIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, db->ldsChunks));
     }
     {   // the batch's last launch: its workgroups of 16 waves carry 16 rank-method areas (the skew valves) and the 64-bit counters
         // of the long queries' work (up to 48 KiB): beyond the 64 KiB a kernel gets without asking

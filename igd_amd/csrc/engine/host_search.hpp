@@ -232,18 +232,6 @@ __global__ void k_expand_runs(const int32_t *__restrict__ runs, int nCtg, int32_
     ichr[i] = lo;
 }
 
-// ... after the table has been checked: run starts monotone from 0 to nq (igd_hip_search_runs_dev's contract: anything else is a broken promise)
-__global__ void k_check_runs(const int32_t *__restrict__ runs, int nCtg, int nq, int32_t *__restrict__ ctl, int epoch)
-{
-    int bad = 0;
-    for (int c = threadIdx.x; c <= nCtg; c += blockDim.x) {
-        if (c < nCtg && runs[c] > runs[c + 1]) bad = 1;
-        if (c == 0 && runs[0] != 0) bad = 1;
-        if (c == nCtg && runs[c] != nq) bad = 1;
-    }
-    if (bad) { ctl[CTL_UNSORTED] = epoch; ctl[CTL_BROKEN] = epoch; }
-}
-
 static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t *d_runs, const int32_t *d_qs,
                            const int32_t *d_qe, int64_t nq, int32_t v, int rule, int flags,
                            int64_t *d_hits, int64_t *d_total, void *stream);
@@ -324,23 +312,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     const bool direct = mode == 1 && packed && db->ldsHits && db->nWin == 1 && db->v.tileD != nullptr && db->v.vshift < 0 && db->v.shift >= 0 && db->nCtg <= QB_CTG &&
                         (db->forceDirect > 0 || (db->forceDirect < 0 && (flags & IGD_HIP_FLAG_SHORT) && nq >= 28ll * db->nT));
     db->lastDirect = direct ? 1 : 0;
-    // ... and its query-partitioned form (scan_chunks.hpp): ONE kernel reads every query once -- no bounds pass, no firstQ[]
-    const bool chunks = direct && db->chunksOn && db->ldsChunks > 0 && chunks_fit(nq, db->grid, db->maxTileCnt);
-    db->lastChunks = chunks ? 1 : 0;
-    if (chunks && d_runs) {                              // (a batch given as contig runs: the kernel reads one contig number per query)
-        if (nq > db->runCap) {
-            HIPCHK(hipStreamSynchronize(st));
-            if (db->d_runIchr) (void)hipFree(db->d_runIchr);
-            db->d_runIchr = nullptr; db->runCap = 0;
-            if ((rc = dalloc(&db->d_runIchr, (size_t)nq, nullptr)) != IGD_HIP_OK) return rc;
-            db->runCap = nq;
-        }
-        k_check_runs<<<1, 256, 0, st>>>(d_runs, db->nCtg, (int)nq, db->d_ctl, db->epoch);
-        k_expand_runs<<<(int)((nq + 255) / 256), 256, 0, st>>>(d_runs, db->nCtg, db->d_runIchr, (int)nq);
-        d_ichr = db->d_runIchr;
-        d_runs = nullptr;
-    }
-    if (mode != 2 && (!chunks || db->wantFirstQ)) {
+    if (mode != 2) {
         bool vec = ((((uintptr_t)d_ichr) | ((uintptr_t)d_qs) | ((uintptr_t)d_qe)) & 15) == 0;   // our own word arrays are aligned
         if (db->qbVec1) vec = false;                  // A/B (IGD_HIP_QB_VEC1, read at open)
         const bool fast = packed && db->v.shift >= 0 && db->nCtg <= QB_CTG;
@@ -415,7 +387,7 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
     a.nq = (int)nq; a.v = v; a.rule = rule; a.epoch = db->epoch; a.mode = mode;
     a.packedWalk = packed ? (useV ? 2 : 1) : 0;
     // the skew valves ride in the batch's last launch: bit 0 bucket path, bit 1 merge join, bit 2 BIG image
-    const int valves = chunks ? 0 : direct ? 8 : (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
+    const int valves = direct ? 8 : (mode != 1 && packed && db->spShift >= 0 ? 1 : 0) | (mode != 2 && packed ? 2 : 0) |
                        (db->bigImage || db->nRec + IGD_CHUNK >= (1ll << 30) ? 4 : 0);
     // (the valve's slices of IGD_HEAVY_SLICE queries are beyond any LDS array of query starts: its waves get none)
     const size_t tailWave = direct ? (size_t)IGD_D_WLDS : (size_t)IGD_WLDS_BYTES;                    // a wave's rank-method area in the last launch
@@ -432,17 +404,11 @@ static int search_dev_impl(igd_hip_db *db, const int32_t *d_ichr, const int32_t 
             if (extEv) { db->evStart = db->ev[4 * slot + 1]; db->evStop = db->ev[4 * slot + 2]; }
             if (direct) {
                 DirK D;
-                D.a.q_ichr = d_ichr; D.a.zeroHits = chunks && !db->wantFirstQ ? zh : nullptr; D.a.zeroTotal = chunks && !db->wantFirstQ ? zt : nullptr;
                 D.db = db->v;
                 D.a.firstQ = db->d_firstQ; D.a.tileD = db->v.tileD; D.a.q_qs = d_qs; D.a.q_qe = d_qe; D.a.ctl = db->d_ctl; D.a.fix = db->d_fix;
                 D.a.heavyS = db->d_heavy + IGD_HEAVY_MAX; D.a.farList = db->d_far; D.a.nq = (int)nq; D.a.v = v; D.a.epoch = db->epoch;
                 D.a.rule = rule; D.a.promised = 1; D.a.sbCap = db->sbCap; D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap;
                 D.a.out = db->d_slab; D.a.hitsOut = (u64 *)d_hits; D.a.totalOut = (u64 *)d_total;
-                if (chunks) {
-                    D.a.wldsBytes = IGD_D_WLDS + 2 * db->sbCap + 16 * IGD_C_WIN;
-                    if (useV) launch_sorted(db, igd_scan_chunks<true>, db->grid, IGD_WG_DIR, (size_t)db->ldsChunks, st, D);
-                    else launch_sorted(db, igd_scan_chunks<false>, db->grid, IGD_WG_DIR, (size_t)db->ldsChunks, st, D);
-                } else
                 if (useV) launch_sorted(db, igd_scan_direct<true>, db->grid, IGD_WG_DIR, (size_t)db->ldsDirect, st, D);
                 else launch_sorted(db, igd_scan_direct<false>, db->grid, IGD_WG_DIR, (size_t)db->ldsDirect, st, D);
             } else

@@ -88,9 +88,7 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
     (void)hipMemsetAsync(d_h, 0, ((size_t)db->nFiles + 1) * 8, st);
     const bool saved = db->evOn;
     db->evOn = false;
-    db->wantFirstQ = true;                               // (the query-partitioned DIRECT step makes no firstQ[]: the bounds pass runs for this count)
     rc = igd_hip_search_dev(db, d_ichr, d_qs, d_qe, nq, v, rule, flags & ~IGD_HIP_FLAG_ZERO_FIRST, d_h, nullptr, st);
-    db->wantFirstQ = false;
     db->evOn = saved;
     int32_t ctl[4] = {0, 0, 0, 0};
     hipError_t e = hipStreamSynchronize(st);
@@ -115,8 +113,6 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
         out->record_bytes = (int64_t)acc[1] * recB;
         out->unit_bytes = (int64_t)sizeof(Unit) * db->nUnits + (path == 2 ? 8ll * (db->nT + 1) : sortedPath ? 4ll * (db->nT + 1) : 8ll * db->nT);
         if (direct) out->unit_bytes = (int64_t)(sizeof(Unit) + 8 + 16) * db->nUnits;      // per unit: its descriptor, two entries of firstQ[], its tile's int4 of tileD[]
-        const bool chunked = direct && db->lastChunks != 0;
-        if (chunked) out->unit_bytes = 16ll * (int64_t)acc[0];   // igd_scan_chunks: one int4 of tileD[] per visited tile (charged per visited unit; no unit descriptors are read)
         // merge join, compact image: one 4-byte word per query (qw0), the compacted later-tile words (later[]: every entry is
         // read at least once), the starts (q_qs) of the tiles the rank method handles; exact arrays: qw, qs, qe;
         // bucket path: 8 B per pair
@@ -127,8 +123,7 @@ extern "C" int igd_hip_batch_traffic(igd_hip_db *db, const int32_t *d_ichr, cons
             e = hipMemcpy(hdr.data(), db->d_laterHdr, (size_t)nb * 8, hipMemcpyDeviceToHost);
             for (int64_t b = 0; b < nb; b++) nLaterWords += hdr[(size_t)b * 2];
         }
-        out->query_bytes = chunked ? 8ll * nq + 4ll * (int64_t)acc[3]       // contig and start of every query once, the end of those a tile owns
-                         : direct ? 8ll * (int64_t)acc[3] : path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
+        out->query_bytes = direct ? 8ll * (int64_t)acc[3] : path == 2 ? 4ll * nq + 4ll * nLaterWords + 4ll * (int64_t)acc[3]
                          : path == 1 ? 12ll * nq : 8ll * (int64_t)acc[2];
         out->slab_bytes = db->ldsHits ? (int64_t)db->grid * db->nFiles * (path == 2 ? 4 : 8) : 8ll * db->nFiles;   // (merge join: 32-bit rows)
         out->total = out->record_bytes + out->unit_bytes + out->query_bytes + out->slab_bytes;

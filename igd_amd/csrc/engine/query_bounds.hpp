@@ -71,8 +71,13 @@ __device__ __forceinline__ bool query_span(const DbView &db, int c, int qs, int 
 #define IGD_HEAVY_MAX 4096     // listed heavy tiles per batch (a further one stays with its own wave)
 #define CTL_NHEAVYS 12   // + (epoch & 1): tiles listed for heavy_sorted_body (merge join)
 #define CTL_NFAR 14      // + (epoch & 1): units the lean build of igd_scan_sorted leaves to far_units_body
-#define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of 4096
-#define IGD_HEAVY_SLICE 4096
+#define IGD_HEAVY_FIRST 8192   // merge join: a tile with more first-tile queries than this is shared out in slices of IGD_HEAVY_SLICE
+// One slice = one wave's work in the batch's last launch: its batches of 64 queries one after the other, each a memory round
+// trip with nothing else on the CU to hide it.  Slices of 4096 (until round 5) left 10^6 queries inside ONE tile to 244 waves
+// of 64 batches each -- 130 us on an otherwise idle chip; slices of 512 are 1953 waves of 8 batches (round 6).
+#ifndef IGD_HEAVY_SLICE
+#define IGD_HEAVY_SLICE 512
+#endif
 #ifndef IGD_FAR_SLICES
 #define IGD_FAR_SLICES 1024    // far_units_body: at most this many slices per listed unit
 #endif

@@ -45,8 +45,7 @@
 
 // Per tile, built at open (k_tile_desc): x = index of the first record that STARTS in tile t+1 (its records from number
 // `pre` on), y = how many of them ride along (<= IGD_D_APP) | (there are more) << 7 | (tile t+1 exists in the contig) << 8
-// | min(rem, 15) << 9 | contig << 13 with rem = (last tile of the contig) - (this tile's number in it); z = index of the tile's
-// first record (low 32 bits), w = the tile's record count -- what igd_scan_chunks builds a unit's descriptor from.
+// | min(w, 15) << 9 | contig << 13, z = contig, w = (last tile of the contig) - (this tile's number in it).
 __global__ void k_tile_desc(DbView db, int4 *__restrict__ out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,7 +66,6 @@ __global__ void k_tile_desc(DbView db, int4 *__restrict__ out)
         d.y = (cnt < IGD_D_APP ? cnt : IGD_D_APP) | (cnt > IGD_D_APP ? 128 : 0) | 256;
     }
     d.y |= ((rem < 15 ? rem : 15) << 9) | (lo << 13);      // what the scan keeps per unit: one word (nCtg <= 1024)
-    d.z = (int)db.tileOff[t]; d.w = db.tileCnt[t];
     out[t] = d;
 }
 
@@ -75,8 +73,6 @@ struct DirArgs {
     const int32_t *firstQ;       // [nT + 1] (k_query_bounds<.., BONLY>)
     const int4 *tileD;           // [nT] (k_tile_desc)
     const int32_t *q_qs, *q_qe;
-    const int32_t *q_ichr;       // igd_scan_chunks: the queries' contig numbers (the round-5 kernel never reads them)
-    u64 *zeroHits, *zeroTotal;   // igd_scan_chunks under IGD_HIP_FLAG_ZERO_FIRST: the caller's hits[] / total, cleared by the batch's first kernel
     int32_t *ctl;
     int2 *fix;                   // the batch's exact-walk list (CTL_NFIX)
     int32_t *heavyS, *farList;   // tiles with more than IGD_HEAVY_FIRST queries / units that could overflow a 32-bit counter: the batch's last launch
@@ -197,41 +193,13 @@ __device__ __forceinline__ void d_walk_exact(const DbView &db, const DirArgs &a,
 // atomics (the batch's last launch: slices of very dense tiles, units that could overflow a 32-bit counter), else to the
 // workgroup's 32-bit LDS counters.  prevQ: the start of the query before f0 when that one belongs to the same tile's range
 // (a slice), else INT_MIN.
-// igd_scan_chunks' query stream: the wave's queries in blocks of 64 (contig, start, end of query bpos + lane), the next block in flight
-struct CStream {
-    int bpos;
-    int C, S, E, Cn, Sn, En;
-    __amdgpu_buffer_rsrc_t rsC, rsS, rsE;
-};
-__device__ __forceinline__ void c_stream_issue(CStream &st, int lane)
+template <bool USE_V, bool GLOBAL, bool KA>
+__device__ __forceinline__ void d_compute(const DbView &db, const DirArgs &a, const DRegs &L, int kk, int lane, DRaw &R, unsigned int *hits32,
+                                          unsigned short *sl, unsigned int *hist, unsigned short *sb, int prevQ, bool *appDirty)
 {
-    st.Cn = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsC, lane * 4, (st.bpos + IGD_WAVE) * 4, 0);
-    st.Sn = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsS, lane * 4, (st.bpos + IGD_WAVE) * 4, 0);
-    st.En = (int)__builtin_amdgcn_raw_buffer_load_b32(st.rsE, lane * 4, (st.bpos + IGD_WAVE) * 4, 0);
-}
-__device__ __forceinline__ void c_stream_advance(CStream &st, int lane)
-{
-    st.bpos += IGD_WAVE;
-    st.C = st.Cn; st.S = st.Sn; st.E = st.En;
-    c_stream_issue(st, lane);
-}
-#define IGD_C_PASS 960          // igd_scan_chunks: queries of one tile counted in one go (< the LDS array of query starts: sbCap = 1024)
-
-// CHK: the order of the starts is verified here (igd_scan_direct's first units).
-// STREAM (igd_scan_chunks, a tile's first unit): the tile's queries are not a known range [f0, f0 + c0) but whatever the wave's
-// query stream holds from lane `off` of its current block on: the run of queries that belong to the tile -- contig ctgS, start
-// in the tiles tlo .. thi of it (the contig's first / last tile also own what lies before / behind, :459-464) -- up to the wave's
-// border qEnd and IGD_C_PASS queries; the stream is left at the first query behind the run (*offOut = its lane).  Returns the
-// number of queries counted.
-template <bool USE_V, bool GLOBAL, bool KA, bool CHK = true, bool STREAM = false>
-__device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, const DRegs &L, int kk, int lane, DRaw &R, unsigned int *hits32,
-                                         unsigned short *sl, unsigned int *hist, unsigned short *sb, int prevQ, bool *appDirty,
-                                         CStream *st = nullptr, int off = 0, int qEnd = 0, int ctgS = 0, int tlo = 0, int thi = 0, int *offOut = nullptr,
-                                         int *lastSOut = nullptr)
-{
-    int c0 = STREAM ? 1 : R.c0;
-    if (c0 <= 0) return 0;
-    const int un = R.n, f0 = STREAM ? st->bpos + off : R.f0, jf = __builtin_amdgcn_readlane(L.jf, kk);
+    const int c0 = R.c0;
+    if (c0 <= 0) return;
+    const int un = R.n, f0 = R.f0, jf = __builtin_amdgcn_readlane(L.jf, kk);
     const int meta = __builtin_amdgcn_readlane(L.appMeta, kk);
     const int W = db.nbp, sh = db.shift;
     const int j = jf >> 4;
@@ -242,8 +210,8 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
     int rem = (meta >> 9) & 15;                          // tiles left in the contig behind this one, capped at 15 ...
     if (rem == 15) rem = DD(ctgNTile)[ctg] - 1 - j;      // ... the true number where it matters (a query of 16+ tiles)
     const bool dead = a.rule == IGD_HIP_RULE_NEST && un == 0;       // (:468; every unit of an empty tile is its placeholder)
-    if (!first && un == 0) return 0;
-    if (!first && dead) return 0;
+    if (!first && un == 0) return;
+    if (!first && dead) return;
     int cnt[IGD_SLOTS + 1];
 #pragma unroll
     for (int r = 0; r <= IGD_SLOTS; r++) cnt[r] = 0;
@@ -275,7 +243,7 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
     // there are and tile t+1 is the contig's last, whatever its end: n2 is clamped, :463)
     const int dlim = !first ? INT_MAX : (rem == 0 || dead) ? INT_MAX : appMore ? covKey - 1 : rem == 1 ? INT_MAX : 2 * W;
     const int capF = push ? 2 * W : W;                   // the usual batch's keys: min(d, capF) + 1
-    const bool inLds = STREAM || c0 < a.sbCap;
+    const bool inLds = c0 < a.sbCap;
     int nFirst = 0, nBack = 0;
     bool disorder = false;
     int carryQ = prevQ;
@@ -286,17 +254,18 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
     // One batch of 64 queries.  (A lambda called for the first batch in straight-line code and for the others in a loop: a
     // load inside a loop makes the compiler wait for ALL loads in flight at the loop's head -- the NEXT unit's records, just
     // issued, included -- so a first batch inside the loop made every unit wait out a memory round trip: 233 against 150 us.)
-    auto batch = [&](const int p, const int qs_, const int qe_, const bool there) {
+    auto batch = [&](const int p, const int qs_, const int qe_) {
         const int idx = p + lane;
         const int a_ = qs_ - T0, d_ = qe_ - T0;
-        if (CHK && !STREAM && first && !(IGD_D_EXP & 16)) {   // the order of the starts, where they are read
+        if (first && !(IGD_D_EXP & 16)) {                // the order of the starts, where they are read
             // lane i gets lane i-1's start, lane 0 keeps the last start of the batch before (DPP wave_shr:1 -- one instruction)
             const int pq = __builtin_amdgcn_update_dpp(carryQ, qs_, 0x138, 0xf, 0xf, false);
-            disorder = disorder || (there && qs_ < pq);
+            disorder = disorder || (idx < c0 && qs_ < pq);
             carryQ = __builtin_amdgcn_readlane(qs_, IGD_WAVE - 1);
         }
         // ---- the usual batch: queries of this tile, none inverted, that end inside it or are served by the records that ride
         // along -- nothing to mask or list ----
+        const bool there = idx < c0;
         if (__ballot(there && !((unsigned)a_ < (unsigned)W && d_ >= (a_ > 1 ? a_ : 1) && d_ <= dlim)) == 0ull) {
             if (rankAny) {
                 const int pos = (IGD_D_EXP & 2) ? (d_ & 255) : lds_lower_bound(sl, (d_ < capF ? d_ : capF) + 1);
@@ -400,60 +369,20 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
         }
         if (inLds && there) sb[idx] = (unsigned short)(inTile ? (qs1 > 65535 ? 65535 : qs1) : (front ? 1 : 65535));
     };
-    if constexpr (STREAM) {
-        // the run of the tile's queries, block by block from the wave's stream.  (The first block in straight-line code: a load
-        // inside a loop makes the compiler wait for everything in flight at the loop's head -- the next tile's records included.)
-        const int sh_ = db.shift;
-        int run = 0, carryS = INT_MIN;
-        auto block = [&](const int lo) -> int {
-            const int qs_ = st->S, qe_ = st->E;
-            const int t_ = tile_shift(qs_, sh_);
-            const bool mine = lane >= lo && st->bpos + lane < qEnd && run + (lane - lo) < IGD_C_PASS && st->C == ctgS && t_ >= tlo && t_ <= thi;
-            const unsigned long long nm = __ballot(lane >= lo && !mine);
-            const int e = nm ? __builtin_ctzll(nm) : IGD_WAVE;
-            const bool there = lane >= lo && lane < e;
-            // inside the run the starts never decrease (lane i against lane i - 1, lane 0 against the block before)
-            const int pq = __builtin_amdgcn_update_dpp(carryS, qs_, 0x138, 0xf, 0xf, false);
-            disorder = disorder || (there && run + (lane - lo) > 0 && qs_ < pq);
-            batch(run - lo, qs_, qe_, there);
-            run += e - lo;
-            if (e > lo) *lastSOut = __builtin_amdgcn_readlane(qs_, e - 1);   // (the run's last start so far: the seam of a tile that goes on)
-            carryS = __builtin_amdgcn_readlane(qs_, IGD_WAVE - 1);
-            return e;
-        };
-        int e = block(off);
-        while (e == IGD_WAVE) {
-            c_stream_advance(*st, lane);
-            e = block(0);
-        }
-        // The stream is set to the first query behind the run: the next run begins at lane 0 of its first block (a run that
-        // began in the middle of a block would take one batch more than its queries need -- at 66 queries per tile a third more
-        // batches).  Asked for HERE, ahead of this unit's term B, prefix sums and flush: the lines are in L2 (the block just
-        // read held them) and the loads have all of that to arrive.
-        if (e > 0) {
-            st->bpos += e;
-            st->C = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsC, lane * 4, st->bpos * 4, 0);
-            st->S = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsS, lane * 4, st->bpos * 4, 0);
-            st->E = (int)__builtin_amdgcn_raw_buffer_load_b32(st->rsE, lane * 4, st->bpos * 4, 0);
-            c_stream_issue(*st, lane);
-        }
-        *offOut = 0;
-        c0 = run;
-    } else {
+    {
         // the next 64 queries are on their way while these are searched (past the batch's last query: no access)
         int qsN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + IGD_WAVE) * 4, 0);
         int qeN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, (f0 + IGD_WAVE) * 4, 0);
-        batch(0, R.qs, R.qe, lane < c0);
+        batch(0, R.qs, R.qe);
         for (int p = IGD_WAVE; p < c0; p += IGD_WAVE) {
             const int qs_ = qsN, qe_ = qeN;
             qsN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsS, vo4, (f0 + p + IGD_WAVE) * 4, 0);
             qeN = (int)__builtin_amdgcn_raw_buffer_load_b32(rsE, vo4, (f0 + p + IGD_WAVE) * 4, 0);
-            batch(p, qs_, qe_, p + lane < c0);
+            batch(p, qs_, qe_);
         }
     }
     if (__ballot(disorder)) d_mark_broken<KA>(a, lane);
-    if (c0 <= 0) return 0;                               // (STREAM: nothing of the stream belonged to the tile -- nothing was staged or counted)
-    if (un == 0 && !push) return c0;                     // (a placeholder that had nothing to push: it only checked its queries)
+    if (un == 0 && !push) return;                        // (a placeholder that had nothing to push: it only checked its queries)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // term B: #{q of this tile: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
@@ -538,7 +467,6 @@ __device__ __forceinline__ int d_compute(const DbView &db, const DirArgs &a, con
             if (cnt[r]) atomicAdd(hits32 + X[r], (unsigned)cnt[r]);
         }
     }
-    return c0;
 }
 
 // The DIRECT scan kernel: 2 workgroups of 12 waves per CU (6 waves per SIMD, like the full build of igd_scan_sorted).

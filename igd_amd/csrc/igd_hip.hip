@@ -282,10 +282,6 @@ struct igd_hip_db {
     int4 *d_tileD;                // DbView::tileD
     uint32_t *d_tileBits;         // DbView::tileBits
     int ldsDirect;                // dynamic LDS of igd_scan_direct
-    int ldsChunks;                // dynamic LDS of igd_scan_chunks (0: the query-partitioned DIRECT step is not available for this database)
-    int chunksOn;                 // IGD_HIP_CHUNKS at open (A/B): 0 = round 5's DIRECT step (bounds pass + igd_scan_direct)
-    int lastChunks;               // ... in its query-partitioned form (igd_scan_chunks)
-    bool wantFirstQ;              // instrumentation (igd_hip_batch_traffic): the DIRECT step also fills firstQ[] (the bounds pass igd_scan_chunks does without)
     int lastDirect;               // the last batch took the DIRECT step (igd_hip_last_scan_kernel)
     bool bigImage;                // the compact image is addressed with per-unit 64-bit bases (>= 2^30 tile records; IGD_HIP_BIG=1 at open: tests)
     bool qbVec1, timing;          // IGD_HIP_QB_VEC1 (A/B), IGD_TIMING at open: no getenv on the per-batch path
@@ -341,8 +337,7 @@ struct igd_hip_db {
 #include "engine/compact_image.hpp"   // k_pack_units: the 6-byte tile-relative image and its unit descriptors
 #include "engine/scan_tiles.hpp"      // igd_scan_tiles (bucket path) and its skew valve
 #include "engine/scan_sorted.hpp"     // igd_scan_sorted: the merge join (pairwise and rank builds) -- the dominant kernel
-#include "engine/scan_direct.hpp"     // dense sorted batches without a per-query pre-pass: the rank method fed by q_qs / q_qe (d_compute), igd_scan_direct
-#include "engine/scan_chunks.hpp"     // ... query-partitioned: igd_scan_chunks reads every query once, no pre-pass at all (round 6)
+#include "engine/scan_direct.hpp"     // dense sorted batches without a per-query pre-pass: k_tile_bounds, igd_scan_direct
 #include "engine/tail.hpp"            // exact walks, coverage, k_reduce_slabs (last launch of a batch), k_sum_hits
 #include "engine/enumerate_dev.hpp"   // `-f` enumeration kernels
 #include "engine/hitmap_dev.hpp"      // `-m` hit map kernel
