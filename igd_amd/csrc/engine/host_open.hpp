@@ -31,43 +31,6 @@ static int dalloc(T **p, size_t n, int64_t *acct)
 extern "C" void igd_hip_close(igd_hip_db *db)
 {
     if (!db) return;
-#if IGD_EXP & 1024
-    {
-        u64 h[8];
-        (void)hipDeviceSynchronize();
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(d_sect), sizeof h) == hipSuccess)
-            fprintf(stderr, "[igd sect] stage %.3f  A %.3f  later %.3f  B %.3f  prefix %.3f  of the waves' time in the unit loop (%llu ticks)\n",
-                    (double)h[0] / h[5], (double)h[1] / h[5], (double)h[2] / h[5], (double)h[3] / h[5], (double)h[4] / h[5], (unsigned long long)h[5]);
-        fprintf(stderr, "[igd sect] waiting for records %.3f, compare phases of all visited units %.3f\n", (double)h[6] / h[5], (double)h[7] / h[5]);
-    }
-#endif
-#if IGD_EXP & 0x1000000
-    {
-        std::vector<u64> h((size_t)8192 * 8);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(d_qbSt), h.size() * 8);
-        FILE *f = fopen("gpurun_out/qb_stamps.bin", "wb");
-        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-    }
-#endif
-#if IGD_EXP & 0x400000
-    {
-        std::vector<u64> h((size_t)16384 * 5);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(d_tailSt), h.size() * 8);
-        FILE *f = fopen("gpurun_out/tail_stamps.bin", "wb");
-        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-    }
-#endif
-#if IGD_EXP & 32
-    if (g_stamps) {
-        std::vector<u64> h((size_t)g_stampWaves * 5);
-        (void)hipDeviceSynchronize();
-        (void)hipMemcpy(h.data(), g_stamps, h.size() * 8, hipMemcpyDeviceToHost);
-        FILE *f = fopen("gpurun_out/stamps.bin", "wb");
-        if (f) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
-    }
-#endif
     if (t_arenaOwner == db) t_arenaOwner = nullptr;
     if (db->inner) { igd_hip_close(db->inner); db->inner = nullptr; }
     (void)hipSetDevice(db->device);

@@ -132,15 +132,6 @@ static SortK make_sortk(igd_hip_db *db, const ScanArgs &a)
     sa.nq = a.nq; sa.v = a.v; sa.epoch = a.epoch; sa.mode = a.mode; sa.out = a.out; sa.rule = a.rule;
     sa.sbCap = db->sbCap; sa.wldsBytes = IGD_WLDS_BYTES + 2 * db->sbCap;
     sa.ctlw = db->d_ctl; sa.heavyS = db->d_heavy + IGD_HEAVY_MAX; sa.farList = db->d_far; sa.tailHistOff = -1; sa.noList = 0;
-    sa.stamps = nullptr;
-#if IGD_EXP & 32
-    {   // diagnostic build: the LAST launch's stamps are dumped by igd_hip_close (gpurun_out/stamps.bin)
-        static u64 *d_st = nullptr;
-        if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)db->grid * (IGD_WG / IGD_WAVE) * 5 * 8);
-        sa.stamps = d_st;
-        g_stamps = d_st; g_stampWaves = db->grid * (IGD_WG / IGD_WAVE);
-    }
-#endif
     SortK K;
     K.db = db->v; K.a = sa; K.hitsOut = (u64 *)a.hitsOut; K.totalOut = a.total;
     return K;

@@ -208,7 +208,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                                                       int32_t *__restrict__ spill, int2 *__restrict__ laterHdr, int promised)
 {
     constexpr int NW = WGT / IGD_WAVE;
-    IGD_QSTAMP(0);
     const bool vnest = (rule >> 8) & 1;                   // a re-tiled copy (DbView::vshift): rule NEST of the call, applied to the FILE's tiles
     rule &= 0xff;
     // The thread's queries (and the one before them) first: their loads are in flight while the tables below are staged
@@ -284,11 +283,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         }
     } else
     __syncthreads();
-    IGD_QSTAMP(1);
-#if IGD_EXP & 0x1000000
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IGD_QSTAMP(2);                                        // the thread's queries have arrived
-#endif
     // contig of query i: the number of run starts 1..nCtg that are <= i (an empty run shares its start with the next one)
     auto contig_of = [&](int i) -> int {
         int pos = 0;                                      // entries sRun[1..] taken so far
@@ -526,7 +520,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
 #undef QB_BASE
 #undef QB_NTILE
 #undef QB_TILE
-    IGD_QSTAMP(3);                                        // keys and words done
     // 4. the workgroup's later-tile words are compacted in query order into its block of later[]: position of each
     // query's (possible) entry = entries of the queries before it in the block.  (A wave that left above is not waited
     // for by the barrier -- and nothing of an unordered batch's block is read.)
@@ -595,7 +588,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         }
         if (threadIdx.x == 0) laterHdr[blockIdx.x] = make_int2(total, 0);
     }
-    IGD_QSTAMP(4);                                        // later[] compacted
     // 5. firstQ (+ lpos): short gaps by the owner, long gaps by the whole wave.  In an ordered batch the gaps add up
     // to at most nT entries; an unordered one would make them add up to nq * nT / 2.  Long gaps are
     // therefore charged to a budget (ctl[CTL_BUDGET + parity], zeroed by the previous batch) and
@@ -648,7 +640,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
                 if (i0 + v < nq) qw0[i0 + v] = w0v[v];
         }
     } else if (i0 < nq) qw0[i0] = w0v[0];
-    IGD_QSTAMP(5);                                        // firstQ filled, qw0 stored
     // head and tail of firstQ[] -- the tiles up to the first query's key and after the last one's, together all the
     // tiles a batch does not reach (7/8 of them for one GPU's slab of an 8-GPU job) -- are filled by the whole grid:
     // left to the first / last query's own wave they took longer than everything else in this kernel.  lpos[] of the
@@ -674,10 +665,6 @@ __global__ __launch_bounds__(WGT, WGT == 256 ? 7 : (FAST ? 8 : 4)) void k_query_
         if (!BONLY && (int)blockIdx.x == (nq - 1) / (WGT * VEC) && (int)threadIdx.x < IGD_SHORT_TILES - 1 && kl + 1 + (int)threadIdx.x <= db.nT)
             lpos[kl + 1 + threadIdx.x] = (nq % (WGT * VEC)) != 0 ? total : 0;
     }
-#if IGD_EXP & 0x1000000
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IGD_QSTAMP(6);                                        // stores drained
-#endif
 }
 
 // Bucket path (any query order).  `gate`: 0 = always run; otherwise run only when

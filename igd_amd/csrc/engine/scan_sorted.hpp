@@ -49,7 +49,6 @@ struct SortArgs {
     int noList;                  // a later pass of a windowed batch: heavy tiles and far units are left out as in the first pass, which listed them
     int tailHistOff;             // the last launch's per-workgroup u64 counters for exact walks and coverage: byte offset in its dynamic LDS (< 0: none)
     u64 *out;                    // slab [grid][nFiles] (LDS counters) or the global hits[]
-    u64 *stamps;                 // IGD_EXP & 32 (diagnostic build): 4 s_memtime stamps per wave
 };
 
 // The two merge-join kernels take ONE argument struct, and read everything their inner loop does not need -- a dozen
@@ -317,9 +316,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                                           u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u)
 {
     const int c0 = R.c0, ln = R.ln;
-#if IGD_EXP & 1024
-    const u64 t_unit = __builtin_amdgcn_s_memtime();
-#endif
     const int un = R.n;
     if (un == 0) return;                                 // placeholder of an empty tile, or nobody asks about this unit (s_issue: n = 0 then)
     const int f0 = R.f0;
@@ -396,11 +392,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         }
     } else {
         // ---- rank ---------------------------------------------------------------------------------
-#if IGD_EXP & 1024
-        u64 tsec = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        SECT(5);                                         // waiting for the unit's records
-#endif
 #define IGD_TILE_START ((int)((unsigned)(__builtin_amdgcn_readlane(L.jf, kk) >> 4) * (unsigned)db.nbp))   /* only the seldom-taken branches need it */
 #pragma unroll
         for (int r = 0; r < IGD_SLOTS; r++)
@@ -409,7 +400,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
         __builtin_amdgcn_wave_barrier();
         const bool inLds = c0 < a.sbCap;           // the tile's query starts fit the wave's LDS array (a power of two)
         int nFirst = 0;
-        SECT(0);
         // One batch of <= 64 entries of the candidate list, entry p + lane in each lane: word w for a first-tile query
         // (IGD_NEVER where the lane has none), later[] entry e for a later-tile one (first batch only: WITH_LATER).
         // Term A: every covering query bisects the unit's starts with its end and adds 1 to the histogram there.
@@ -498,7 +488,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             }
             if (p < nE) batchA(wn, 0, p, false);
         }
-        SECT(1);
         if (far)
             far_later<true>(a, __builtin_amdgcn_readlane(L.la, kk), ln, f0, lane, [&](int e) {
                 bool covers;
@@ -513,7 +502,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             });
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        SECT(2);
         // term B: #{first-tile q: qs' > e'} = c0 - #{qs' <= e'}: every record bisects the tile's ordered query starts
         {
             const int levels = 32 - __builtin_clz((unsigned)c0), top = 1 << levels;   // top = 2^levels > c0 >= IGD_DENSE_MIN, c0 < 2^30
@@ -579,7 +567,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
                 for (int r = 0; r < IGD_SLOTS; r++) cnt[r] -= c0 - pos[r];
             }
         }
-        SECT(3);
         // term A: #{q: p_q <= i} = inclusive prefix sum of the histogram over the record positions
         int carry = 0;
 #pragma unroll
@@ -593,7 +580,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (R.a[r] == 0u || !keep[r]) cnt[r] = 0;    // no record here (loads past the unit's end return 0; a record word has e' >= 1) / fails the value filter
         }
         if (lane == 0) hist[IGD_SLOTS * IGD_WAVE] = 0u;  // p = 320: queries beyond every record of a full unit
-        SECT(4);
 #undef IGD_TILE_START
     }
     // CNT32 (the workgroup's LDS counters are 32-bit): one 32-bit LDS atomic per slot, for all lanes -- a lane without
@@ -665,9 +651,6 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             if (c) atomicAdd((u64 *)((char *)gh + ((size_t)R.x[r] << 3)), (u64)(unsigned)c);
         }
     }
-#if IGD_EXP & 1024
-    if (lane == 0) atomicAdd(&hist[321 + 6], (unsigned)(__builtin_amdgcn_s_memtime() - t_unit));   // all of the unit's compare phase
-#endif
     if (found) {                                         // skew valve: the batch total is kept by the caller of this unit
         int t = 0;
 #pragma unroll
@@ -826,13 +809,6 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
     Raw2 A, B;
     unsigned spent = 0u;                                 // CNT32: what this wave's units may have added to any one LDS counter
     const unsigned budget = 0xFFFFFFFFu / (unsigned)(WGT / IGD_WAVE);
-#if IGD_EXP & 1024
-    const u64 t_kernel = __builtin_amdgcn_s_memtime();
-#endif
-#if IGD_EXP & 32
-    const u64 t_start = __builtin_amdgcn_s_memtime();
-    u64 t_desc = 0, t_first = 0;
-#endif
     // Issue slots go to the OLDEST wave of a SIMD first: left alone, the eight waves of a SIMD finish their equal
     // shares one after the other (the first in 63 % of the last one's time, measured) and the SIMD runs ever emptier
     // towards the end.  Every wave therefore lowers its own priority as it gets through its share -- a wave that is
@@ -894,9 +870,6 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
         }
         int cntU = (int)(((long long)db.nUnits - ub + nwaves - 1) / nwaves);
         if (cntU > IGD_ROUND) cntU = IGD_ROUND;
-#if IGD_EXP & 32
-        if (ub == gwave) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(L.f0), "v"(L.c0), "v"(L.ln)); t_desc = __builtin_amdgcn_s_memtime(); }
-#endif
         // (the lean build: when more than a quarter of the round's units hold no record or are asked about by nobody -- a database
         // with empty tiles -- it steps through the others only, like the full build; its own loop below takes every unit in turn
         // with nothing to find out per unit, which is what a round of visited units wants)
@@ -944,9 +917,6 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
         s_issue<USE_V, BIG, !RANK>(db, a, L, 0, true, lane, A);
         for (int kk = 0; kk < cntU; kk += 2) {
             s_issue<USE_V, BIG, !RANK>(db, a, L, kk + 1, kk + 1 < cntU, lane, B);
-#if IGD_EXP & 32
-            if (ub == gwave && kk == 0) { asm volatile("s_waitcnt vmcnt(0)" ::"v"(A.a[0]), "v"(A.x[0])); t_first = __builtin_amdgcn_s_memtime(); }
-#endif
             IGD_UNIT(kk, A);
             s_issue<USE_V, BIG, !RANK>(db, a, L, kk + 2, kk + 2 < cntU, lane, A);
             if (kk + 1 < cntU) IGD_UNIT(kk + 1, B);
@@ -962,15 +932,6 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
 #endif
         }
     }
-#if IGD_EXP & 32
-    const u64 t_loop = __builtin_amdgcn_s_memtime();
-#endif
-#if IGD_EXP & 1024
-    if (RANK && lane < 5) atomicAdd(&d_sect[lane], (u64)hist[321 + lane]);
-    if (RANK && lane == 6) atomicAdd(&d_sect[6], (u64)hist[321 + 5]);
-    if (RANK && lane == 7) atomicAdd(&d_sect[7], (u64)hist[321 + 6]);
-    if (RANK && lane == 5) atomicAdd(&d_sect[5], __builtin_amdgcn_s_memtime() - t_kernel);
-#endif
     if (LDS_HITS) {
         __syncthreads();
         const int nFiles = KARG(db.nFiles);
@@ -980,12 +941,6 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
             for (int f = threadIdx.x; f < nFiles; f += WGT) row32[f] = ((unsigned int *)hits)[f];
         } else for (int f = threadIdx.x; f < nFiles; f += WGT) row[f] = hits[f];
     }
-#if IGD_EXP & 32
-    if (KARG(a.stamps) && lane == 0) {
-        u64 *o = KARG(a.stamps) + (size_t)gwave * 5;
-        o[0] = t_start; o[1] = t_desc; o[2] = t_first; o[3] = t_loop; o[4] = __builtin_amdgcn_s_memtime();
-    }
-#endif
 }
 
 #undef IGD_UNIT

@@ -61,7 +61,6 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         }
     }
     if (gate != 0 && __builtin_amdgcn_readfirstlane(ctl[CTL_UNSORTED]) != gate) return;
-    IGD_QSTAMP(0);                                        // (diagnostic build -DIGD_EXP=0x1000000: tools/sp_stamps.py)
     __shared__ uint32_t hist[SP_MAXC], wsum[SP_WG / IGD_WAVE];
     uint32_t *cur = hist;                                 // (a bucket's count is read, then its cursor written, by the one thread that owns the bucket)
     for (int b = threadIdx.x; b < nCoarse; b += SP_WG) hist[b] = 0;
@@ -83,7 +82,6 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
     for (int w = threadIdx.x; w < bitsWords; w += SP_WG) sl_bits[w] = db.tileBits[w];
     for (int c = threadIdx.x; c < ctgStaged; c += SP_WG) { sCtgN[c] = db.ctgNTile[c]; sCtgB[c] = db.ctgBase[c]; }
     __syncthreads();
-    IGD_QSTAMP(1);
     auto has_records = [&](int t) -> bool { return bitsWords ? ((sl_bits[t >> 5] >> (t & 31)) & 1u) != 0u : db.tileCnt[t] > 0; };
     // (query_span's last test -- rule NEST: an empty first tile ends the query, :468 -- is made here, from the bits)
     const int spanRule = (rule & ~0xff) | IGD_HIP_RULE_FLAT;
@@ -148,9 +146,7 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
             }
         }
     }
-    IGD_QSTAMP(2);                                        // wave 0 has counted its pairs
     __syncthreads();
-    IGD_QSTAMP(3);                                        // ... and every wave
     {   // exclusive prefix over the buckets: thread t owns buckets 4t .. 4t+3 (SP_MAXC = 4 * SP_WG)
         const int b0 = threadIdx.x * (SP_MAXC / SP_WG);
         uint32_t c[SP_MAXC / SP_WG], sum = 0;
@@ -177,7 +173,6 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         }
     }
     __syncthreads();
-    IGD_QSTAMP(4);                                        // table row written, cursors set
     const size_t rb = (size_t)blockIdx.x * SP_CAP;
     // The tuples go to their places in the workgroup's region -- grouped by bucket, i.e. 64 lanes to 64 places: a store
     // instruction of 64 separate 12-byte pieces, 16 000 of them per 10^6 queries, was a third of this kernel.  The region is
@@ -221,11 +216,6 @@ __global__ __launch_bounds__(SP_WG) void k_split_local(DbView db, const int32_t 
         uint4 *dst = (uint4 *)(reg + rb);                 // (a region starts at a multiple of SP_CAP tuples: 16-byte aligned; the last piece may carry up to 12 bytes beyond the pairs -- inside the area, inside the region, never read)
         for (uint32_t k = threadIdx.x; k < (nPairs * 3 + 3) / 4; k += SP_WG) dst[k] = src[k];
     }
-#if IGD_EXP & 0x1000000
-    IGD_QSTAMP(5);                                        // tuples issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    IGD_QSTAMP(6);                                        // stores drained
-#endif
 }
 
 #define SP_ROWS 4     // table rows a thread keeps in flight
@@ -244,7 +234,6 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
     __shared__ uint32_t wsum[SPF_WG / IGD_WAVE], baseSh;
     const int t0 = b << shift;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    IGD_QSTAMP(0);                                        // (diagnostic build, IGD_HIP_SPLIT_ONE=1: tools/sp_stamps.py fine)
     for (int f = threadIdx.x; f < F; f += SPF_WG) cnt[f] = 0;
     // The usual bucket (round 5): all of its segments are short and its pairs fit the workgroup's staging area (cap tuples
     // of LDS behind the counters).  One thread per segment walked its tuples one dependent load after the other, twice
@@ -266,7 +255,6 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         for (int o = 32; o > 0; o >>= 1) offs += (uint32_t)__shfl_xor((int)offs, o);
         if (lane == 63) { wsumN[wv] = incl; wsumO[wv] = offs; }
         anyLong = __syncthreads_or(anyLong);
-        IGD_QSTAMP(1);                                    // table column arrived, summed
         uint32_t at0 = incl - mine, N = 0, O = 0;
         for (int k = 0; k < SPF_WG / IGD_WAVE; k++) { if (k < wv) at0 += wsumN[k]; N += wsumN[k]; O += wsumO[k]; }
         if (!anyLong && N <= (uint32_t)cap) {
@@ -278,7 +266,6 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
                 for (int j = 0, c = (int)(e[r] >> 16); j < c; j++) stT[at0++] = at + (unsigned)j;
             }
             __syncthreads();
-            IGD_QSTAMP(2);                                // segments laid out
             // (eight in flight: a bucket of the benchmark's batch holds ~1400 tuples, 5-6 per thread -- in rounds of four the second
             // round trip, to tuples another XCD has just written, was a fifth of the workgroup's time)
             for (int k0 = 0; k0 < nStaged; k0 += SPF_FLY * SPF_WG) {
@@ -341,7 +328,6 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         }
     };
     if (nStaged < 0) walk([&](const SpTuple &tu) { atomicAdd(&cnt[tu.t - t0], 1u); });
-    IGD_QSTAMP(3);                                        // wave 0's tuples fetched, counted, staged
     __syncthreads();
     {   // exclusive prefix over the bucket's tiles: thread t owns F/SPF_WG consecutive tiles
         const int per0 = F >= SPF_WG ? F / SPF_WG : 1, f0 = threadIdx.x * per0;
@@ -374,18 +360,12 @@ __device__ __forceinline__ void split_fine_whole(int b, int nT, int shift, int n
         }
     }
     __syncthreads();
-    IGD_QSTAMP(4);                                        // tiles' first places known
     if (nStaged >= 0) {       // (placed straight from LDS; putting the bucket's pairs in order in LDS first and writing them out side by side
                               // -- what pays in k_split_local -- cost 3 us here: the places of one bucket lie within a dozen KB)
         for (int k = (int)threadIdx.x; k < nStaged; k += SPF_WG) {
             const uint32_t pos = atomicAdd(&start[stT[k]], 1u);
             pairs[pos] = make_int2((int)stS[k], (int)stE[k]);
         }
-#if IGD_EXP & 0x1000000
-        IGD_QSTAMP(5);                                    // pairs issued
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        IGD_QSTAMP(6);                                    // stores drained
-#endif
         return;
     }
     walk([&](const SpTuple &tu) {

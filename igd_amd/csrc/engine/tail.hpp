@@ -405,12 +405,6 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     const int lane = threadIdx.x & 63;
     // what the exact walks and the coverage find is counted in the workgroup's LDS first (when the files fit): a batch of
     // long queries makes one addition per (query, record) pair here
-#if IGD_EXP & 0x400000
-    u64 ts0 = __builtin_amdgcn_s_memtime(), ts1, ts2, ts3;
-#define IGD_TSTAMP(x) x = __builtin_amdgcn_s_memtime()
-#else
-#define IGD_TSTAMP(x) do { } while (0)
-#endif
     TailHist hist;
     hist.p = (igd_lds_u64 *)(smem + (K.a.tailHistOff >= 0 ? K.a.tailHistOff : 0));
     hist.on = false;
@@ -429,11 +423,8 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
     // workgroups flush 1900 LDS counters each -- slower, 560 -> 874 us for 10^6 queries of 100-200 kbp: the walks want the waves.)
     // (Tried: half the waves of a SIMD taking their coverage sums before their walks, so that the two kinds of work overlap:
     // 108.5 vs 109.1 us for 10^5 queries of 100-200 kbp -- both are bound by the instructions the launch's 4 waves per SIMD issue.)
-    IGD_TSTAMP(ts1);
     if (!(IGD_EXP & 0x100000)) exact_walk_body<USE_V>(K.db, wa, fixList, longList, gwave, nwaves, ctlv, hist);
-    IGD_TSTAMP(ts2);
     if (!(IGD_EXP & 0x200000)) coverage_body<USE_V>(K.db, wa, d_hits, d_total, gwave, nwaves, ctlv, hist);
-    IGD_TSTAMP(ts3);
     if (hist.on) {
         __syncthreads();
         for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
@@ -441,9 +432,6 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
             if (c) atomicAdd(&d_hits[f], c);
         }
     }
-#if IGD_EXP & 0x400000
-    if (lane == 0 && gwave < 16384) { u64 *o = d_tailSt + (size_t)gwave * 5; o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = __builtin_amdgcn_s_memtime(); }
-#endif
     if (valves & 1) heavy_bucket_body<USE_V>(K.db, wa, heavyB, d_hits, d_total, gwave, nwaves, lane, ctlv);
     if (valves & 8) {                                    // the batch took the DIRECT step (scan_direct.hpp): its dense tiles and deferred units
         DirArgs d;

@@ -107,9 +107,11 @@ typedef unsigned long long u64;
 #define IGD_EXP 0      // measurement-only builds (bits 1..512 and 8192 give WRONG counts): 1 no LDS flush, 2 no per-query compares,
                        // 4 no compares at all, 8 no later-tile queries, 64/128/256 rank method without term B / the searches of
                        // term A / prefix sums, 512 later-tile queries found but not searched, 8192 k_query_bounds without the
-                       // compaction of the later-tile words; 32 time stamps per wave (tools/stamps.py), 1024 section timers of the
-                       // rank method (printed by igd_hip_close); 0x10000 / 0x20000 the last launch without heavy_sorted_body /
-                       // far_units_body, 0x40000 / 0x80000 k_query_bounds without the firstQ[] fill / the head and tail fill, 0x100000 / 0x200000 the last launch without the exact walks / the coverage sums (WRONG counts); 0x400000 time stamps of the last launch's waves (tools/tail_stamps.py); 0x800000 k_query_bounds without the lpos[] stores of short gaps (WRONG counts); 0x1000000 time stamps of k_query_bounds' workgroups (tools/qb_stamps.py)
+                       // compaction of the later-tile words; 0x10000 / 0x20000 the last launch without heavy_sorted_body /
+                       // far_units_body, 0x40000 / 0x80000 k_query_bounds without the firstQ[] fill / the head and tail fill,
+                       // 0x100000 / 0x200000 the last launch without the exact walks / the coverage sums, 0x800000 k_query_bounds
+                       // without the lpos[] stores of short gaps (all WRONG counts).  (The time-stamp builds of rounds 2-5 -- bits 32,
+                       // 1024, 0x400000, 0x1000000 -- left the source in round 6; their results are in LABNOTES.md.)
 #endif
 #ifndef IGD_ASM_MATCH
 #define IGD_ASM_MATCH 1 // igd_scan_sorted's pairwise compare loop written out in assembly (0: the compiler's everywhere, 2: written out in the lean build only)
@@ -119,26 +121,6 @@ typedef unsigned long long u64;
 #endif
 #ifndef IGD_OPT_PRIO
 #define IGD_OPT_PRIO 1 // igd_scan_sorted: waves lower their issue priority as they get through their share
-#endif
-#if IGD_EXP & 1024
-// diagnostic build: the waves' time (s_memtime ticks) in the sections of the rank method, summed over all launches
-__device__ u64 d_sect[8];
-#define SECT(i) do { const u64 t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&hist[321 + (i)], (unsigned)(t_ - tsec)); tsec = t_; } while (0)   /* per wave, in spare words of its LDS histogram */
-#else
-#define SECT(i) do { } while (0)
-#endif
-#if IGD_EXP & 0x1000000
-__device__ u64 d_qbSt[8192 * 8];      // diagnostic build: s_memtime stamps of k_query_bounds' workgroups (wave 0): tools/qb_stamps.py
-#define IGD_QSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) d_qbSt[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define IGD_QSTAMP(k) do { } while (0)
-#endif
-#if IGD_EXP & 0x400000
-__device__ u64 d_tailSt[16384 * 5];   // diagnostic build: s_memtime stamps of the last launch's waves (start, counters cleared, walks done, sums done, end): tools/tail_stamps.py
-#endif
-#if IGD_EXP & 32
-static u64 *g_stamps = nullptr;     // diagnostic build: s_memtime stamps of the last igd_scan_sorted launch
-static int g_stampWaves = 0;
 #endif
 
 // ------------------------------------------------------------------------------------------
