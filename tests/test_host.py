@@ -214,6 +214,22 @@ def test_every_declared_function_is_exported(header, N):
     C.CDLL(lib)      # and it loads (HIP runtime resolves) without a GPU
 
 
+@pytest.mark.parametrize("env", [None, "37", "0", "999999999"])
+def test_lazy_binding_and_engine_agree_on_the_batch_limit(env, N):
+    """igd_hip_max_batch() is answered by the host flavours' lazy binding WITHOUT mapping the engine (igd_hip_lazy.c) and
+    by the engine itself (igd_hip.hip); both evaluate igd_hip_max_batch_rule() of include/igd_hip.h -- same value with and without
+    the test-only IGD_HIP_MAX_BATCH (each library in a fresh process: the engine reads the variable once)."""
+    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); L.igd_hip_max_batch.restype = ctypes.c_int64; print(L.igd_hip_max_batch())")
+    e = dict(os.environ)
+    e.pop("IGD_HIP_MAX_BATCH", None)
+    if env is not None:
+        e["IGD_HIP_MAX_BATCH"] = env
+    vals = [int(subprocess.run([sys.executable, "-c", code, os.path.join(N.LIBDIR, lib)], stdout=subprocess.PIPE, env=e, check=True).stdout)
+            for lib in ("libigd.so", "libigd_hip.so", "libigd_py.so")]
+    assert len(set(vals)) == 1, vals
+    assert vals[0] == (37 if env == "37" else 1 << 24)
+
+
 def test_cli_globals_are_exported(N):
     out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(N.LIBDIR, "libigd.so")],
                          stdout=subprocess.PIPE, check=True).stdout.decode()
