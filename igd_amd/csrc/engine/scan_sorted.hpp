@@ -75,6 +75,7 @@ __device__ __forceinline__ T karg_load(unsigned off)
 #define IGD_LN_G2(ln) (((ln) >> 26) & 3)
 #define IGD_LN_FAR(ln) (((ln) >> 28) & 1)
 struct SRegs { int32_t offLo, offHi, n, jf, w[IGD_SLOTS], f0, c0, la, ln; };
+typedef __attribute__((address_space(3))) u64 igd_lds_u64;      // a 64-bit counter in the workgroup's LDS (the batch's last launch)
 
 struct Raw2 {
     uint32_t a[IGD_SLOTS];       // s' | e' << 16 (inverted s', see k_pack_units)
@@ -313,7 +314,7 @@ __device__ __forceinline__ void far_later(const SortArgs &a, int la, int ln, int
 template <bool USE_V, bool CNT32, bool RANK, bool LDSH = false, int FEW = 0>
 __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, const SRegs &L, int kk, int lane, Raw2 &R,
                                           u64 *hits, unsigned short *sl, unsigned int *hist, unsigned short *sb, bool rankOK,
-                                          u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u)
+                                          u64 *found = nullptr, unsigned *spent = nullptr, unsigned budget = 0u, igd_lds_u64 *lhits = nullptr)
 {
     const int c0 = R.c0, ln = R.ln;
     const int un = R.n;
@@ -642,6 +643,17 @@ __device__ __forceinline__ void s_compute(const DbView &db, const SortArgs &a, c
             } else
             if ((!RANK && !few) || cnt[r]) atomicAdd((unsigned int *)hits + R.x[r], (unsigned)cnt[r]);
         }
+    } else
+    if (LDSH && lhits) {
+        // the skew valves of the batch's last launch: into the workgroup's 64-bit LDS counters, flushed once per workgroup.
+        // (Straight to hits[] these adds were the valves' cost: a piled-up tile's ~2000 slices all add to the SAME few hundred
+        // counters -- a dozen lines of hits[] -- and requests for one line are served one after the other: 58 of the 125 us of
+        // 10^6 queries inside one tile were far_units_body's slices waiting for each other's atomics.)
+#pragma unroll
+        for (int r = 0; r < IGD_SLOTS; r++) {
+            const int c = cnt[r];
+            if (c) (void)__hip_atomic_fetch_add(lhits + R.x[r], (u64)(unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     } else {
         u64 *gh = CNT32 ? KARG(hitsOut) : hits;          // (CNT32: the slab rows hold 32-bit counts, this unit's go to hits[] itself)
         if (CNT32) found = KARG(totalOut);
@@ -953,7 +965,7 @@ __attribute__((amdgpu_waves_per_eu(RANK ? IGD_WPE_RANK : IGD_WPE_LEAN, RANK ? IG
 // LDS area for the rank method.  Must sit in a kernel whose FIRST argument is the batch's SortK (KARG).
 template <bool USE_V, bool BIG>
 __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restrict__ d_hits, u64 *__restrict__ d_total,
-                                                  unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv)
+                                                  unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv, igd_lds_u64 *lhits = nullptr)
 {
     const DbView &db = K.db;
     const SortArgs &a = K.a;
@@ -992,7 +1004,7 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
             L.la = 0; L.ln = 0;
             Raw2 A;
             s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
-            s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
+            s_compute<USE_V, false, true, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total, nullptr, 0u, lhits);
         });
 }
 
@@ -1002,7 +1014,7 @@ __device__ __forceinline__ void heavy_sorted_body(const SortK &K, u64 *__restric
 // heavy_sorted_body, its first-tile queries, added to hits[] and the batch total with global atomics.
 template <bool USE_V, bool BIG>
 __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__ d_hits, u64 *__restrict__ d_total,
-                                               unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv)
+                                               unsigned char *wsm, int gwave, int nwaves, int lane, int ctlv, igd_lds_u64 *lhits = nullptr)
 {
     const DbView &db = K.db;
     const SortArgs &a = K.a;
@@ -1058,6 +1070,6 @@ __device__ __forceinline__ void far_units_body(const SortK &K, u64 *__restrict__
         if ((L.c0 | L.ln) == 0) continue;
         Raw2 A;
         s_issue<USE_V, BIG>(db, a, L, 0, true, lane, A);
-        s_compute<USE_V, false, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total);
+        s_compute<USE_V, false, true, true>(db, a, L, 0, lane, A, d_hits, sl, hist, sb, rankOK, d_total, nullptr, 0u, lhits);
     }
 }

@@ -9,7 +9,6 @@
 // be null, or point at global memory) the compiler emitted flat_atomic_add_x2 -- 138 of them in k_reduce_slabs, not one
 // ds_add_u64 -- and a flat atomic that resolves to LDS goes the vector-memory way round (address check in the texture
 // path, both counters) instead of straight to the LDS: the long queries' last launch spent most of its time there.
-typedef __attribute__((address_space(3))) u64 igd_lds_u64;
 struct TailHist {
     igd_lds_u64 *p;
     bool on;
@@ -444,8 +443,26 @@ __device__ __forceinline__ void batch_tail(const SortK &K, const ScanArgs &wa, c
         unsigned char *wsm = smem + (size_t)(threadIdx.x >> 6) * (size_t)K.a.wldsBytes;
         if (valves & 4) heavy_sorted_body<USE_V, true>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
         else {
-            if (!(IGD_EXP & 0x10000)) heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);
-            if (!(IGD_EXP & 0x20000)) far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv);   // (the lean build does not exist for BIG images)
+            // what the two valves count goes to the workgroup's LDS counters first (when the files fit and a valve has work:
+            // the same answer in every wave of the launch) and to hits[] once per workgroup
+            const int par = wa.epoch & 1;
+            const bool work = (__builtin_amdgcn_readlane(ctlv, CTL_NHEAVYS + par) | __builtin_amdgcn_readlane(ctlv, CTL_NFAR + par)) != 0 &&
+                              __builtin_amdgcn_readlane(ctlv, CTL_UNSORTED) != wa.epoch;
+            igd_lds_u64 *lh = (K.a.tailHistOff >= 0 && work) ? hist.p : nullptr;
+            if (lh) {
+                __syncthreads();                         // (the walks' flush above has read the counters)
+                for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) lh[f] = 0;
+                __syncthreads();
+            }
+            if (!(IGD_EXP & 0x10000)) heavy_sorted_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv, lh);
+            if (!(IGD_EXP & 0x20000)) far_units_body<USE_V, false>(K, d_hits, d_total, wsm, gwave, nwaves, lane, ctlv, lh);   // (the lean build does not exist for BIG images)
+            if (lh) {
+                __syncthreads();
+                for (int f = threadIdx.x; f < K.db.nFiles; f += blockDim.x) {
+                    const u64 c = lh[f];
+                    if (c) atomicAdd(&d_hits[f], c);
+                }
+            }
         }
     }
 }
