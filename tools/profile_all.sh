@@ -9,8 +9,10 @@ bash tools/profile.sh exact --exact-arrays > gpurun_out/p_exact.log 2>&1
 bash tools/profile.sh dense --queries 12500000 --steps 10 --warmup 2 --no-cpu > gpurun_out/p_dense.log 2>&1
 bash tools/profile.sh slab8 --slab-of 8 --steps 10 --warmup 2 --no-cpu > gpurun_out/p_slab8.log 2>&1
 bash tools/pmc_any.sh pmc_scan_sorted igd_scan_sorted > /dev/null 2>&1
-bash tools/pmc_any.sh pmc_scan_dense igd_scan_sorted --queries 12500000 > /dev/null 2>&1
-bash tools/pmc_any.sh pmc_scan_slab8 igd_scan_sorted --slab-of 8 > /dev/null 2>&1
+rm -rf gpurun_out/pmc_direct_dense gpurun_out/pmc_direct_slab8 gpurun_out/pmc_qb_slab8      # (never a stale summary of an earlier round)
+bash tools/pmc_any.sh pmc_direct_dense igd_scan_direct --queries 12500000 > /dev/null 2>&1
+bash tools/pmc_any.sh pmc_direct_slab8 igd_scan_direct --slab-of 8 > /dev/null 2>&1
+bash tools/pmc_any.sh pmc_qb_slab8 k_query_bounds --slab-of 8 > /dev/null 2>&1
 bash tools/pmc_any.sh pmc_qb_dense k_query_bounds --queries 12500000 > /dev/null 2>&1
 python tools/measure_misc.py > gpurun_out/misc.json 2> gpurun_out/misc.err
 bash tools/profile_create.sh > gpurun_out/p_create.log 2>&1
