@@ -25,6 +25,8 @@ p = pile(1)
 ichr = np.concatenate([d[0], p[0]]); qs = np.concatenate([d[1], p[1]]); qe = np.concatenate([d[2], p[2]])
 o = np.lexsort((qs, ichr))
 cases.append(("dense 1.25e7 + 10^6 in 1 tile", (ichr[o], qs[o], qe[o])))
+if len(sys.argv) > 1:                                   # `skew_probe.py 1`: only the cases whose name holds "in 1 tiles" (for rocprofv3 / counters)
+    cases = [c for c in cases if ("in %s tiles" % sys.argv[1]) in c[0] and not c[0].startswith("dense")]
 for name, q in cases:
     job = bench.Job(db, dev, st.cuda_stream, *q, 0, 1)
     el, prof = job.run(10, 2)
