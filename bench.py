@@ -18,7 +18,9 @@ RANK/WORLD_SIZE/MASTER_* in the environment; started as plain `python bench.py -
 process spawns the N ranks itself -- BEFORE it touches the GPU or imports torch -- and relays
 rank 0's JSON line.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with
+Prints ONE compact JSON line on rank 0 (contract in the task statement; at most LINE_CAP = 8 KB -- the driver keeps the last ~8 KB of
+stdout -- asserted here and in tests/test_gpu_bench_line.py) and writes the whole record, every side measurement in full, to
+bench_extra.json (--extra-out).  Both carry
   roofline     : dominant kernel (igd_scan_sorted; igd_scan_tiles on the bucket path).  `achieved` / `frac` price its HIP-event time
                  against the COMPULSORY bytes of the batch, computed in this run by the engine
                  (igd_hip_batch_traffic: every visited unit's records once in the bytes of the image
@@ -30,8 +32,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement), with
                  same .igd and the same queries as BED text, 1 thread; falls back to the oracle
                  port (kind "port") when the prebuilt reference binary did not travel.
   extra_configs: short timed runs of configs 3 (`-v 500`), shuffled input, config 4's per-GPU share
-                 (1.25e7 queries on one GPU), one GPU's slab of the 8-GPU job, two small batches and config 5 (`-f`)
-                 in the same process (N = 1 only).
+                 (1.25e7 queries on one GPU), one GPU's slab of the 2- / 4- / 8-GPU job, two small batches, the stress shapes
+                 (skew, long queries, clustered and sparse databases) and config 5 (`-f`, 8 and 16 bytes per overlap)
+                 in the same process (N = 1 only), each checked against the oracle's committed counts; the compact line
+                 keeps key, ms_per_step, kernel_ms, frac and matches_oracle of every row.
+  cli_end_to_end: the product command line on the workload's files, every size on BOTH routes (engine = MI355X, host = CPU
+                 threads for small files), each labelled with who counted.
 The oracle / reference are used here ONLY for that baseline and to check the GPU totals.
 """
 import argparse
