@@ -27,9 +27,8 @@ from test_gpu_rank import _dense_queries
 
 pytestmark = pytest.mark.gpu
 FLAG_SORTED, FLAG_SHORT = 1, 16
-# the DIRECT step's scan kernel: igd_scan_chunks (round 6: query-partitioned, no pre-pass) or, with IGD_HIP_CHUNKS=0 or when the
-# database does not fit it, round 5's igd_scan_direct behind the bounds-only pass
-DIRECT_KERNELS = ("igd_scan_direct", "igd_scan_chunks")
+# the DIRECT step's scan kernel (one name today; a tuple so that a second form of the step can be tried without touching the tests)
+DIRECT_KERNELS = ("igd_scan_direct",)
 
 
 @pytest.fixture(scope="module")
