@@ -228,6 +228,25 @@ def test_f_output_does_not_depend_on_the_number_of_formatting_threads():
             shutil.rmtree(d, ignore_errors=True)
 
 
+def test_f_output_is_the_references_through_both_record_widths():
+    """`-f` moves 8 bytes per overlap over PCIe when the database's records fit them (igd_hip_enumerate_stream8, round 6) and 16
+    otherwise (IGD_ENUM_HIT16=1 forces that stream): the text is the reference's recorded stdout either way, whole and in chunk
+    buffers of 50 overlaps (seams inside the formatter's expansion)."""
+    for case in ("smallrand", "edge", "gtype0", "quirk"):
+        d, dst, man = materialize(case)
+        try:
+            runs = [r for r in man["runs"] if "-f" in r["args"] and "-q" in r["args"]]
+            assert runs
+            for run in runs:
+                want = open(os.path.join(dst, run["stdout"])).read()
+                for env in ({}, {"IGD_ENUM_HIT16": "1"}, {"IGD_ENUM_CHUNK_HITS": "50"}, {"IGD_ENUM_HIT16": "1", "IGD_ENUM_CHUNK_HITS": "50"}):
+                    got = subprocess.run([os.path.join(ROOT, "bin", "igd")] + run["args"], cwd=dst, stdout=subprocess.PIPE, timeout=600,
+                                         env=dict(os.environ, IGD_HOST_MAX_QUERIES="0", **env)).stdout.decode()
+                    assert got == want, (case, env)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+
 def test_sorted_bed_with_another_chromosome_order_takes_the_merge_join():
     """`sort -k1,1 -k2,2n` orders chromosomes lexicographically, the database numbers contigs by first appearance: such a
     BED is one ordered run per contig, the runs out of contig order.  The host puts the runs into the database's order
